@@ -1,0 +1,104 @@
+"""Pins the CPU oracle (oracle/functional.py) against vectors produced by the REAL reference
+(tests/golden/*, written by oracle/make_golden.py in the build container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import functional as Fn
+from oracle import weights as W
+
+TOL = 2e-5  # fp32 re-association noise between two CPU op orders; outputs are O(1)
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) if v.shape else v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _schema(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def test_schema_unet_full(golden_dir):
+    ref = _schema(golden_dir, "schema_unet_full.json")
+    mine = W.unet_state_shapes(Fn.UNetConfig())
+    assert list(mine.keys()).__len__() == 1254
+    assert {k: tuple(v) for k, v in mine.items()} == ref
+
+
+def test_schema_unet_full_ip(golden_dir):
+    ref = _schema(golden_dir, "schema_unet_full_ip.json")
+    mine = W.unet_state_shapes(Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=16))
+    assert {k: tuple(v) for k, v in mine.items()} == ref
+
+
+def test_schema_tiny_and_vae(golden_dir):
+    assert {k: tuple(v) for k, v in W.unet_state_shapes(Fn.tiny_unet_config()).items()} == _schema(golden_dir, "schema_unet_tiny.json")
+    assert {k: tuple(v) for k, v in W.unet_state_shapes(Fn.tiny_unet_config(use_ip_cross_attention=True)).items()} == \
+        _schema(golden_dir, "schema_unet_tiny_ip.json")
+    assert {k: tuple(v) for k, v in W.vae_decoder_state_shapes(Fn.VAEConfig()).items()} == _schema(golden_dir, "schema_vae.json")
+
+
+def test_ddim_tables_and_step(golden_dir):
+    g = _load(golden_dir, "ddim.npz")
+    c = Fn.DDIMConfig()
+    abar = Fn.ddim_alphas_cumprod(c)
+    assert torch.equal(abar, g["alphas_cumprod"])          # same fp32 op sequence -> bit exact
+    assert abar[999].item() == 0.0
+    for n in (5, 25, 50):
+        assert torch.equal(Fn.ddim_timesteps(c, n), g[f"timesteps_{n}"])
+    assert Fn.ddim_timesteps(c, 25)[0].item() == 961
+    for t in (961, 1):
+        out = Fn.ddim_step(c, abar, 25, g["step_model_output"], t, g["step_sample"])
+        assert torch.allclose(out, g[f"step_out_t{t}"], atol=1e-6, rtol=0)
+
+
+def test_unet_forward_tiny(golden_dir):
+    g = _load(golden_dir, "unet_tiny_fwd.npz")
+    cfg = Fn.tiny_unet_config()
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["weight_seed"]))
+    with torch.no_grad():
+        y = Fn.unet3d_forward(sd, cfg, g["sample"], torch.tensor(int(g["timestep"])), g["text"], g["fps"], g["flow"])
+    assert y.shape == g["out"].shape
+    assert (y - g["out"]).abs().max().item() < TOL
+
+
+def test_unet_forward_tiny_ip(golden_dir):
+    g = _load(golden_dir, "unet_tiny_ip_fwd.npz")
+    cfg = Fn.tiny_unet_config(use_ip_cross_attention=True, ip_scale=0.7, ip_reference_cpu_scale_quirk=True)
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["weight_seed"]))
+    with torch.no_grad():
+        y = Fn.unet3d_forward(sd, cfg, g["sample"], torch.tensor(961), g["text"], g["fps"], g["flow"], g["ip_tokens"])
+    assert (y - g["out"]).abs().max().item() < TOL
+
+
+def test_vae_decode_tiny(golden_dir):
+    g = _load(golden_dir, "vae_tiny.npz")
+    vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))
+    sd = W.make_weights(W.vae_decoder_state_shapes(vcfg), int(g["weight_seed"]))
+    with torch.no_grad():
+        y = Fn.vae_decode(sd, vcfg, g["z"])
+    assert (y - g["out"]).abs().max().item() < TOL
+
+
+def test_pipeline_trajectory_tiny(golden_dir):
+    """Oracle denoise loop + decode vs AnimationPipeline.__call__ of the real reference."""
+    g = _load(golden_dir, "pipeline_tiny.npz")
+    cfg = Fn.tiny_unet_config()
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["unet_weight_seed"]))
+    traj = []
+    with torch.no_grad():
+        lat = Fn.denoise(sd, cfg, Fn.DDIMConfig(), g["latents"], g["text_embeddings"], 5, 8.0,
+                         g["first_image_latents"], g["first_images_mask"], torch.tensor([2]), torch.tensor([4]),
+                         callback=lambda i, t, l: traj.append(l.clone()))
+    traj = torch.stack(traj)
+    assert traj.shape == g["trajectory"].shape
+    err = (traj - g["trajectory"]).abs().amax(dim=(1, 2, 3, 4, 5))
+    assert err.max().item() < 1e-4, err
+    vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))
+    sdv = W.make_weights(W.vae_decoder_state_shapes(vcfg), int(g["vae_weight_seed"]))
+    with torch.no_grad():
+        vid = Fn.decode_latents(sdv, vcfg, lat)
+    assert (vid - g["videos"]).abs().max().item() < 1e-4
