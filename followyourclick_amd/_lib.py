@@ -1,0 +1,137 @@
+"""ctypes binding of libfyc_hip.so (include/fyc.h).  Fails loudly: there is no CPU fallback.
+
+The structures below mirror include/fyc.h field for field; tests/test_abi.py checks that every
+symbol the header declares is exported and that the struct sizes agree with a C compile of the header.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfyc_hip.so")
+
+FYC_F32, FYC_BF16 = 0, 1
+GEMM_PLAIN, GEMM_CONV3X3, GEMM_CONV3X3_UP2 = 0, 1, 2
+EPI_LINEAR, EPI_GEGLU, EPI_HEADS = 0, 1, 2
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("a", vp), ("w", vp), ("bias", vp), ("rowbias", vp), ("residual", vp), ("out", vp),
+                ("seg_out", vp * 3), ("seg_transposed", i32 * 3), ("seg_ld", i32 * 3),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldw", i32), ("ldo", i32), ("ldr", i32),
+                ("stride_a", i64), ("stride_w", i64), ("stride_o", i64),
+                ("batch", i32), ("mode", i32), ("epilogue", i32),
+                ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32),
+                ("rows_per_batch", i32), ("seg_cols", i32), ("heads", i32), ("tokens", i32),
+                ("out_scale", f32), ("dtype", i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp),
+                ("batch", i32), ("heads", i32), ("n_q", i32), ("n_k", i32), ("d", i32),
+                ("ldo", i32), ("ldvt", i32), ("kv_batch_div", i32), ("o_accumulate", i32),
+                ("scale", f32), ("o_scale", f32), ("dtype", i32)]
+
+
+class TAttnArgs(C.Structure):
+    _fields_ = [("qkv", vp), ("o", vp), ("clips", i32), ("frames", i32), ("pixels", i32), ("heads", i32), ("d", i32),
+                ("scale", f32), ("dtype", i32)]
+
+
+class GnStatsArgs(C.Structure):
+    _fields_ = [("x", vp), ("stats", vp), ("rows", i32), ("C", i32), ("groups", i32), ("rows_per_sample", i32), ("dtype", i32)]
+
+
+class GnApplyArgs(C.Structure):
+    _fields_ = [("x", vp), ("stats", vp), ("gamma", vp), ("beta", vp), ("y", vp),
+                ("rows", i32), ("C", i32), ("groups", i32), ("rows_per_sample", i32), ("eps", f32), ("silu", i32), ("dtype", i32)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("pe", vp), ("y", vp),
+                ("rows", i32), ("C", i32), ("eps", f32), ("pe_div", i32), ("pe_rows", i32), ("dtype", i32)]
+
+
+class SoftmaxArgs(C.Structure):
+    _fields_ = [("x", vp), ("rows", i64), ("cols", i32), ("ld", i32), ("dtype", i32)]
+
+
+class ConcatArgs(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("y", vp), ("rows", i64), ("c1", i32), ("c2", i32), ("dtype", i32)]
+
+
+class SiluArgs(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("n", i64)]
+
+
+class CastArgs(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("rows", i64), ("cols", i32), ("ld", i32), ("dtype", i32)]
+
+
+class UnetInputArgs(C.Structure):
+    _fields_ = [("latents", vp), ("mask", vp), ("first", vp), ("x", vp),
+                ("B", i32), ("F", i32), ("HW", i32), ("c_latent", i32), ("c_pad", i32), ("cfg_dup", i32), ("mask_frames", i32),
+                ("dtype", i32)]
+
+
+class CfgDdimArgs(C.Structure):
+    _fields_ = [("pred", vp), ("latents", vp), ("coef", vp),
+                ("B", i32), ("F", i32), ("HW", i32), ("c_latent", i32), ("ld", i32), ("cfg", i32), ("guidance", f32),
+                ("pred_type", i32), ("clip_sample", i32), ("dtype", i32)]
+
+
+class NchwInArgs(C.Structure):
+    _fields_ = [("z", vp), ("x", vp), ("N", i32), ("C", i32), ("HW", i32), ("c_pad", i32), ("scale", f32), ("dtype", i32)]
+
+
+class NhwcOutArgs(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("N", i32), ("C", i32), ("HW", i32), ("ld", i32),
+                ("mul", f32), ("add", f32), ("lo", f32), ("hi", f32), ("dtype", i32)]
+
+
+# name -> args struct for every `int fyc_<op>(const args*, void* stream)` entry point
+OPS = {
+    "fyc_gemm": GemmArgs, "fyc_attention": AttnArgs, "fyc_temporal_attention": TAttnArgs,
+    "fyc_gn_stats": GnStatsArgs, "fyc_gn_apply": GnApplyArgs, "fyc_layernorm": LayerNormArgs,
+    "fyc_softmax_rows": SoftmaxArgs, "fyc_concat_channels": ConcatArgs, "fyc_silu_f32": SiluArgs,
+    "fyc_cast_from_f32": CastArgs, "fyc_cast_to_f32": CastArgs, "fyc_unet_input": UnetInputArgs,
+    "fyc_cfg_ddim_step": CfgDdimArgs, "fyc_nchw_to_nhwc": NchwInArgs, "fyc_nhwc_to_nchw": NhwcOutArgs,
+}
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_gemm_staging"]
+
+_lib = None
+
+
+class FycError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FycError(f"{LIB_PATH} is missing: build it with `python -m followyourclick_amd._build` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.fyc_version.restype = C.c_int
+    lib.fyc_last_error.restype = C.c_char_p
+    lib.fyc_init.argtypes = [vp]
+    lib.fyc_device_caps.argtypes = [C.POINTER(i64)]
+    lib.fyc_set_gemm_staging.argtypes = [C.c_int]
+    for name, st in OPS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [C.POINTER(st), vp]
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise FycError(f"{what} failed (rc={rc}): {load().fyc_last_error().decode(errors='replace')}")

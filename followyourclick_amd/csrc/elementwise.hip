@@ -1,0 +1,229 @@
+// Small HBM-bound kernels around the UNet/VAE: layout changes at the API boundary
+// ((b,c,f,h,w) f32 <-> channels-last), channel concat, guidance + DDIM update, casts.
+#include "fyc_common.h"
+
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) concat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                                                     long long chunks, int c1_8, int c2_8) {
+  const int ct8 = c1_8 + c2_8;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long long)gridDim.x * 256) {
+    const long long row = idx / ct8;
+    const int c = (int)(idx - row * ct8);
+    const u32x4* src = (c < c1_8) ? reinterpret_cast<const u32x4*>(a) + (row * c1_8 + c) * (int)(sizeof(T) * 8 / 16)
+                                  : reinterpret_cast<const u32x4*>(b) + (row * c2_8 + (c - c1_8)) * (int)(sizeof(T) * 8 / 16);
+    u32x4* dst = reinterpret_cast<u32x4*>(y) + idx * (int)(sizeof(T) * 8 / 16);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) * 8 / 16); ++k) dst[k] = src[k];
+  }
+}
+
+__global__ void __launch_bounds__(256) silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = silu_f(x[i]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) cast_from_kernel(const float* __restrict__ x, T* __restrict__ y, long long rows, int cols, int ld) {
+  const long long n = rows * ld;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / ld;
+    const int c = (int)(i - r * ld);
+    ElemIO<T>::st(y + i, c < cols ? x[r * cols + c] : 0.f);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) cast_to_kernel(const T* __restrict__ x, float* __restrict__ y, long long rows, int cols, int ld) {
+  const long long n = rows * cols;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / cols;
+    const int c = (int)(i - r * cols);
+    y[i] = ElemIO<T>::ld(x + r * ld + c);
+  }
+}
+
+// one thread per output pixel-row (frame, pixel): writes c_pad channels
+template <typename T>
+__global__ void __launch_bounds__(256) unet_input_kernel(const float* __restrict__ lat, const float* __restrict__ mask,
+                                                         const float* __restrict__ first, T* __restrict__ x, int B, int F,
+                                                         int HW, int CL, int c_pad, int cfg_dup, int mask_frames) {
+  const long long total = (long long)cfg_dup * B * F * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const long long bf = i / HW;
+    const int f = (int)(bf % F);
+    const int b = (int)((bf / F) % B);  // CFG duplicates share the same latents
+    T* o = x + i * c_pad;
+    for (int c = 0; c < CL; ++c) ElemIO<T>::st(o + c, lat[(((long long)b * CL + c) * F + f) * HW + p]);
+    float m;
+    if (mask) {
+      const int mf = mask_frames > 1 ? f : 0;
+      m = fminf(fmaxf(mask[((long long)b * mask_frames + mf) * HW + p], 0.f), 1.f);
+    } else {
+      m = (f == 0) ? 1.f : 0.f;
+    }
+    ElemIO<T>::st(o + CL, m);
+    for (int c = 0; c < CL; ++c)
+      ElemIO<T>::st(o + CL + 1 + c, (f == 0 && first) ? first[((long long)b * CL + c) * HW + p] : 0.f);
+    for (int c = 2 * CL + 1; c < c_pad; ++c) ElemIO<T>::st(o + c, 0.f);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ pred, float* __restrict__ lat,
+                                                       const float* __restrict__ coef, int B, int F, int HW, int CL, int ld,
+                                                       int cfg, float guidance, int pred_type, int clip) {
+  const float sa = coef[0], sb = coef[1], sap = coef[2], sbp = coef[3];
+  const long long total = (long long)B * F * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const long long bf = i / HW;
+    const int f = (int)(bf % F), b = (int)(bf / F);
+    const T* pu = pred + i * ld;                                   // uncond (or the only) half
+    const T* pc = pred + ((long long)B * F * HW + i) * ld;         // cond half
+    for (int c = 0; c < CL; ++c) {
+      float v = ElemIO<T>::ld(pu + c);
+      if (cfg) v = v + guidance * (ElemIO<T>::ld(pc + c) - v);
+      float* lp = lat + (((long long)b * CL + c) * F + f) * HW + p;
+      const float x = *lp;
+      float x0, eps;
+      if (pred_type == 1) { x0 = sa * x - sb * v; eps = sa * v + sb * x; }
+      else if (pred_type == 0) { x0 = (x - sb * v) / sa; eps = v; }
+      else { x0 = v; eps = v; }
+      if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      *lp = sap * x0 + sbp * eps;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ z, T* __restrict__ x, int N, int C, int HW,
+                                                           int c_pad, float scale) {
+  const long long total = (long long)N * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const long long n = i / HW;
+    T* o = x + i * c_pad;
+    for (int c = 0; c < C; ++c) ElemIO<T>::st(o + c, z[(n * C + c) * HW + p] * scale);
+    for (int c = C; c < c_pad; ++c) ElemIO<T>::st(o + c, 0.f);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int C, int HW,
+                                                           int ld, float mul, float add, float lo, float hi) {
+  const long long total = (long long)N * C * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const long long nc = i / HW;
+    const int c = (int)(nc % C);
+    const long long n = nc / C;
+    const float v = ElemIO<T>::ld(x + (n * HW + p) * ld + c) * mul + add;
+    y[i] = fminf(fmaxf(v, lo), hi);
+  }
+}
+
+inline int grid_for(long long n) {
+  long long b = ceil_div64(n, 256);
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+#define FYC_DT(a, call_bf16, call_f32)                         \
+  do {                                                         \
+    if ((a)->dtype == FYC_BF16) { call_bf16; }                 \
+    else if ((a)->dtype == FYC_F32) { call_f32; }              \
+    else FYC_FAIL(-2, "bad dtype %d", (a)->dtype);             \
+  } while (0)
+
+extern "C" int fyc_concat_channels(const fyc_concat_args* a, void* stream) {
+  FYC_REQUIRE(a && a->a && a->b && a->y, "fyc_concat_channels: null pointer");
+  FYC_REQUIRE(a->c1 % 8 == 0 && a->c2 % 8 == 0 && a->rows > 0, "fyc_concat_channels: channels must be multiples of 8");
+  hipStream_t st = (hipStream_t)stream;
+  const long long chunks = a->rows * ((a->c1 + a->c2) / 8);
+  FYC_DT(a,
+         hipLaunchKernelGGL(concat_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, st, (const bf16_t*)a->a, (const bf16_t*)a->b, (bf16_t*)a->y, chunks, a->c1 / 8, a->c2 / 8),
+         hipLaunchKernelGGL(concat_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, st, (const float*)a->a, (const float*)a->b, (float*)a->y, chunks, a->c1 / 8, a->c2 / 8));
+  FYC_CHECK_LAUNCH("fyc_concat_channels");
+  return 0;
+}
+
+extern "C" int fyc_silu_f32(const fyc_silu_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->y && a->n > 0, "fyc_silu_f32: bad args");
+  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(a->n)), dim3(256), 0, (hipStream_t)stream, a->x, a->y, (long long)a->n);
+  FYC_CHECK_LAUNCH("fyc_silu_f32");
+  return 0;
+}
+
+extern "C" int fyc_cast_from_f32(const fyc_cast_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->y && a->rows > 0 && a->cols > 0 && a->ld >= a->cols, "fyc_cast_from_f32: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = a->rows * a->ld;
+  FYC_DT(a,
+         hipLaunchKernelGGL(cast_from_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->x, (bf16_t*)a->y, (long long)a->rows, a->cols, a->ld),
+         hipLaunchKernelGGL(cast_from_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->x, (float*)a->y, (long long)a->rows, a->cols, a->ld));
+  FYC_CHECK_LAUNCH("fyc_cast_from_f32");
+  return 0;
+}
+
+extern "C" int fyc_cast_to_f32(const fyc_cast_to_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->y && a->rows > 0 && a->cols > 0 && a->ld >= a->cols, "fyc_cast_to_f32: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = a->rows * a->cols;
+  FYC_DT(a,
+         hipLaunchKernelGGL(cast_to_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->x, a->y, (long long)a->rows, a->cols, a->ld),
+         hipLaunchKernelGGL(cast_to_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->x, a->y, (long long)a->rows, a->cols, a->ld));
+  FYC_CHECK_LAUNCH("fyc_cast_to_f32");
+  return 0;
+}
+
+extern "C" int fyc_unet_input(const fyc_unet_input_args* a, void* stream) {
+  FYC_REQUIRE(a && a->latents && a->x, "fyc_unet_input: null pointer");
+  FYC_REQUIRE(a->B > 0 && a->F > 0 && a->HW > 0 && a->c_latent > 0 && a->c_pad >= 2 * a->c_latent + 1, "fyc_unet_input: bad dims");
+  FYC_REQUIRE(a->cfg_dup == 1 || a->cfg_dup == 2, "fyc_unet_input: cfg_dup must be 1 or 2");
+  FYC_REQUIRE(a->mask == nullptr || a->mask_frames == 1 || a->mask_frames == a->F, "fyc_unet_input: mask_frames must be 1 or F");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)a->cfg_dup * a->B * a->F * a->HW;
+  const int mf = a->mask ? a->mask_frames : 1;
+  FYC_DT(a,
+         hipLaunchKernelGGL(unet_input_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (bf16_t*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf),
+         hipLaunchKernelGGL(unet_input_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (float*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf));
+  FYC_CHECK_LAUNCH("fyc_unet_input");
+  return 0;
+}
+
+extern "C" int fyc_cfg_ddim_step(const fyc_cfg_ddim_args* a, void* stream) {
+  FYC_REQUIRE(a && a->pred && a->latents && a->coef, "fyc_cfg_ddim_step: null pointer");
+  FYC_REQUIRE(a->B > 0 && a->F > 0 && a->HW > 0 && a->c_latent > 0 && a->ld >= a->c_latent, "fyc_cfg_ddim_step: bad dims");
+  FYC_REQUIRE(a->pred_type >= 0 && a->pred_type <= 2, "fyc_cfg_ddim_step: pred_type %d", a->pred_type);
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)a->B * a->F * a->HW;
+  FYC_DT(a,
+         hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample),
+         hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample));
+  FYC_CHECK_LAUNCH("fyc_cfg_ddim_step");
+  return 0;
+}
+
+extern "C" int fyc_nchw_to_nhwc(const fyc_nchw_in_args* a, void* stream) {
+  FYC_REQUIRE(a && a->z && a->x && a->N > 0 && a->C > 0 && a->HW > 0 && a->c_pad >= a->C, "fyc_nchw_to_nhwc: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)a->N * a->HW;
+  FYC_DT(a,
+         hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->z, (bf16_t*)a->x, a->N, a->C, a->HW, a->c_pad, a->scale),
+         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->z, (float*)a->x, a->N, a->C, a->HW, a->c_pad, a->scale));
+  FYC_CHECK_LAUNCH("fyc_nchw_to_nhwc");
+  return 0;
+}
+
+extern "C" int fyc_nhwc_to_nchw(const fyc_nhwc_out_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->y && a->N > 0 && a->C > 0 && a->HW > 0 && a->ld >= a->C, "fyc_nhwc_to_nchw: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)a->N * a->C * a->HW;
+  FYC_DT(a,
+         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->x, a->y, a->N, a->C, a->HW, a->ld, a->mul, a->add, a->lo, a->hi),
+         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->x, a->y, a->N, a->C, a->HW, a->ld, a->mul, a->add, a->lo, a->hi));
+  FYC_CHECK_LAUNCH("fyc_nhwc_to_nchw");
+  return 0;
+}

@@ -1,0 +1,125 @@
+// Shared device/host helpers for libfyc_hip.so (gfx950 only; wave64, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fyc.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define FYC_WAVE 64
+
+// ---- error plumbing (host) ----------------------------------------------------------------
+extern thread_local char g_fyc_err[512];
+extern const void* g_fyc_zero_page;
+extern int g_fyc_gemm_staging;
+
+#define FYC_FAIL(code, ...)                                   \
+  do {                                                        \
+    snprintf(g_fyc_err, sizeof(g_fyc_err), __VA_ARGS__);      \
+    return (code);                                            \
+  } while (0)
+
+#define FYC_REQUIRE(cond, ...)                                \
+  do {                                                        \
+    if (!(cond)) FYC_FAIL(-2, __VA_ARGS__);                   \
+  } while (0)
+
+#define FYC_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess) FYC_FAIL(-3, "%s launch failed: %s", name, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- dtype helpers (device) ---------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+// round-to-nearest-even, NaN preserved (same rounding torch uses for float->bfloat16)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  // 4 consecutive elements
+  __device__ static __forceinline__ void ld4(const float* p, float v[4]) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ static __forceinline__ void st4(float* p, const float v[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct ElemIO<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) {
+    return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p));
+  }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) {
+    *reinterpret_cast<unsigned short*>(p) = f32_to_bf16_bits(v);
+  }
+  __device__ static __forceinline__ void ld4(const bf16_t* p, float v[4]) {
+    u32x2 t = *reinterpret_cast<const u32x2*>(p);
+    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void st4(bf16_t* p, const float v[4]) {
+    u32x2 t;
+    t[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+    t[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    *reinterpret_cast<u32x2*>(p) = t;
+  }
+};
+
+// 8 consecutive elements as floats (two 16-B loads for f32, one for bf16)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+  ElemIO<float>::ld4(p, v); ElemIO<float>::ld4(p + 4, v + 4);
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
+  u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(t[i] << 16);
+    v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
+  ElemIO<float>::st4(p, v); ElemIO<float>::st4(p + 4, v + 4);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
+  u32x4 t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    t[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+  *reinterpret_cast<u32x4*>(p) = t;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

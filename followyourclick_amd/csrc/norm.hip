@@ -1,0 +1,239 @@
+// HBM-bound normalisation kernels (channels-last activations): GroupNorm statistics + apply(+SiLU),
+// LayerNorm(+positional table), row softmax.  All statistics in f32/f64; 16-byte vector I/O.
+#include "fyc_common.h"
+
+namespace {
+
+// ---- GroupNorm statistics ------------------------------------------------------------------
+// grid = (row_chunks, samples).  A block walks `rows_per_block` rows of one sample; thread t owns the
+// 8-channel chunk (t % C8) of rows (t / C8), (t / C8) + RPI, ...  Per-channel partial sums are folded
+// per group through LDS, then one f64 atomicAdd pair per (block, group).
+template <typename T>
+__global__ void __launch_bounds__(512) gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int C,
+                                                       int groups, int rows_per_sample, int rows_per_block) {
+  extern __shared__ float sh[];  // [2][groups]
+  const int tid = threadIdx.x, C8 = C >> 3, cpg = C / groups;
+  const int sample = blockIdx.y;
+  const int nthr = blockDim.x;
+  for (int i = tid; i < 2 * groups; i += nthr) sh[i] = 0.f;
+  __syncthreads();
+  const int rpi = nthr / C8;  // rows per iteration (host guarantees blockDim >= C/8)
+  const int row_begin = blockIdx.x * rows_per_block;
+  const int row_end = min(row_begin + rows_per_block, rows_per_sample);
+  const T* base = x + (long long)sample * rows_per_sample * C;
+  if (tid < rpi * C8) {
+    const int c8 = tid % C8, r0 = tid / C8;
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    for (int r = row_begin + r0; r < row_end; r += rpi) {
+      float v[8];
+      load8<T>(base + (long long)r * C + c8 * 8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
+    }
+    // fold the 8 channels into their groups (a chunk spans at most 8 groups; usually 1-2)
+    int gcur = (c8 * 8) / cpg;
+    float gs = 0.f, gq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gi = (c8 * 8 + i) / cpg;
+      if (gi != gcur) {
+        atomicAdd(&sh[gcur], gs); atomicAdd(&sh[groups + gcur], gq);
+        gcur = gi; gs = 0.f; gq = 0.f;
+      }
+      gs += s[i]; gq += q[i];
+    }
+    atomicAdd(&sh[gcur], gs); atomicAdd(&sh[groups + gcur], gq);
+  }
+  __syncthreads();
+  for (int gi = tid; gi < groups; gi += nthr) {
+    atomicAdd(&stats[((long long)sample * groups + gi) * 2 + 0], (double)sh[gi]);
+    atomicAdd(&stats[((long long)sample * groups + gi) * 2 + 1], (double)sh[groups + gi]);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, long long chunks, int C, int groups,
+                                                       int rows_per_sample, float eps, int silu) {
+  const int C8 = C >> 3, cpg = C / groups;
+  const double inv_cnt = 1.0 / ((double)rows_per_sample * cpg);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long long)gridDim.x * 256) {
+    const long long row = idx / C8;
+    const int c8 = (int)(idx - row * C8);
+    const int sample = (int)(row / rows_per_sample);
+    float v[8];
+    load8<T>(x + idx * 8, v);
+    int gprev = -1;
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c8 * 8 + i, gi = c / cpg;
+      if (gi != gprev) {
+        const double s = stats[((long long)sample * groups + gi) * 2], q = stats[((long long)sample * groups + gi) * 2 + 1];
+        const double m = s * inv_cnt;
+        double var = q * inv_cnt - m * m;
+        var = var > 0.0 ? var : 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+        gprev = gi;
+      }
+      float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      v[i] = silu ? silu_f(o) : o;
+    }
+    store8<T>(y + idx * 8, v);
+  }
+}
+
+// ---- LayerNorm: one wave per row -----------------------------------------------------------
+template <typename T, int MAXC8>  // MAXC8 chunks of 8 per lane
+__global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ pe,
+                                                        T* __restrict__ y, int rows, int C, float eps, int pe_div,
+                                                        int pe_rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int C8 = C >> 3;
+  const T* xr = x + (long long)row * C;
+  float v[MAXC8][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC8; ++k) {
+    const int c8 = lane + k * 64;
+    if (c8 < C8) {
+      load8<T>(xr + c8 * 8, v[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[k][i];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC8; ++k) {
+    const int c8 = lane + k * 64;
+    if (c8 < C8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const float* per = pe ? pe + (long long)((row / pe_div) % pe_rows) * C : nullptr;
+  T* yr = y + (long long)row * C;
+#pragma unroll
+  for (int k = 0; k < MAXC8; ++k) {
+    const int c8 = lane + k * 64;
+    if (c8 < C8) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        o[i] = (v[k][i] - mean) * rstd * gamma[c] + beta[c];
+        if (per) o[i] += per[c];
+      }
+      store8<T>(yr + c8 * 8, o);
+    }
+  }
+}
+
+// ---- row softmax in place: one block per row -------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(T* __restrict__ x, int cols, int ld) {
+  __shared__ float red[8];
+  T* xr = x + (long long)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -INFINITY;
+  for (int c = tid; c < cols; c += 256) m = fmaxf(m, ElemIO<T>::ld(xr + c));
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int c = tid; c < cols; c += 256) s += expf(ElemIO<T>::ld(xr + c) - m);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid; c < cols; c += 256) ElemIO<T>::st(xr + c, expf(ElemIO<T>::ld(xr + c) - m) * inv);
+}
+
+}  // namespace
+
+extern "C" int fyc_gn_stats(const fyc_gn_stats_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->stats, "fyc_gn_stats: null pointer");
+  FYC_REQUIRE(a->C % 8 == 0 && a->C <= 4096 && a->groups > 0 && a->C % a->groups == 0, "fyc_gn_stats: C=%d groups=%d", a->C, a->groups);
+  FYC_REQUIRE(a->rows_per_sample > 0 && a->rows % a->rows_per_sample == 0, "fyc_gn_stats: rows=%d rows_per_sample=%d", a->rows, a->rows_per_sample);
+  FYC_REQUIRE(a->C / 8 <= 512, "fyc_gn_stats: C too large");
+  hipStream_t st = (hipStream_t)stream;
+  const int samples = a->rows / a->rows_per_sample;
+  hipError_t e = hipMemsetAsync(a->stats, 0, sizeof(double) * 2 * samples * a->groups, st);
+  if (e != hipSuccess) FYC_FAIL(-3, "fyc_gn_stats: memset failed: %s", hipGetErrorString(e));
+  // aim for >= ~2048 blocks in total, >= 32 rows per block
+  int chunks = (int)ceil_div64(2048, samples);
+  int rpb = (int)ceil_div64(a->rows_per_sample, chunks);
+  if (rpb < 32) rpb = 32;
+  chunks = (int)ceil_div64(a->rows_per_sample, rpb);
+  dim3 grid(chunks, samples);
+  const size_t sh = sizeof(float) * 2 * a->groups;
+  const int c8 = a->C / 8;
+  const int nthr = c8 >= 256 ? ((c8 + 63) / 64) * 64 : 256;  // thread t <-> fixed 8-channel chunk t % c8
+  if (a->dtype == FYC_BF16)
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(nthr), sh, st, (const bf16_t*)a->x, a->stats, a->C, a->groups, a->rows_per_sample, rpb);
+  else if (a->dtype == FYC_F32)
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(nthr), sh, st, (const float*)a->x, a->stats, a->C, a->groups, a->rows_per_sample, rpb);
+  else FYC_FAIL(-2, "fyc_gn_stats: bad dtype");
+  FYC_CHECK_LAUNCH("fyc_gn_stats");
+  return 0;
+}
+
+extern "C" int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->stats && a->gamma && a->beta && a->y, "fyc_gn_apply: null pointer");
+  FYC_REQUIRE(a->C % 8 == 0 && a->groups > 0 && a->C % a->groups == 0, "fyc_gn_apply: C=%d groups=%d", a->C, a->groups);
+  FYC_REQUIRE(a->rows_per_sample > 0 && a->rows % a->rows_per_sample == 0, "fyc_gn_apply: rows/rows_per_sample");
+  hipStream_t st = (hipStream_t)stream;
+  const long long chunks = (long long)a->rows * (a->C / 8);
+  int blocks = (int)(ceil_div64(chunks, 256) < 8192 ? ceil_div64(chunks, 256) : 8192);
+  if (a->dtype == FYC_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a->x, a->stats, a->gamma, a->beta,
+                       (bf16_t*)a->y, chunks, a->C, a->groups, a->rows_per_sample, a->eps, a->silu);
+  else if (a->dtype == FYC_F32)
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a->x, a->stats, a->gamma, a->beta,
+                       (float*)a->y, chunks, a->C, a->groups, a->rows_per_sample, a->eps, a->silu);
+  else FYC_FAIL(-2, "fyc_gn_apply: bad dtype");
+  FYC_CHECK_LAUNCH("fyc_gn_apply");
+  return 0;
+}
+
+extern "C" int fyc_layernorm(const fyc_layernorm_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->gamma && a->beta && a->y, "fyc_layernorm: null pointer");
+  FYC_REQUIRE(a->C % 8 == 0 && a->C <= 2048 && a->rows > 0, "fyc_layernorm: C=%d (multiple of 8, <= 2048)", a->C);
+  FYC_REQUIRE(a->pe == nullptr || (a->pe_div > 0 && a->pe_rows > 0), "fyc_layernorm: pe_div/pe_rows");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((a->rows + 3) / 4);
+  const int pd = a->pe ? a->pe_div : 1, pr = a->pe ? a->pe_rows : 1;
+#define FYC_LN(T, MAXC8) hipLaunchKernelGGL((layernorm_kernel<T, MAXC8>), grid, dim3(256), 0, st, (const T*)a->x, a->gamma, a->beta, a->pe, (T*)a->y, a->rows, a->C, a->eps, pd, pr)
+  const int need = (a->C / 8 + 63) / 64;
+  if (a->dtype == FYC_BF16) {
+    if (need <= 1) FYC_LN(bf16_t, 1); else if (need <= 2) FYC_LN(bf16_t, 2); else FYC_LN(bf16_t, 4);
+  } else if (a->dtype == FYC_F32) {
+    if (need <= 1) FYC_LN(float, 1); else if (need <= 2) FYC_LN(float, 2); else FYC_LN(float, 4);
+  } else FYC_FAIL(-2, "fyc_layernorm: bad dtype");
+#undef FYC_LN
+  FYC_CHECK_LAUNCH("fyc_layernorm");
+  return 0;
+}
+
+extern "C" int fyc_softmax_rows(const fyc_softmax_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->rows > 0 && a->cols > 0 && a->ld >= a->cols, "fyc_softmax_rows: bad args");
+  FYC_REQUIRE(a->rows < (1ll << 31), "fyc_softmax_rows: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == FYC_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)a->rows), dim3(256), 0, st, (bf16_t*)a->x, a->cols, a->ld);
+  else if (a->dtype == FYC_F32)
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)a->rows), dim3(256), 0, st, (float*)a->x, a->cols, a->ld);
+  else FYC_FAIL(-2, "fyc_softmax_rows: bad dtype");
+  FYC_CHECK_LAUNCH("fyc_softmax_rows");
+  return 0;
+}

@@ -1,0 +1,206 @@
+"""Tensor-level wrappers over the C ABI (include/fyc.h).
+
+torch is plumbing here: it owns device memory and the stream; every op below only forwards raw
+``data_ptr()``s and sizes to libfyc_hip.so.  There is no CPU implementation in the product: a tensor
+that is not on a HIP device raises.  (The engine reaches these functions through the module-level
+``impl`` object so that the CPU test-suite can exercise the host orchestration with an op emulator
+that lives under tests/ - never in the product path.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return L.FYC_BF16
+    if t.dtype == torch.float32:
+        return L.FYC_F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.FycError("followyourclick_amd ops need HIP device tensors; there is no CPU fallback")
+    return t.data_ptr()
+
+
+def _f32(t: Optional[Tensor], what: str) -> Optional[int]:
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError(f"{what} must be float32")
+    return _p(t)
+
+
+class HipOps:
+    """The product backend: libfyc_hip.so on the current torch HIP stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = L.load()
+        self._zero = None
+        self._inited_dev = None
+
+    # -- library ---------------------------------------------------------------------------
+    def ensure_init(self, device: torch.device) -> None:
+        if self._inited_dev == device:
+            return
+        if not torch.cuda.is_available():
+            raise L.FycError("no HIP device visible: followyourclick_amd has no CPU fallback")
+        self._zero = torch.zeros(4096, dtype=torch.uint8, device=device)
+        L.check(self.lib.fyc_init(self._zero.data_ptr()), "fyc_init")
+        self._inited_dev = device
+
+    def device_caps(self):
+        caps = (L.i64 * 8)()
+        L.check(self.lib.fyc_device_caps(caps), "fyc_device_caps")
+        return list(caps)
+
+    def set_gemm_staging(self, staging: int) -> None:
+        L.check(self.lib.fyc_set_gemm_staging(staging), "fyc_set_gemm_staging")
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def _call(self, name: str, args) -> None:
+        L.check(getattr(self.lib, name)(C.byref(args), self._stream()), name)
+
+    # -- GEMM family -------------------------------------------------------------------------
+    def gemm(self, a: Tensor, w: Tensor, out: Optional[Tensor], *, M: int, N: int, K: int, lda: int, ldw: int,
+             ldo: int = 0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None, rows_per_batch: int = 1,
+             residual: Optional[Tensor] = None, ldr: int = 0, out_scale: float = 1.0, epilogue: int = L.EPI_LINEAR,
+             mode: int = L.GEMM_PLAIN, conv: Optional[dict] = None, batch: int = 1, stride_a: int = 0,
+             stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None) -> None:
+        self.ensure_init(a.device)
+        g = L.GemmArgs()
+        g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
+        g.residual, g.out = _p(residual), _p(out)
+        g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldr = M, N, K, lda, ldw, ldo, ldr
+        g.stride_a, g.stride_w, g.stride_o, g.batch = stride_a, stride_w, stride_o, batch
+        g.mode, g.epilogue, g.rows_per_batch, g.out_scale, g.dtype = mode, epilogue, rows_per_batch, out_scale, _dt(a)
+        if a.dtype != w.dtype:
+            raise TypeError(f"gemm: activation {a.dtype} vs weight {w.dtype}")
+        if conv is not None:
+            g.Hout, g.Wout, g.Hin, g.Win, g.Cin, g.conv_stride = (conv["Hout"], conv["Wout"], conv["Hin"], conv["Win"],
+                                                                  conv["Cin"], conv.get("stride", 1))
+        if heads is not None:
+            g.seg_cols, g.heads, g.tokens = heads["seg_cols"], heads["heads"], heads["tokens"]
+            for i, (t, tr, ld) in enumerate(zip(heads["outs"], heads["transposed"], heads["ld"])):
+                g.seg_out[i], g.seg_transposed[i], g.seg_ld[i] = _p(t), int(tr), int(ld)
+        self._call("fyc_gemm", g)
+
+    # -- attention ---------------------------------------------------------------------------
+    def attention(self, q: Tensor, k: Tensor, vt: Tensor, o: Tensor, *, batch: int, heads: int, n_q: int, n_k: int,
+                  d: int, ldo: int, ldvt: int, scale: float, kv_batch_div: int = 1, accumulate: bool = False,
+                  o_scale: float = 1.0) -> None:
+        self.ensure_init(q.device)
+        a = L.AttnArgs()
+        a.q, a.k, a.vt, a.o = _p(q), _p(k), _p(vt), _p(o)
+        a.batch, a.heads, a.n_q, a.n_k, a.d, a.ldo, a.ldvt = batch, heads, n_q, n_k, d, ldo, ldvt
+        a.kv_batch_div, a.o_accumulate, a.scale, a.o_scale, a.dtype = kv_batch_div, int(accumulate), scale, o_scale, _dt(q)
+        self._call("fyc_attention", a)
+
+    def temporal_attention(self, qkv: Tensor, o: Tensor, *, clips: int, frames: int, pixels: int, heads: int, d: int,
+                           scale: float) -> None:
+        self.ensure_init(qkv.device)
+        a = L.TAttnArgs()
+        a.qkv, a.o, a.clips, a.frames, a.pixels, a.heads, a.d, a.scale, a.dtype = (_p(qkv), _p(o), clips, frames, pixels,
+                                                                                  heads, d, scale, _dt(qkv))
+        self._call("fyc_temporal_attention", a)
+
+    # -- normalisation -----------------------------------------------------------------------
+    def gn_stats(self, x: Tensor, stats: Tensor, *, rows: int, C_: int, groups: int, rows_per_sample: int) -> None:
+        a = L.GnStatsArgs()
+        if stats.dtype != torch.float64:
+            raise TypeError("gn stats buffer must be float64")
+        a.x, a.stats, a.rows, a.C, a.groups, a.rows_per_sample, a.dtype = _p(x), _p(stats), rows, C_, groups, rows_per_sample, _dt(x)
+        self._call("fyc_gn_stats", a)
+
+    def gn_apply(self, x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, *, rows: int, C_: int,
+                 groups: int, rows_per_sample: int, eps: float, silu: bool) -> None:
+        a = L.GnApplyArgs()
+        a.x, a.stats, a.gamma, a.beta, a.y = _p(x), _p(stats), _f32(gamma, "gamma"), _f32(beta, "beta"), _p(y)
+        a.rows, a.C, a.groups, a.rows_per_sample, a.eps, a.silu, a.dtype = rows, C_, groups, rows_per_sample, eps, int(silu), _dt(x)
+        self._call("fyc_gn_apply", a)
+
+    def layernorm(self, x: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, *, rows: int, C_: int, eps: float = 1e-5,
+                  pe: Optional[Tensor] = None, pe_div: int = 1, pe_rows: int = 1) -> None:
+        a = L.LayerNormArgs()
+        a.x, a.gamma, a.beta, a.pe, a.y = _p(x), _f32(gamma, "gamma"), _f32(beta, "beta"), _f32(pe, "pe"), _p(y)
+        a.rows, a.C, a.eps, a.pe_div, a.pe_rows, a.dtype = rows, C_, eps, pe_div, pe_rows, _dt(x)
+        self._call("fyc_layernorm", a)
+
+    def softmax_rows(self, x: Tensor, *, rows: int, cols: int, ld: int) -> None:
+        a = L.SoftmaxArgs()
+        a.x, a.rows, a.cols, a.ld, a.dtype = _p(x), rows, cols, ld, _dt(x)
+        self._call("fyc_softmax_rows", a)
+
+    # -- elementwise / layout ------------------------------------------------------------------
+    def concat_channels(self, a_: Tensor, b_: Tensor, y: Tensor, *, rows: int, c1: int, c2: int) -> None:
+        a = L.ConcatArgs()
+        a.a, a.b, a.y, a.rows, a.c1, a.c2, a.dtype = _p(a_), _p(b_), _p(y), rows, c1, c2, _dt(a_)
+        self._call("fyc_concat_channels", a)
+
+    def silu_f32(self, x: Tensor, y: Tensor) -> None:
+        a = L.SiluArgs()
+        a.x, a.y, a.n = _f32(x, "x"), _f32(y, "y"), x.numel()
+        self._call("fyc_silu_f32", a)
+
+    def cast_from_f32(self, x: Tensor, y: Tensor, *, rows: int, cols: int, ld: int) -> None:
+        a = L.CastArgs()
+        a.x, a.y, a.rows, a.cols, a.ld, a.dtype = _f32(x, "x"), _p(y), rows, cols, ld, _dt(y)
+        self._call("fyc_cast_from_f32", a)
+
+    def cast_to_f32(self, x: Tensor, y: Tensor, *, rows: int, cols: int, ld: int) -> None:
+        a = L.CastArgs()
+        a.x, a.y, a.rows, a.cols, a.ld, a.dtype = _p(x), _f32(y, "y"), rows, cols, ld, _dt(x)
+        self._call("fyc_cast_to_f32", a)
+
+    def unet_input(self, latents: Tensor, mask: Optional[Tensor], first: Optional[Tensor], x: Tensor, *, B: int, F: int,
+                   HW: int, c_latent: int, c_pad: int, cfg_dup: int, mask_frames: int = 1) -> None:
+        self.ensure_init(latents.device)
+        a = L.UnetInputArgs()
+        a.latents, a.mask, a.first, a.x = _f32(latents, "latents"), _f32(mask, "mask"), _f32(first, "first"), _p(x)
+        a.B, a.F, a.HW, a.c_latent, a.c_pad, a.cfg_dup, a.mask_frames, a.dtype = B, F, HW, c_latent, c_pad, cfg_dup, mask_frames, _dt(x)
+        self._call("fyc_unet_input", a)
+
+    def cfg_ddim_step(self, pred: Tensor, latents: Tensor, coef: Tensor, *, B: int, F: int, HW: int, c_latent: int,
+                      ld: int, cfg: bool, guidance: float, pred_type: int, clip_sample: bool) -> None:
+        a = L.CfgDdimArgs()
+        a.pred, a.latents, a.coef = _p(pred), _f32(latents, "latents"), _f32(coef, "coef")
+        a.B, a.F, a.HW, a.c_latent, a.ld, a.cfg, a.guidance = B, F, HW, c_latent, ld, int(cfg), guidance
+        a.pred_type, a.clip_sample, a.dtype = pred_type, int(clip_sample), _dt(pred)
+        self._call("fyc_cfg_ddim_step", a)
+
+    def nchw_to_nhwc(self, z: Tensor, x: Tensor, *, N: int, C_: int, HW: int, c_pad: int, scale: float) -> None:
+        self.ensure_init(z.device)
+        a = L.NchwInArgs()
+        a.z, a.x, a.N, a.C, a.HW, a.c_pad, a.scale, a.dtype = _f32(z, "z"), _p(x), N, C_, HW, c_pad, scale, _dt(x)
+        self._call("fyc_nchw_to_nhwc", a)
+
+    def nhwc_to_nchw(self, x: Tensor, y: Tensor, *, N: int, C_: int, HW: int, ld: int, mul: float = 1.0, add: float = 0.0,
+                     lo: float = -3.0e38, hi: float = 3.0e38) -> None:
+        a = L.NhwcOutArgs()
+        a.x, a.y, a.N, a.C, a.HW, a.ld, a.mul, a.add, a.lo, a.hi, a.dtype = _p(x), _f32(y, "y"), N, C_, HW, ld, mul, add, lo, hi, _dt(x)
+        self._call("fyc_nhwc_to_nchw", a)
+
+
+impl = None  # type: Optional[HipOps]
+
+
+def get() -> HipOps:
+    """The active backend; created on first use.  Raises if libfyc_hip.so is missing."""
+    global impl
+    if impl is None:
+        impl = HipOps()
+    return impl

@@ -1,0 +1,199 @@
+/*
+ * fyc.h - C ABI of libfyc_hip.so, the MI355X (gfx950) compute library behind
+ * FollowYourClick's denoising hot path (AnimationPipeline.__call__ -> UNet3DConditionModel.forward
+ * -> DDIMScheduler.step -> vae.decode).
+ *
+ * The reference is 100 % Python and has no FFI of its own, so there is nothing
+ * to bind one-to-one; each entry point below names the reference op sequence (file:line under
+ * /root/reference) it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - every op: int fyc_<op>(const fyc_<op>_args*, void* hip_stream); 0 = ok, <0 = error,
+ *    fyc_last_error() returns the thread-local message.  Never throws, never exits.
+ *  - the callee never allocates, frees or synchronises: all tensors/workspaces are raw device
+ *    pointers owned by the caller; work is enqueued on `hip_stream` (hipGraph-capturable).
+ *  - activations are channels-last: [frames = B*F][H][W][C] (== token-major [rows][C]), element type
+ *    `dtype` (FYC_BF16 production, FYC_F32 parity mode); statistics, biases, norm affine
+ *    parameters, time-embedding rows and latents are always f32.
+ */
+#ifndef FYC_H
+#define FYC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FYC_VERSION 100
+
+typedef enum { FYC_F32 = 0, FYC_BF16 = 1 } fyc_dtype;
+
+/* ---- library ------------------------------------------------------------------------- */
+int fyc_version(void);
+const char* fyc_last_error(void);
+/* zero_page: >= 256 bytes of zeroed device memory owned by the caller for the life of the process
+ * (source for out-of-range / padding lanes of the direct-to-LDS loaders). */
+int fyc_init(const void* zero_page);
+/* fills caps[0..7]: CU count, LDS bytes/CU, wave size, gfx arch number (950), clock kHz, L2 bytes, 0, 0 */
+int fyc_device_caps(int64_t* caps);
+/* staging: 0 = direct global->LDS DMA (default), 1 = register staging (A/B test + bring-up hedge) */
+int fyc_set_gemm_staging(int staging);
+
+/* ---- GEMM / implicit-GEMM convolution --------------------------------------------------
+ * out[m][n] = ( sum_k A[m][k] * W[n][k] + bias[n] + rowbias[m / rows_per_batch][n] + residual[m][n] ) * out_scale
+ * Replaces: nn.Linear / 1x1 Conv2d everywhere on the path (diffusers/models/attention.py:600-623,
+ * 772-775; animatediff/models/attention.py:270-304; motion_module.py:191,199), InflatedConv3d 3x3
+ * (animatediff/models/resnet.py:19-27, 296-342), Downsample3D (:188-196), Upsample3D (:137-170),
+ * and the baddbmm/bmm of the materialised attention used in f32 parity mode and the VAE
+ * (diffusers/models/attention.py:342-368, 649-678).
+ */
+enum { FYC_GEMM_PLAIN = 0, FYC_GEMM_CONV3X3 = 1, FYC_GEMM_CONV3X3_UP2 = 2 };
+enum { FYC_EPI_LINEAR = 0, FYC_EPI_GEGLU = 1, FYC_EPI_HEADS = 2 };
+
+typedef struct {
+  const void* a;         /* PLAIN: [batch][M][lda]; CONV: NHWC input [frames][Hin][Win][Cin] */
+  const void* w;         /* [batch?][Nw][ldw], K contiguous; conv: K = 9*Cin ordered (ky,kx,ci) */
+  const float* bias;     /* [N] or NULL (GEGLU: packed order) */
+  const float* rowbias;  /* [M / rows_per_batch][N] or NULL (ResnetBlock3D time_emb_proj add) */
+  const void* residual;  /* [M][ldr] or NULL */
+  void* out;             /* LINEAR/GEGLU: [batch][M][ldo] */
+  void* seg_out[3];      /* HEADS: per column segment (q,k,v): [b][heads][tok][d] or transposed [b][heads][d][tok] */
+  int32_t seg_transposed[3];
+  int32_t seg_ld[3];     /* transposed segments: row pitch in elements (>= tokens; 0 = tokens) */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldo, ldr;
+  int64_t stride_a, stride_w, stride_o; /* batch strides in elements (0 = shared) */
+  int32_t batch;
+  int32_t mode;          /* FYC_GEMM_* */
+  int32_t epilogue;      /* FYC_EPI_* */
+  int32_t Hout, Wout, Hin, Win, Cin, conv_stride; /* conv modes */
+  int32_t rows_per_batch;
+  int32_t seg_cols, heads, tokens; /* HEADS: columns per segment (=heads*d), tokens per batch element */
+  float out_scale;
+  int32_t dtype;
+} fyc_gemm_args;
+int fyc_gemm(const fyc_gemm_args* a, void* stream);
+
+/* ---- fused flash attention (bf16 MFMA, online softmax) ----------------------------------
+ * o[b][tok][h*d + i] = softmax_k( q[b,h,tok,:] . k[b,h,key,:] * scale ) @ v
+ * Replaces CrossAttention._attention / xformers.memory_efficient_attention for spatial attn1 and
+ * attn2 (diffusers/models/attention.py:649-678, 723-730) and IPCrossAttention's two cores
+ * (animatediff/models/attention.py:88-120): with o_accumulate=1 the result is added to `o`
+ * scaled by o_scale (out = attn_text + scale * attn_ip).
+ * q,k: [BH][N][d]; vt: [BH][d][ldvt] (transposed V written by the HEADS epilogue). kv_batch_div: K/V batch
+ * index = (b / kv_batch_div) * heads + h  (text K/V are shared by the F frames of a clip).
+ */
+typedef struct {
+  const void* q; const void* k; const void* vt; void* o;
+  int32_t batch, heads, n_q, n_k, d;
+  int32_t ldo;           /* row stride of o in elements (token-major [batch*n_q][ldo]) */
+  int32_t ldvt;          /* row pitch of vt in elements: multiple of 8, >= n_k; pad keys must be finite (zero) */
+  int32_t kv_batch_div;
+  int32_t o_accumulate;
+  float scale, o_scale;
+  int32_t dtype;         /* FYC_BF16 only */
+} fyc_attn_args;
+int fyc_attention(const fyc_attn_args* a, void* stream);
+
+/* ---- temporal self-attention core of the motion module ------------------------------------
+ * For every (clip b, pixel p, head h): softmax over the F frames (motion_module.py:371-464 with
+ * mm_attn_cross.py:148-177).  qkv is the token-major output of the fused to_q|to_k|to_v GEMM,
+ * [(b f p)][3C]; o is token-major [(b f p)][C].  The '(b f) d c -> (b d) f c' transposes of the
+ * reference are index arithmetic here.
+ */
+typedef struct {
+  const void* qkv; void* o;
+  int32_t clips, frames, pixels, heads, d;
+  float scale;
+  int32_t dtype;
+} fyc_tattn_args;
+int fyc_temporal_attention(const fyc_tattn_args* a, void* stream);
+
+/* ---- normalisation -----------------------------------------------------------------------
+ * GroupNorm statistics over `rows_per_sample` rows x (C/groups) channels:
+ *   cross-frame (ResnetBlock3D.norm1/norm2, conv_norm_out: nn.GroupNorm on the 5-D tensor,
+ *   resnet.py:299,322; unet.py:665): rows_per_sample = F*H*W;
+ *   per-frame (Transformer3DModel.norm, TemporalTransformer3DModel.norm, VAE): rows_per_sample = H*W.
+ * stats: [samples][groups][2] doubles (sum, sum of squares), zeroed by the call.
+ */
+typedef struct {
+  const void* x; double* stats;
+  int32_t rows, C, groups, rows_per_sample;
+  int32_t dtype;
+} fyc_gn_stats_args;
+int fyc_gn_stats(const fyc_gn_stats_args* a, void* stream);
+
+/* y = (x - mean) * rstd * gamma[c] + beta[c], optional SiLU */
+typedef struct {
+  const void* x; const double* stats; const float* gamma; const float* beta; void* y;
+  int32_t rows, C, groups, rows_per_sample;
+  float eps; int32_t silu;
+  int32_t dtype;
+} fyc_gn_apply_args;
+int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream);
+
+/* LayerNorm over C (eps 1e-5, affine) + optional additive table pe[(row / pe_div) % pe_rows][c]
+ * (motion module: PositionalEncoding added to the normalised tokens, motion_module.py:272-278,377) */
+typedef struct {
+  const void* x; const float* gamma; const float* beta; const float* pe; void* y;
+  int32_t rows, C; float eps;
+  int32_t pe_div, pe_rows;
+  int32_t dtype;
+} fyc_layernorm_args;
+int fyc_layernorm(const fyc_layernorm_args* a, void* stream);
+
+/* row softmax (in place, f32 math): x [rows][ld], first `cols` columns (materialised attention) */
+typedef struct { void* x; int64_t rows; int32_t cols, ld; int32_t dtype; } fyc_softmax_args;
+int fyc_softmax_rows(const fyc_softmax_args* a, void* stream);
+
+/* ---- elementwise / layout ---------------------------------------------------------------- */
+/* y[r][0:c1] = a[r][:], y[r][c1:c1+c2] = b[r][:]  (torch.cat(dim=1) of unet_blocks.py:763,885) */
+typedef struct { const void* a; const void* b; void* y; int64_t rows; int32_t c1, c2; int32_t dtype; } fyc_concat_args;
+int fyc_concat_channels(const fyc_concat_args* a, void* stream);
+
+/* y = silu(x) (f32, small: time embeddings) */
+typedef struct { const float* x; float* y; int64_t n; } fyc_silu_args;
+int fyc_silu_f32(const fyc_silu_args* a, void* stream);
+
+/* f32 [rows][cols] -> dtype [rows][ld] (cols <= ld, tail zero filled) and back */
+typedef struct { const float* x; void* y; int64_t rows; int32_t cols, ld; int32_t dtype; } fyc_cast_args;
+int fyc_cast_from_f32(const fyc_cast_args* a, void* stream);
+typedef struct { const void* x; float* y; int64_t rows; int32_t cols, ld; int32_t dtype; } fyc_cast_to_args;
+int fyc_cast_to_f32(const fyc_cast_to_args* a, void* stream);
+
+/* Build the UNet input: latents (B,4,F,h,w) f32, mask (B,1,F|1,h,w) f32 or NULL, first-frame latents
+ * (B,4,h,w) f32 -> channels-last [cfg_dup*B*F][h*w][c_pad] with channels
+ * [latent(4) | mask(1) | first_frame_block(4) | 0...]  (pipeline_animation.py:693-711). */
+typedef struct {
+  const float* latents; const float* mask; const float* first; void* x;
+  int32_t B, F, HW, c_latent, c_pad, cfg_dup, mask_frames;
+  int32_t dtype;
+} fyc_unet_input_args;
+int fyc_unet_input(const fyc_unet_input_args* a, void* stream);
+
+/* Classifier-free guidance + DDIM update (eta = 0) in one pass (pipeline_animation.py:754-767,
+ * scheduling_ddim.py:308-349).  pred: channels-last [cfg*B*F][HW][ld] (uncond half first);
+ * latents (B,4,F,h,w) f32 updated in place.  coef (device f32[4], host-precomputed from the
+ * alphas_cumprod table, so the loop has no GPU->CPU sync) = {sqrt(abar_t), sqrt(1-abar_t),
+ * sqrt(abar_prev), sqrt(1-abar_prev)}.  pred_type: 0 epsilon, 1 v_prediction, 2 sample. */
+typedef struct {
+  const void* pred; float* latents; const float* coef;
+  int32_t B, F, HW, c_latent, ld, cfg; float guidance;
+  int32_t pred_type, clip_sample;
+  int32_t dtype;
+} fyc_cfg_ddim_args;
+int fyc_cfg_ddim_step(const fyc_cfg_ddim_args* a, void* stream);
+
+/* VAE ends: z (N,4,h,w) f32 * scale -> channels-last [N][hw][c_pad];
+ * image channels-last [N][HW][ld] -> (N,3,H,W) f32 = clamp(x/2+0.5, 0, 1) (pipeline_animation.py:402,410) */
+typedef struct { const float* z; void* x; int32_t N, C, HW, c_pad; float scale; int32_t dtype; } fyc_nchw_in_args;
+int fyc_nchw_to_nhwc(const fyc_nchw_in_args* a, void* stream);
+typedef struct { const void* x; float* y; int32_t N, C, HW, ld; float mul, add, lo, hi; int32_t dtype; } fyc_nhwc_out_args;
+int fyc_nhwc_to_nchw(const fyc_nhwc_out_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FYC_H */

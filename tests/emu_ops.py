@@ -1,0 +1,207 @@
+"""Torch-CPU emulation of the C ABI ops (TEST INFRASTRUCTURE, never imported by the product).
+
+Two uses:
+  * `-m "not gpu"` tests swap this in for `followyourclick_amd.ops.impl` to check the *host
+    orchestration* (layouts, weight packing, residual wiring, scheduler tables) of the engine against
+    the oracle without a GPU;
+  * `-m gpu` tests use it as the per-op specification the HIP kernels are compared with.
+It mirrors the buffer layouts of include/fyc.h exactly (flat buffers + leading dimensions).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+PLAIN, CONV, CONV_UP2 = 0, 1, 2
+LINEAR, GEGLU, HEADS = 0, 1, 2
+
+
+def _flat(t):
+    return t.reshape(-1)
+
+
+class EmuOps:
+    name = "emu"
+
+    def __init__(self, acc=torch.float32):
+        self.acc = acc
+
+    def ensure_init(self, device):
+        pass
+
+    def set_gemm_staging(self, s):
+        pass
+
+    # ------------------------------------------------------------------------------------
+    def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
+             ldr=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
+             heads=None):
+        acc_t = self.acc
+        af, wf = _flat(a), _flat(w)
+        for z in range(batch):
+            W = torch.as_strided(wf, (N, K), (ldw, 1), z * stride_w).to(acc_t)
+            if mode == PLAIN:
+                A = torch.as_strided(af, (M, K), (lda, 1), z * stride_a).to(acc_t)
+                acc = A @ W.t()
+            else:
+                Hin, Win, Cin, Hout, Wout = conv["Hin"], conv["Win"], conv["Cin"], conv["Hout"], conv["Wout"]
+                frames = M // (Hout * Wout)
+                x = af[: frames * Hin * Win * Cin].reshape(frames, Hin, Win, Cin).permute(0, 3, 1, 2).to(acc_t)
+                if mode == CONV_UP2:
+                    x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+                    stride = 1
+                else:
+                    stride = conv.get("stride", 1)
+                w4 = W.reshape(N, 3, 3, Cin).permute(0, 3, 1, 2)
+                y = F.conv2d(x, w4, None, stride=stride, padding=1)
+                assert y.shape[2] == Hout and y.shape[3] == Wout, (y.shape, Hout, Wout)
+                acc = y.permute(0, 2, 3, 1).reshape(M, N)
+            if bias is not None:
+                acc = acc + bias.to(acc_t)[None, :N]
+            if rowbias is not None:
+                rb = rowbias.reshape(-1, N).to(acc_t)
+                acc = acc + rb.repeat_interleave(rows_per_batch, dim=0)[:M]
+            if epilogue == GEGLU:
+                blk = acc.reshape(M, N // 32, 2, 16)
+                y = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(M, N // 2)
+                o = torch.as_strided(_flat(out), (M, N // 2), (ldo, 1), z * stride_o)
+                o.copy_(y.to(out.dtype))
+            elif epilogue == LINEAR:
+                if residual is not None:
+                    acc = acc + torch.as_strided(_flat(residual), (M, N), (ldr, 1), 0).to(acc_t)
+                acc = acc * out_scale
+                o = torch.as_strided(_flat(out), (M, N), (ldo, 1), z * stride_o)
+                o.copy_(acc.to(out.dtype))
+            else:
+                acc = acc * out_scale
+                sc, H, T = heads["seg_cols"], heads["heads"], heads["tokens"]
+                d, Bn = sc // H, M // T
+                for s, (t, tr, ld) in enumerate(zip(heads["outs"], heads["transposed"], heads["ld"])):
+                    seg = acc[:, s * sc:(s + 1) * sc].reshape(Bn, T, H, d)
+                    if not tr:
+                        _flat(t)[: Bn * H * T * d].reshape(Bn, H, T, d).copy_(seg.permute(0, 2, 1, 3).to(t.dtype))
+                    else:
+                        ld = ld if ld > 0 else T
+                        v = torch.as_strided(_flat(t), (Bn, H, d, T), (H * d * ld, d * ld, ld, 1), 0)
+                        v.copy_(seg.permute(0, 2, 3, 1).to(t.dtype))
+
+    # ------------------------------------------------------------------------------------
+    def attention(self, q, k, vt, o, *, batch, heads, n_q, n_k, d, ldo, ldvt, scale, kv_batch_div=1, accumulate=False,
+                  o_scale=1.0):
+        acc_t = self.acc
+        Q = _flat(q)[: batch * heads * n_q * d].reshape(batch, heads, n_q, d).to(acc_t)
+        kvB = (batch + kv_batch_div - 1) // kv_batch_div
+        Kt = _flat(k)[: kvB * heads * n_k * d].reshape(kvB, heads, n_k, d).to(acc_t)
+        Vt = torch.as_strided(_flat(vt), (kvB, heads, d, n_k), (heads * d * ldvt, d * ldvt, ldvt, 1), 0).to(acc_t)
+        idx = torch.arange(batch) // kv_batch_div
+        S = torch.matmul(Q, Kt[idx].transpose(-1, -2)) * scale
+        P = S.softmax(dim=-1)
+        if q.dtype == torch.bfloat16:
+            P = P.to(torch.bfloat16).to(acc_t)  # the kernel feeds bf16 probabilities to the MFMA
+        O = torch.matmul(P, Vt[idx].transpose(-1, -2))           # b h n d
+        O = O.permute(0, 2, 1, 3).reshape(batch * n_q, heads * d)
+        dst = torch.as_strided(_flat(o), (batch * n_q, heads * d), (ldo, 1), 0)
+        if accumulate:
+            O = dst.to(acc_t) + o_scale * O
+        dst.copy_(O.to(o.dtype))
+
+    def temporal_attention(self, qkv, o, *, clips, frames, pixels, heads, d, scale):
+        acc_t = self.acc
+        Cc = heads * d
+        x = _flat(qkv)[: clips * frames * pixels * 3 * Cc].reshape(clips, frames, pixels, 3, heads, d).to(acc_t)
+        q, k, v = x[:, :, :, 0], x[:, :, :, 1], x[:, :, :, 2]          # b f p h d
+        q, k, v = (t.permute(0, 2, 3, 1, 4) for t in (q, k, v))          # b p h f d
+        P = (torch.matmul(q, k.transpose(-1, -2)) * scale).softmax(dim=-1)
+        if qkv.dtype == torch.bfloat16:
+            P = P.to(torch.bfloat16).to(acc_t)
+        O = torch.matmul(P, v).permute(0, 3, 1, 2, 4).reshape(clips * frames * pixels, Cc)
+        _flat(o)[: O.numel()].reshape(O.shape).copy_(O.to(o.dtype))
+
+    # ------------------------------------------------------------------------------------
+    def gn_stats(self, x, stats, *, rows, C_, groups, rows_per_sample):
+        xs = _flat(x)[: rows * C_].reshape(rows // rows_per_sample, rows_per_sample, groups, C_ // groups).double()
+        stats.reshape(-1)[: xs.shape[0] * groups * 2].reshape(xs.shape[0], groups, 2).copy_(
+            torch.stack([xs.sum(dim=(1, 3)), (xs * xs).sum(dim=(1, 3))], dim=-1))
+
+    def gn_apply(self, x, stats, gamma, beta, y, *, rows, C_, groups, rows_per_sample, eps, silu):
+        S = rows // rows_per_sample
+        cpg = C_ // groups
+        st = stats.reshape(-1)[: S * groups * 2].reshape(S, groups, 2)
+        cnt = rows_per_sample * cpg
+        mean = st[..., 0] / cnt
+        var = (st[..., 1] / cnt - mean * mean).clamp_min(0)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        xs = _flat(x)[: rows * C_].reshape(S, rows_per_sample, groups, cpg).float()
+        yv = (xs - mean.float()[:, None, :, None]) * rstd.float()[:, None, :, None]
+        yv = yv.reshape(S, rows_per_sample, C_) * gamma.float() + beta.float()
+        if silu:
+            yv = F.silu(yv)
+        _flat(y)[: rows * C_].reshape(S, rows_per_sample, C_).copy_(yv.to(y.dtype))
+
+    def layernorm(self, x, gamma, beta, y, *, rows, C_, eps=1e-5, pe=None, pe_div=1, pe_rows=1):
+        xs = _flat(x)[: rows * C_].reshape(rows, C_).float()
+        yv = F.layer_norm(xs, (C_,), gamma.float(), beta.float(), eps)
+        if pe is not None:
+            idx = (torch.arange(rows) // pe_div) % pe_rows
+            yv = yv + pe.reshape(-1, C_)[idx].float()
+        _flat(y)[: rows * C_].reshape(rows, C_).copy_(yv.to(y.dtype))
+
+    def softmax_rows(self, x, *, rows, cols, ld):
+        v = torch.as_strided(_flat(x), (rows, cols), (ld, 1), 0)
+        v.copy_(v.float().softmax(dim=-1).to(x.dtype))
+
+    # ------------------------------------------------------------------------------------
+    def concat_channels(self, a_, b_, y, *, rows, c1, c2):
+        _flat(y)[: rows * (c1 + c2)].reshape(rows, c1 + c2).copy_(
+            torch.cat([_flat(a_)[: rows * c1].reshape(rows, c1), _flat(b_)[: rows * c2].reshape(rows, c2)], dim=1))
+
+    def silu_f32(self, x, y):
+        y.copy_(F.silu(x))
+
+    def cast_from_f32(self, x, y, *, rows, cols, ld):
+        v = _flat(y)[: rows * ld].reshape(rows, ld)
+        v.zero_()
+        v[:, :cols].copy_(_flat(x)[: rows * cols].reshape(rows, cols).to(y.dtype))
+
+    def cast_to_f32(self, x, y, *, rows, cols, ld):
+        _flat(y)[: rows * cols].reshape(rows, cols).copy_(_flat(x)[: rows * ld].reshape(rows, ld)[:, :cols].float())
+
+    def unet_input(self, latents, mask, first, x, *, B, F, HW, c_latent, c_pad, cfg_dup, mask_frames=1):
+        lat = latents.reshape(B, c_latent, F, HW)
+        out = torch.zeros(B, F, HW, c_pad)
+        out[..., :c_latent] = lat.permute(0, 2, 3, 1)
+        if mask is not None:
+            m = mask.reshape(B, mask_frames, HW).clamp(0, 1)
+            out[..., c_latent] = m if mask_frames > 1 else m.expand(B, F, HW)
+        else:
+            out[:, 0, :, c_latent] = 1.0
+        if first is not None:
+            out[:, 0, :, c_latent + 1: 2 * c_latent + 1] = first.reshape(B, c_latent, HW).permute(0, 2, 1)
+        out = torch.cat([out] * cfg_dup, dim=0)
+        _flat(x)[: out.numel()].reshape(out.shape).copy_(out.to(x.dtype))
+
+    def cfg_ddim_step(self, pred, latents, coef, *, B, F, HW, c_latent, ld, cfg, guidance, pred_type, clip_sample):
+        n = (2 if cfg else 1) * B * F * HW
+        p = _flat(pred)[: n * ld].reshape(-1, B, F, HW, ld)[..., :c_latent].float()
+        v = p[0] + guidance * (p[1] - p[0]) if cfg else p[0]
+        v = v.permute(0, 3, 1, 2)                                  # B C F HW
+        x = latents.reshape(B, c_latent, F, HW)
+        sa, sb, sap, sbp = [float(c) for c in coef.reshape(-1)[:4]]
+        if pred_type == 1:
+            x0, eps = sa * x - sb * v, sa * v + sb * x
+        elif pred_type == 0:
+            x0, eps = (x - sb * v) / sa, v
+        else:
+            x0, eps = v, v
+        if clip_sample:
+            x0 = x0.clamp(-1, 1)
+        x.copy_(sap * x0 + sbp * eps)
+
+    def nchw_to_nhwc(self, z, x, *, N, C_, HW, c_pad, scale):
+        out = torch.zeros(N, HW, c_pad)
+        out[..., :C_] = z.reshape(N, C_, HW).permute(0, 2, 1) * scale
+        _flat(x)[: out.numel()].reshape(out.shape).copy_(out.to(x.dtype))
+
+    def nhwc_to_nchw(self, x, y, *, N, C_, HW, ld, mul=1.0, add=0.0, lo=-3.0e38, hi=3.0e38):
+        v = _flat(x)[: N * HW * ld].reshape(N, HW, ld)[..., :C_].float() * mul + add
+        _flat(y)[: N * C_ * HW].reshape(N, C_, HW).copy_(v.clamp(lo, hi).permute(0, 2, 1))

@@ -1,0 +1,317 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against the torch-CPU op specification
+(tests/emu_ops.py).  Tolerances: f32 mode rel-L2 <= 2e-5; bf16 mode rel-L2 <= 4e-3 (inputs are the
+same bf16 values on both sides, so the only differences are accumulation order and the final
+round-to-bf16)."""
+import math
+
+import pytest
+import torch
+
+from emu_ops import EmuOps
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": torch.bfloat16, "f32": torch.float32}
+RTOL = {"bf16": 4e-3, "f32": 2e-5}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from followyourclick_amd import ops
+    h = ops.get()
+    h.ensure_init(torch.device("cuda:0"))
+    return h
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return EmuOps(acc=torch.float64)
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def close(hip_t, emu_t, tag, rtol):
+    a, b = hip_t.detach().cpu().double().reshape(-1), emu_t.detach().double().reshape(-1)
+    assert a.shape == b.shape, (tag, a.shape, b.shape)
+    assert torch.isfinite(a).all(), f"{tag}: non-finite values in HIP output ({(~torch.isfinite(a)).sum().item()} of {a.numel()})"
+    err = (a - b).norm() / (b.norm() + 1e-30)
+    mx = (a - b).abs().max().item()
+    bad = ((a - b).abs() > 10 * rtol * (b.abs().max() + 1e-30)).nonzero().reshape(-1)
+    assert err.item() <= rtol, (f"{tag}: rel-L2 {err.item():.3e} > {rtol:.1e}; max abs {mx:.3e} (ref max {b.abs().max().item():.3e}); "
+                                f"{bad.numel()}/{a.numel()} elements off, first at {bad[:8].tolist()}")
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("staging", [0, 1])
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (300, 320, 320), (154, 64, 768), (8, 256, 64), (1000, 960, 40), (513, 4, 576)])
+def test_gemm_plain(hip, emu, dt, staging, M, N, K):
+    T = DT[dt]
+    a, w = rnd((M, K), T, 1), rnd((N, K), T, 2, 1 / math.sqrt(K))
+    bias, res = rnd((N,), torch.float32, 3), rnd((M, N), T, 4)
+    rpb = 50
+    rowb = rnd(((M + rpb - 1) // rpb, N), torch.float32, 5)
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, rows_per_batch=rpb, out_scale=0.75)
+    hip.set_gemm_staging(staging)
+    try:
+        o_h = torch.full((M, N), float("nan"), dtype=T, device="cuda")
+        hip.gemm(a.cuda(), w.cuda(), o_h, bias=bias.cuda(), rowbias=rowb.cuda(), residual=res.cuda(), **kw)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_gemm_staging(0)
+    o_e = torch.zeros(M, N, dtype=T)
+    emu.gemm(a, w, o_e, bias=bias, rowbias=rowb, residual=res, **kw)
+    close(o_h, o_e, f"gemm {dt} {M}x{N}x{K} staging={staging}", RTOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("mode,stride,frames,H,W,Cin,Cout", [
+    (1, 1, 3, 8, 8, 64, 64), (1, 1, 2, 16, 12, 128, 320), (1, 2, 2, 16, 16, 64, 128), (2, 1, 2, 6, 5, 64, 64),
+    (1, 1, 5, 1, 1, 64, 64), (1, 1, 1, 32, 32, 192, 4), (1, 2, 3, 2, 2, 64, 64)])
+def test_gemm_conv(hip, emu, dt, mode, stride, frames, H, W, Cin, Cout):
+    T = DT[dt]
+    Ho, Wo = (2 * H, 2 * W) if mode == 2 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+    M, K = frames * Ho * Wo, 9 * Cin
+    x, w = rnd((frames * H * W, Cin), T, 1), rnd((Cout, K), T, 2, 1 / math.sqrt(K))
+    bias = rnd((Cout,), torch.float32, 3)
+    rowb = rnd((frames, Cout), torch.float32, 5)
+    res = rnd((M, Cout), T, 6)
+    conv = dict(Hout=Ho, Wout=Wo, Hin=H, Win=W, Cin=Cin, stride=stride)
+    kw = dict(M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, ldr=Cout, mode=mode, conv=conv, rows_per_batch=Ho * Wo)
+    o_h = torch.full((M, Cout), float("nan"), dtype=T, device="cuda")
+    hip.gemm(x.cuda(), w.cuda(), o_h, bias=bias.cuda(), rowbias=rowb.cuda(), residual=res.cuda(), **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(M, Cout, dtype=T)
+    emu.gemm(x, w, o_e, bias=bias, rowbias=rowb, residual=res, **kw)
+    close(o_h, o_e, f"conv {dt} mode={mode} s={stride} {frames}x{H}x{W} {Cin}->{Cout}", RTOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_gemm_geglu(hip, emu, dt):
+    T = DT[dt]
+    M, C = 200, 64
+    a, w, bias = rnd((M, C), T, 1), rnd((8 * C, C), T, 2, 1 / 8), rnd((8 * C,), torch.float32, 3)
+    kw = dict(M=M, N=8 * C, K=C, lda=C, ldw=C, ldo=4 * C, epilogue=1)
+    o_h = torch.full((M, 4 * C), float("nan"), dtype=T, device="cuda")
+    hip.gemm(a.cuda(), w.cuda(), o_h, bias=bias.cuda(), **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(M, 4 * C, dtype=T)
+    emu.gemm(a, w, o_e, bias=bias, **kw)
+    close(o_h, o_e, f"geglu {dt}", RTOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("tokens,heads,d", [(64, 8, 8), (77, 8, 40), (20, 2, 160)])
+def test_gemm_heads(hip, emu, dt, tokens, heads, d):
+    T = DT[dt]
+    Bn, C = 3, heads * d
+    M, ld = Bn * tokens, ((tokens + 7) // 8) * 8
+    a, w, bias = rnd((M, 64), T, 1), rnd((3 * C, 64), T, 2, 1 / 8), rnd((3 * C,), torch.float32, 3)
+
+    def outs(dev):
+        return [torch.zeros(Bn, heads, tokens, d, dtype=T, device=dev), torch.zeros(Bn, heads, tokens, d, dtype=T, device=dev),
+                torch.zeros(Bn, heads, d, ld, dtype=T, device=dev)]
+    oh, oe = outs("cuda"), outs("cpu")
+    kw = dict(M=M, N=3 * C, K=64, lda=64, ldw=64, epilogue=2)
+    hip.gemm(a.cuda(), w.cuda(), None, bias=bias.cuda(), heads=dict(seg_cols=C, heads=heads, tokens=tokens, outs=oh, transposed=[0, 0, 1], ld=[0, 0, ld]), **kw)
+    torch.cuda.synchronize()
+    emu.gemm(a, w, None, bias=bias, heads=dict(seg_cols=C, heads=heads, tokens=tokens, outs=oe, transposed=[0, 0, 1], ld=[0, 0, ld]), **kw)
+    for i, n in enumerate("qkv"):
+        close(oh[i], oe[i], f"heads {dt} seg {n}", RTOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_gemm_batched(hip, emu, dt):
+    """the materialised-attention shape: S[z] = q[z] k[z]^T * scale, d = 40"""
+    T = DT[dt]
+    Z, N, d = 6, 100, 40
+    q, k = rnd((Z, N, d), T, 1), rnd((Z, N, d), T, 2)
+    ldo = 104
+    kw = dict(M=N, N=N, K=d, lda=d, ldw=d, ldo=ldo, batch=Z, stride_a=N * d, stride_w=N * d, stride_o=N * ldo, out_scale=d ** -0.5)
+    o_h = torch.zeros(Z, N, ldo, dtype=T, device="cuda")
+    hip.gemm(q.cuda(), k.cuda(), o_h, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(Z, N, ldo, dtype=T)
+    emu.gemm(q, k, o_e, **kw)
+    close(o_h, o_e, f"bgemm {dt}", RTOL[dt])
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,nq,nk,d,div", [(2, 8, 256, 256, 40, 1), (4, 8, 64, 77, 40, 2), (1, 8, 100, 300, 80, 1), (2, 8, 64, 64, 160, 1),
+                                            (2, 8, 16, 16, 8, 1), (3, 2, 33, 93, 32, 3), (1, 8, 1024, 1024, 40, 1), (2, 8, 1, 1, 32, 1)])
+def test_attention(hip, emu, B, H, nq, nk, d, div):
+    T = torch.bfloat16
+    kvB, ldvt = (B + div - 1) // div, ((nk + 7) // 8) * 8
+    q, k = rnd((B * H, nq, d), T, 1), rnd((kvB * H, nk, d), T, 2)
+    vt = torch.zeros(kvB * H, d, ldvt, dtype=T)
+    vt[..., :nk] = rnd((kvB * H, d, nk), T, 3)
+    kw = dict(batch=B, heads=H, n_q=nq, n_k=nk, d=d, ldo=H * d, ldvt=ldvt, scale=d ** -0.5, kv_batch_div=div)
+    o_h = torch.full((B * nq, H * d), float("nan"), dtype=T, device="cuda")
+    hip.attention(q.cuda(), k.cuda(), vt.cuda(), o_h, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(B * nq, H * d, dtype=T)
+    emu.attention(q, k, vt, o_e, **kw)
+    close(o_h, o_e, f"attn B{B} H{H} nq{nq} nk{nk} d{d}", 6e-3)
+    # decoupled IP-Adapter form: o += 0.7 * attn
+    o_h2, o_e2 = o_h.clone(), o_e.clone()
+    hip.attention(q.cuda(), k.cuda(), vt.cuda(), o_h2, accumulate=True, o_scale=0.7, **kw)
+    torch.cuda.synchronize()
+    emu.attention(q, k, vt, o_e2, accumulate=True, o_scale=0.7, **kw)
+    close(o_h2, o_e2, f"attn-accumulate d{d}", 8e-3)
+
+
+def test_attention_peaked_softmax(hip, emu):
+    """rows whose max jumps by orders of magnitude between key tiles exercise the online rescale"""
+    T = torch.bfloat16
+    B, H, n, d = 1, 8, 256, 40
+    q, k = rnd((B * H, n, d), T, 1), rnd((B * H, n, d), T, 2)
+    k[:, 200] = (q[:, 17].float() * 4).to(T)   # one key aligned with one query, late in the sequence
+    k[:, 3] = (q[:, 90].float() * 6).to(T)
+    vt = rnd((B * H, d, n), T, 3)
+    kw = dict(batch=B, heads=H, n_q=n, n_k=n, d=d, ldo=H * d, ldvt=n, scale=d ** -0.5)
+    o_h = torch.zeros(B * n, H * d, dtype=T, device="cuda")
+    hip.attention(q.cuda(), k.cuda(), vt.cuda(), o_h, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(B * n, H * d, dtype=T)
+    emu.attention(q, k, vt, o_e, **kw)
+    close(o_h, o_e, "attn peaked", 6e-3)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("clips,F,P,H,d", [(2, 16, 64, 8, 40), (1, 8, 16, 8, 8), (2, 4, 1, 8, 32), (1, 24, 9, 8, 80), (1, 16, 5, 8, 160), (1, 32, 4, 8, 16)])
+def test_temporal_attention(hip, emu, dt, clips, F, P, H, d):
+    T = DT[dt]
+    C = H * d
+    qkv = rnd((clips * F * P, 3 * C), T, 1)
+    kw = dict(clips=clips, frames=F, pixels=P, heads=H, d=d, scale=d ** -0.5)
+    o_h = torch.full((clips * F * P, C), float("nan"), dtype=T, device="cuda")
+    hip.temporal_attention(qkv.cuda(), o_h, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(clips * F * P, C, dtype=T)
+    emu.temporal_attention(qkv, o_e, **kw)
+    close(o_h, o_e, f"tattn {dt} F{F} P{P} d{d}", 6e-3 if dt == "bf16" else 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("samples,rps,C", [(2, 4 * 64, 320), (8, 64, 64), (2, 16 * 16, 2560), (6, 1, 128), (3, 1000, 960), (2, 37, 1920)])
+def test_groupnorm(hip, emu, dt, samples, rps, C):
+    T = DT[dt]
+    rows = samples * rps
+    x = (rnd((rows, C), torch.float32, 1) * 2 + 0.7).to(T)
+    gamma, beta = rnd((C,), torch.float32, 2) * 0.1 + 1, rnd((C,), torch.float32, 3) * 0.1
+    st_h = torch.full((samples, 32, 2), float("nan"), dtype=torch.float64, device="cuda")
+    hip.gn_stats(x.cuda(), st_h, rows=rows, C_=C, groups=32, rows_per_sample=rps)
+    st_e = torch.zeros(samples, 32, 2, dtype=torch.float64)
+    emu.gn_stats(x, st_e, rows=rows, C_=C, groups=32, rows_per_sample=rps)
+    torch.cuda.synchronize()
+    close(st_h, st_e, f"gn_stats {dt} C{C}", 1e-5)
+    for silu in (False, True):
+        y_h = torch.zeros(rows, C, dtype=T, device="cuda")
+        hip.gn_apply(x.cuda(), st_h, gamma.cuda(), beta.cuda(), y_h, rows=rows, C_=C, groups=32, rows_per_sample=rps, eps=1e-5, silu=silu)
+        y_e = torch.zeros(rows, C, dtype=T)
+        emu.gn_apply(x, st_e, gamma, beta, y_e, rows=rows, C_=C, groups=32, rows_per_sample=rps, eps=1e-5, silu=silu)
+        torch.cuda.synchronize()
+        close(y_h, y_e, f"gn_apply {dt} C{C} silu={silu}", RTOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("rows,C,pe", [(100, 320, False), (64, 64, True), (33, 1280, True), (7, 640, False)])
+def test_layernorm(hip, emu, dt, rows, C, pe):
+    T = DT[dt]
+    x = (rnd((rows, C), torch.float32, 1) * 3 + 1).to(T)
+    gamma, beta = rnd((C,), torch.float32, 2) * 0.1 + 1, rnd((C,), torch.float32, 3) * 0.1
+    pet = rnd((5, C), torch.float32, 4) if pe else None
+    kw = dict(rows=rows, C_=C, eps=1e-5, pe_div=3, pe_rows=5) if pe else dict(rows=rows, C_=C, eps=1e-5)
+    y_h = torch.zeros(rows, C, dtype=T, device="cuda")
+    hip.layernorm(x.cuda(), gamma.cuda(), beta.cuda(), y_h, pe=pet.cuda() if pe else None, **kw)
+    y_e = torch.zeros(rows, C, dtype=T)
+    emu.layernorm(x, gamma, beta, y_e, pe=pet, **kw)
+    torch.cuda.synchronize()
+    close(y_h, y_e, f"layernorm {dt} C{C}", RTOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_softmax_rows(hip, emu, dt):
+    T = DT[dt]
+    x = (rnd((50, 104), torch.float32, 1) * 4).to(T)
+    x_h = x.cuda()
+    hip.softmax_rows(x_h, rows=50, cols=100, ld=104)
+    x_e = x.clone()
+    emu.softmax_rows(x_e, rows=50, cols=100, ld=104)
+    torch.cuda.synchronize()
+    close(x_h[:, :100], x_e[:, :100], f"softmax {dt}", RTOL[dt])
+    assert torch.equal(x_h[:, 100:].cpu(), x[:, 100:])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_elementwise(hip, emu, dt):
+    T = DT[dt]
+    a, b = rnd((77, 64), T, 1), rnd((77, 128), T, 2)
+    y_h = torch.zeros(77, 192, dtype=T, device="cuda")
+    hip.concat_channels(a.cuda(), b.cuda(), y_h, rows=77, c1=64, c2=128)
+    torch.cuda.synchronize()
+    assert torch.equal(y_h.cpu(), torch.cat([a, b], 1))
+    x = rnd((1000,), torch.float32, 3)
+    y = torch.zeros(1000, device="cuda")
+    hip.silu_f32(x.cuda(), y)
+    close(y, torch.nn.functional.silu(x), "silu", 1e-6)
+    x = rnd((10, 9), torch.float32, 4)
+    y_h, y_e = torch.ones(10, 16, dtype=T, device="cuda"), torch.ones(10, 16, dtype=T)
+    hip.cast_from_f32(x.cuda(), y_h, rows=10, cols=9, ld=16)
+    emu.cast_from_f32(x, y_e, rows=10, cols=9, ld=16)
+    torch.cuda.synchronize()
+    assert torch.equal(y_h.cpu(), y_e)
+    z_h = torch.zeros(10, 9, device="cuda")
+    hip.cast_to_f32(y_h, z_h, rows=10, cols=9, ld=16)
+    torch.cuda.synchronize()
+    assert torch.equal(z_h.cpu(), y_e[:, :9].float())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("use_mask,cfg", [(True, 2), (False, 1)])
+def test_unet_input_and_ddim(hip, emu, dt, use_mask, cfg):
+    T = DT[dt]
+    B, F, HW, CL, cp = 2, 4, 48, 4, 64
+    lat, first = rnd((B, CL, F, HW), torch.float32, 1), rnd((B, CL, HW), torch.float32, 2)
+    mask = (rnd((B, 1, HW), torch.float32, 3) * 2) if use_mask else None
+    x_h, x_e = torch.ones(cfg * B * F * HW, cp, dtype=T, device="cuda"), torch.ones(cfg * B * F * HW, cp, dtype=T)
+    hip.unet_input(lat.cuda(), mask.cuda() if use_mask else None, first.cuda(), x_h, B=B, F=F, HW=HW, c_latent=CL, c_pad=cp, cfg_dup=cfg)
+    emu.unet_input(lat, mask, first, x_e, B=B, F=F, HW=HW, c_latent=CL, c_pad=cp, cfg_dup=cfg)
+    torch.cuda.synchronize()
+    assert torch.equal(x_h.cpu(), x_e)
+    pred = rnd((cfg * B * F * HW, cp), T, 5)
+    coef = torch.tensor([0.6, 0.8, 0.7, 0.714], dtype=torch.float32)
+    for ptype in (0, 1, 2):
+        l_h, l_e = lat.clone().cuda(), lat.clone()
+        kw = dict(B=B, F=F, HW=HW, c_latent=CL, ld=cp, cfg=cfg == 2, guidance=8.0, pred_type=ptype, clip_sample=ptype == 0)
+        hip.cfg_ddim_step(pred.cuda(), l_h, coef.cuda(), **kw)
+        emu.cfg_ddim_step(pred, l_e, coef, **kw)
+        torch.cuda.synchronize()
+        close(l_h, l_e, f"cfg_ddim {dt} type{ptype}", 1e-6)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_vae_layout_kernels(hip, emu, dt):
+    T = DT[dt]
+    z = rnd((3, 4, 30), torch.float32, 1)
+    x_h, x_e = torch.ones(3 * 30, 64, dtype=T, device="cuda"), torch.ones(3 * 30, 64, dtype=T)
+    hip.nchw_to_nhwc(z.cuda(), x_h, N=3, C_=4, HW=30, c_pad=64, scale=1 / 0.18215)
+    emu.nchw_to_nhwc(z, x_e, N=3, C_=4, HW=30, c_pad=64, scale=1 / 0.18215)
+    torch.cuda.synchronize()
+    close(x_h, x_e, f"nchw_to_nhwc {dt}", RTOL[dt])
+    img = rnd((3 * 30, 64), T, 2)
+    y_h, y_e = torch.zeros(3, 3, 30, device="cuda"), torch.zeros(3, 3, 30)
+    hip.nhwc_to_nchw(img.cuda(), y_h, N=3, C_=3, HW=30, ld=64, mul=0.5, add=0.5, lo=0.0, hi=1.0)
+    emu.nhwc_to_nchw(img, y_e, N=3, C_=3, HW=30, ld=64, mul=0.5, add=0.5, lo=0.0, hi=1.0)
+    torch.cuda.synchronize()
+    close(y_h, y_e, f"nhwc_to_nchw {dt}", 1e-6)
+
+
+def test_missing_device_tensor_raises(hip):
+    from followyourclick_amd._lib import FycError
+    with pytest.raises(FycError):
+        hip.silu_f32(torch.zeros(4), torch.zeros(4))
