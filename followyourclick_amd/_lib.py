@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("a", vp), ("w", vp), ("bias", vp), ("rowbias", vp), ("residual", vp), ("out", vp),
                 ("seg_out", vp * 3), ("seg_transposed", i32 * 3), ("seg_ld", i32 * 3),
                 ("M", i32), ("N", i32), ("K", i32),
-                ("lda", i32), ("ldw", i32), ("ldo", i32), ("ldr", i32),
+                ("lda", i32), ("ldw", i32), ("ldo", i32), ("ldr", i32), ("ldrb", i32),
                 ("stride_a", i64), ("stride_w", i64), ("stride_o", i64),
                 ("batch", i32), ("mode", i32), ("epilogue", i32),
                 ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32),

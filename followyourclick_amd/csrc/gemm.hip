@@ -26,7 +26,7 @@ namespace {
 struct GemmP {
   const char* a; const char* w; const float* bias; const float* rowbias; const char* residual; char* out;
   char* seg_out[3]; int seg_transposed[3]; int seg_ld[3];
-  int M, N, K, lda, ldw, ldo, ldr;
+  int M, N, K, lda, ldw, ldo, ldr, ldrb;
   long long stride_a, stride_w, stride_o;
   int mode, epilogue;
   int Hout, Wout, Hin, Win, Cin, conv_stride;
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   for (int i = 0; i < WTM; ++i) {
     const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
     if (m >= p.M) continue;
-    const float* rb = p.rowbias ? p.rowbias + (long long)(m / p.rows_per_batch) * p.N : nullptr;
+    const float* rb = p.rowbias ? p.rowbias + (long long)(m / p.rows_per_batch) * p.ldrb : nullptr;
     if (p.epilogue == FYC_EPI_GEGLU) {
       // packed columns: [32b, 32b+16) = value channels 16b.., [32b+16, 32b+32) = their gates
 #pragma unroll
@@ -357,6 +357,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.mode = a->mode; p.epilogue = a->epilogue;
   p.Hout = a->Hout; p.Wout = a->Wout; p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin; p.conv_stride = a->conv_stride;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
+  p.ldrb = a->ldrb > 0 ? a->ldrb : a->N;
   p.out_scale = a->out_scale;
   p.zero = (const char*)g_fyc_zero_page;
   const int batch = a->batch > 0 ? a->batch : 1;

@@ -1,0 +1,274 @@
+"""UNet3D denoiser: the op schedule of one forward pass over channels-last activations.
+
+Restates what UNet3DConditionModel.forward computes (reference animatediff/models/unet.py:422-672,
+unet_blocks.py:342-360/482-529/604-632/749-809/880-905, resnet.py:296-342, attention.py:217-308 &
+489-564, motion_module.py:157-208 & 270-283 & 371-464) as a flat sequence of libfyc_hip.so calls:
+
+  * activations live as [B*F*H*W][C] (channels-last == token-major), so every `rearrange`/`permute`
+    of the reference is free; only the 9-channel model input and the 4-channel prediction cross the
+    (b,c,f,h,w) boundary (ops.unet_input / ops.cfg_ddim_step);
+  * text (and IP) keys/values do not depend on the timestep or the frame: they are projected once
+    per clip (`prepare_context`) instead of F*steps times (reference attention.py:264 repeats them);
+  * all time-embedding work (3 sinusoid MLPs + the 22 ResnetBlock3D.time_emb_proj) is done for every
+    DDIM step up front in f32 (`prepare_time_embeddings`) and enters the convs as an epilogue row.
+
+The only torch calls are allocation (`torch.empty/zeros`) and host->device copies of tables.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from .. import _lib as L
+from .. import ops as ops_mod
+from .base import EngineBase
+from .config import UNet3DConfig
+from .weights import Packed, pad_channels
+
+Tensor = torch.Tensor
+
+
+def sinusoid_host(values: Sequence[float], dim: int) -> Tensor:
+    """Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) on the host: [cos | sin]
+    (reference diffusers/models/embeddings.py:21-64; unet.py:129).  f32 like the reference."""
+    half = dim // 2
+    v = torch.tensor(list(values), dtype=torch.float32)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    ang = v[:, None] * freqs[None, :]
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).contiguous()
+
+
+class UNet3DEngine(EngineBase):
+    def __init__(self, packed: Packed, ops=None):
+        self.P = packed
+        self.cfg: UNet3DConfig = packed.cfg
+        self.dtype = packed.dtype
+        self.ops = ops if ops is not None else ops_mod.get()
+        self.device = packed.conv_in_w.device
+        self.heads = self.cfg.attention_head_dim
+        self.groups = self.cfg.norm_num_groups
+        self.mat_attn = self.dtype != torch.bfloat16  # f32 parity mode: materialised attention through the GEMM
+        self.transformers: List[Packed] = []
+        for blk in self.P.down:
+            self.transformers += [l.attn for l in blk.layers if l.attn is not None]
+        self.transformers.append(self.P.mid.attn)
+        for blk in self.P.up:
+            self.transformers += [l.attn for l in blk.layers if l.attn is not None]
+        for i, t in enumerate(self.transformers):
+            t["idx"] = i
+        self.ctx_cache = None
+        self.ops.ensure_init(self.device)
+
+    # ---- once per clip ---------------------------------------------------------------------
+    def prepare_time_embeddings(self, timesteps: Sequence[int], fps: Optional[Sequence[float]], flow: Optional[Sequence[float]],
+                                batch: int):
+        """Returns (emb [S*batch, 1280] f32, temb [S*batch, temb_total] f32); row = step*batch + b.
+        emb = time_embedding(sin t) + fps_embedding(sin fps_b) + motion_embedding(sin flow_b)
+        (reference unet.py:526-558); temb = time_emb_proj(SiLU(emb)) of all ResNets (resnet.py:306-307)."""
+        cfg, P, o = self.cfg, self.P, self.ops
+        c0, S = cfg.block_out_channels[0], len(timesteps)
+        rows = S * batch
+
+        def mlp(m: Packed, sin: Tensor, residual=None) -> Tensor:
+            h = self.lin(sin.to(self.device), m.w1, rows, bias=m.b1)
+            a = self.new(rows, h.shape[1], dtype=torch.float32)
+            o.silu_f32(h, a)
+            return self.lin(a, m.w2, rows, bias=m.b2, residual=residual)
+
+        emb = mlp(P.emb["time_embedding"], sinusoid_host(timesteps, c0).repeat_interleave(batch, dim=0))
+        if cfg.use_fps_condition and fps is not None:
+            emb = mlp(P.emb["fps_embedding"], sinusoid_host(fps, c0).repeat(S, 1), residual=emb)
+            emb = mlp(P.emb["motion_embedding"], sinusoid_host(flow, c0).repeat(S, 1), residual=emb)
+        act = self.new(rows, emb.shape[1], dtype=torch.float32)
+        o.silu_f32(emb, act)
+        temb = self.lin(act, P.temb_w, rows, bias=P.temb_b)
+        return emb, temb
+
+    def prepare_context(self, ctx: Tensor, ip_tokens: Optional[Tensor] = None) -> None:
+        """ctx: (B_eff, 77, D) text states; ip_tokens: (B_eff, n, D) projected image tokens.  Projects the
+        cross-attention K / V^T of all 16 transformers once (they are constant over steps and frames)."""
+        cfg, o = self.cfg, self.ops
+        Bn, Nk, D = ctx.shape
+        H = self.heads
+
+        def to_T(t: Tensor) -> Tensor:
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            y = self.new(t.shape[0] * t.shape[1], D)
+            o.cast_from_f32(t, y, rows=t.shape[0] * t.shape[1], cols=D, ld=D)
+            return y
+
+        def project(x: Tensor, w: Tensor, n_tok: int, C: int):
+            d = C // H
+            ld = ((n_tok + 7) // 8) * 8
+            k = self.new(Bn, H, n_tok, d)
+            vt = self.zeros(Bn, H, d, ld)
+            o.gemm(x, w, None, M=Bn * n_tok, N=2 * C, K=D, lda=D, ldw=D, epilogue=L.EPI_HEADS,
+                   heads=dict(seg_cols=C, heads=H, tokens=n_tok, outs=[k, vt], transposed=[0, 1], ld=[0, ld]))
+            return k, vt, ld
+
+        xt = to_T(ctx)
+        xi = to_T(ip_tokens) if (cfg.use_ip_cross_attention and ip_tokens is not None) else None
+        cache = []
+        for t in self.transformers:
+            e = dict(text=project(xt, t.kv2_w, Nk, t.C), n_text=Nk, ip=None)
+            if xi is not None:
+                e["ip"] = project(xi, t.kvip_w, ip_tokens.shape[1], t.C)
+                e["n_ip"] = ip_tokens.shape[1]
+            cache.append(e)
+        self.ctx_cache = cache
+
+    # ---- attention cores -----------------------------------------------------------------------
+    def _attend(self, q: Tensor, k: Tensor, vt: Tensor, out: Tensor, *, batch: int, n_q: int, n_k: int, d: int, ldvt: int,
+                C: int, kv_div: int, accumulate: bool = False, o_scale: float = 1.0) -> None:
+        H, o = self.heads, self.ops
+        scale = d ** -0.5
+        if not self.mat_attn:
+            o.attention(q, k, vt, out, batch=batch, heads=H, n_q=n_q, n_k=n_k, d=d, ldo=C, ldvt=ldvt, scale=scale,
+                        kv_batch_div=kv_div, accumulate=accumulate, o_scale=o_scale)
+            return
+        # f32 parity mode: softmax(q k^T * scale) v materialised per batch element through the GEMM
+        # (reference CrossAttention._attention, diffusers/models/attention.py:649-678)
+        ldS = ((n_k + 7) // 8) * 8
+        for b in range(batch):
+            kb = b // kv_div
+            S = self.zeros(H, n_q, ldS)
+            o.gemm(q[b], k[kb], S, M=n_q, N=n_k, K=d, lda=d, ldw=d, ldo=ldS, batch=H, stride_a=n_q * d, stride_w=n_k * d,
+                   stride_o=n_q * ldS, out_scale=scale)
+            o.softmax_rows(S, rows=H * n_q, cols=n_k, ld=ldS)
+            dst = out[b * n_q:(b + 1) * n_q]
+            if accumulate:
+                tmp = self.new(n_q, C)
+                o.gemm(S, vt[kb], tmp, M=n_q, N=d, K=ldS, lda=ldS, ldw=ldvt, ldo=C, batch=H, stride_a=n_q * ldS, stride_w=d * ldvt,
+                       stride_o=d)
+                self._axpy(tmp, dst, n_q, C, o_scale)
+            else:
+                o.gemm(S, vt[kb], dst, M=n_q, N=d, K=ldS, lda=ldS, ldw=ldvt, ldo=C, batch=H, stride_a=n_q * ldS, stride_w=d * ldvt,
+                       stride_o=d)
+
+    def _axpy(self, x: Tensor, y: Tensor, rows: int, C: int, alpha: float) -> None:
+        """y = y + alpha * x via the GEMM epilogue (parity mode only): (x @ (alpha*I)) + y."""
+        key = ("axpy", C, alpha)
+        if not hasattr(self, "_eyes"):
+            self._eyes = {}
+        if key not in self._eyes:
+            self._eyes[key] = (torch.eye(C, dtype=torch.float32) * alpha).to(self.dtype).to(self.device)
+        self.ops.gemm(x, self._eyes[key], y, M=rows, N=C, K=C, lda=C, ldw=C, ldo=C, residual=y, ldr=C)
+
+    # ---- blocks --------------------------------------------------------------------------------
+    def resnet(self, r: Packed, x: Tensor, temb: Tensor, g: dict) -> Tensor:
+        """ResnetBlock3D (reference resnet.py:296-342): cross-frame GroupNorm statistics."""
+        rows, rpb = g["rows"], g["F"] * g["H"] * g["W"]
+        frames = g["B"] * g["F"]
+        cin_p = r.c1_w.shape[1] // 9
+        h = self.group_norm(x, r.n1_g, r.n1_b, rows, cin_p, rpb, self.cfg.norm_eps, True)
+        tb = temb[:, r.temb_off:]  # view: row pitch stays temb_total (ldrb)
+        h = self.conv(h, r.c1_w, r.c1_b, frames, g["H"], g["W"], rowbias=tb, rpb=rpb, ldrb=temb.shape[1])
+        h = self.group_norm(h, r.n2_g, r.n2_b, rows, r.cout, rpb, self.cfg.norm_eps, True)
+        sc = self.lin(x, r.sc_w, rows, bias=r.sc_b) if r.sc_w is not None else x
+        return self.conv(h, r.c2_w, r.c2_b, frames, g["H"], g["W"], residual=sc)
+
+    def feed_forward(self, ff: Packed, ln, tok: Tensor, rows: int, C: int) -> Tensor:
+        n = self.layer_norm(tok, ln, rows, C)
+        hmid = self.lin(n, ff.w1, rows, bias=ff.b1, geglu=True)
+        return self.lin(hmid, ff.w2, rows, bias=ff.b2, residual=tok)
+
+    def transformer(self, t: Packed, x: Tensor, g: dict) -> Tensor:
+        """Transformer3DModel + BasicTransformerBlock (reference attention.py:217-308, 489-564)."""
+        rows, C, H, o = g["rows"], t.C, self.heads, self.ops
+        BF, N = g["B"] * g["F"], g["H"] * g["W"]
+        d = C // H
+        h = self.group_norm(x, t.norm_g, t.norm_b, rows, C, N, 1e-6, False)
+        tok = self.lin(h, t.pin_w, rows, bias=t.pin_b)
+        # --- attn1: spatial self-attention
+        n1 = self.layer_norm(tok, t.ln1, rows, C)
+        ld = ((N + 7) // 8) * 8
+        q, k, vt = self.new(BF, H, N, d), self.new(BF, H, N, d), (self.zeros(BF, H, d, ld) if ld != N else self.new(BF, H, d, ld))
+        o.gemm(n1, t.qkv_w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS,
+               heads=dict(seg_cols=C, heads=H, tokens=N, outs=[q, k, vt], transposed=[0, 0, 1], ld=[0, 0, ld]))
+        att = self.new(rows, C)
+        self._attend(q, k, vt, att, batch=BF, n_q=N, n_k=N, d=d, ldvt=ld, C=C, kv_div=1)
+        tok = self.lin(att, t.o1_w, rows, bias=t.o1_b, residual=tok)
+        # --- attn2: cross-attention on the cached text (and IP) K/V
+        n2 = self.layer_norm(tok, t.ln2, rows, C)
+        q2 = self.new(BF, H, N, d)
+        o.gemm(n2, t.q2_w, None, M=rows, N=C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS,
+               heads=dict(seg_cols=C, heads=H, tokens=N, outs=[q2], transposed=[0], ld=[0]))
+        cache = self.ctx_cache[t.idx]
+        kt, vtt, ldt = cache["text"]
+        att2 = self.new(rows, C)
+        self._attend(q2, kt, vtt, att2, batch=BF, n_q=N, n_k=cache["n_text"], d=d, ldvt=ldt, C=C, kv_div=g["F"])
+        if cache["ip"] is not None:
+            ki, vti, ldi = cache["ip"]
+            self._attend(q2, ki, vti, att2, batch=BF, n_q=N, n_k=cache["n_ip"], d=d, ldvt=ldi, C=C, kv_div=g["F"],
+                         accumulate=True, o_scale=self.cfg.ip_scale)
+        tok = self.lin(att2, t.o2_w, rows, bias=t.o2_b, residual=tok)
+        tok = self.feed_forward(t.ff, t.ln3, tok, rows, C)
+        return self.lin(tok, t.pout_w, rows, bias=t.pout_b, residual=x)
+
+    def motion(self, m: Packed, x: Tensor, g: dict) -> Tensor:
+        """VanillaTemporalModule (reference motion_module.py:157-208, 270-283, 371-464)."""
+        rows, C, o = g["rows"], m.C, self.ops
+        N, Hm = g["H"] * g["W"], self.cfg.motion_num_attention_heads
+        d = C // Hm
+        h = self.group_norm(x, m.norm_g, m.norm_b, rows, C, N, 1e-6, False)
+        tok = self.lin(h, m.pin_w, rows, bias=m.pin_b)
+        for blk in m.blocks:
+            for a in blk.attns:
+                n = self.layer_norm(tok, a.ln, rows, C, pe=a.pe, pe_div=N, pe_rows=g["F"])
+                qkv = self.lin(n, a.qkv_w, rows)
+                att = self.new(rows, C)
+                o.temporal_attention(qkv, att, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5)
+                tok = self.lin(att, a.o_w, rows, bias=a.o_b, residual=tok)
+            tok = self.feed_forward(blk.ff, blk.ff_ln, tok, rows, C)
+        return self.lin(tok, m.pout_w, rows, bias=m.pout_b, residual=x)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, x: Tensor, temb: Tensor, B: int, F: int, H: int, W: int) -> Tensor:
+        """x: channels-last model input [B*F*H*W][pad64(conv_in_channels)] (B already includes the CFG
+        duplicate); temb: [B, temb_total] f32 rows of the current step.  Returns [B*F*H*W][out_channels]."""
+        assert self.ctx_cache is not None, "call prepare_context() first"
+        cfg, P, o = self.cfg, self.P, self.ops
+        g = dict(B=B, F=F, H=H, W=W, rows=B * F * H * W)
+        frames = B * F
+        x = self.conv(x, P.conv_in_w, P.conv_in_b, frames, H, W)
+        if cfg.use_first_frame_condition_concat:
+            raise NotImplementedError("use_first_frame_condition_concat (sample/2 path, reference unet.py:589-590)")
+        skips = [(x, P.conv_in_w.shape[0])]
+        for blk in P.down:
+            for l in blk.layers:
+                x = self.resnet(l.resnet, x, temb, g)
+                if l.attn is not None:
+                    x = self.transformer(l.attn, x, g)
+                if l.motion is not None:
+                    x = self.motion(l.motion, x, g)
+                skips.append((x, l.resnet.cout))
+            if blk.down is not None:
+                x = self.conv(x, blk.down.w, blk.down.b, frames, g["H"], g["W"], stride=2)
+                g = dict(g, H=(g["H"] - 1) // 2 + 1, W=(g["W"] - 1) // 2 + 1)
+                g["rows"] = B * F * g["H"] * g["W"]
+                skips.append((x, blk.down.w.shape[0]))
+        x = self.resnet(P.mid.r0, x, temb, g)
+        x = self.transformer(P.mid.attn, x, g)
+        if P.mid.motion is not None:
+            x = self.motion(P.mid.motion, x, g)
+        x = self.resnet(P.mid.r1, x, temb, g)
+        c_cur = P.mid.r1.cout
+        for blk in P.up:
+            for l in blk.layers:
+                skip, c_skip = skips.pop()
+                cat = self.new(g["rows"], c_cur + c_skip)
+                o.concat_channels(x, skip, cat, rows=g["rows"], c1=c_cur, c2=c_skip)  # cat([hidden, skip], dim=1)
+                x = self.resnet(l.resnet, cat, temb, g)
+                c_cur = l.resnet.cout
+                if l.attn is not None:
+                    x = self.transformer(l.attn, x, g)
+                if l.motion is not None:
+                    x = self.motion(l.motion, x, g)
+            if blk.up is not None:
+                x = self.conv(x, blk.up.w, blk.up.b, frames, g["H"], g["W"], up2=True)
+                g = dict(g, H=2 * g["H"], W=2 * g["W"])
+                g["rows"] = B * F * g["H"] * g["W"]
+        h = self.group_norm(x, P.out_g, P.out_b, g["rows"], c_cur, F * g["H"] * g["W"], cfg.norm_eps, True)
+        return self.conv(h, P.conv_out_w, P.conv_out_b, frames, g["H"], g["W"])

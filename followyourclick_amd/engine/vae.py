@@ -1,0 +1,98 @@
+"""AutoencoderKL decoder as an op schedule over channels-last activations.
+
+Restates AutoencoderKL.decode / Decoder.forward (reference diffusers/models/vae.py:208-224, 575-610),
+ResnetBlock2D without temb (diffusers/models/resnet.py:454-493), Upsample2D (:108-143, nearest x2 folded
+into the conv gather), the single-head mid AttentionBlock (diffusers/models/attention.py:328-379) and
+AnimationPipeline.decode_latents (animatediff/pipelines/pipeline_animation.py:400-413).  The reference
+decodes one frame per call; here all frames of a chunk go through the same launches.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+from .. import ops as ops_mod
+from .base import EngineBase
+from .config import VAEDecoderConfig
+from .weights import Packed, pad_channels
+
+Tensor = torch.Tensor
+
+
+class VAEDecoderEngine(EngineBase):
+    def __init__(self, packed: Packed, ops=None):
+        self.P = packed
+        self.cfg: VAEDecoderConfig = packed.cfg
+        self.dtype = packed.dtype
+        self.ops = ops if ops is not None else ops_mod.get()
+        self.device = packed.conv_in_w.device
+        self.groups = self.cfg.norm_num_groups
+        self.ops.ensure_init(self.device)
+
+    def resnet(self, r: Packed, x: Tensor, frames: int, H: int, W: int) -> Tensor:
+        rows, hw = frames * H * W, H * W
+        h = self.group_norm(x, r.n1_g, r.n1_b, rows, r.cin, hw, 1e-6, True)
+        h = self.conv(h, r.c1_w, r.c1_b, frames, H, W)
+        h = self.group_norm(h, r.n2_g, r.n2_b, rows, r.cout, hw, 1e-6, True)
+        sc = self.lin(x, r.sc_w, rows, bias=r.sc_b) if r.sc_w is not None else x
+        return self.conv(h, r.c2_w, r.c2_b, frames, H, W, residual=sc)
+
+    def attention(self, a: Packed, x: Tensor, frames: int, H: int, W: int) -> Tensor:
+        """single head, d = C (512): scores materialised through the batched GEMM, softmax in f32"""
+        o = self.ops
+        rows, N = frames * H * W, H * W
+        C = a.o_w.shape[0]
+        h = self.group_norm(x, a.g, a.b, rows, C, N, 1e-6, False)
+        ld = ((N + 7) // 8) * 8
+        q, k = self.new(frames, 1, N, C), self.new(frames, 1, N, C)
+        vt = self.zeros(frames, 1, C, ld) if ld != N else self.new(frames, 1, C, ld)
+        o.gemm(h, a.qkv_w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, bias=a.qkv_b, epilogue=L.EPI_HEADS,
+               heads=dict(seg_cols=C, heads=1, tokens=N, outs=[q, k, vt], transposed=[0, 0, 1], ld=[0, 0, ld]))
+        S = self.zeros(frames, N, ld) if ld != N else self.new(frames, N, ld)
+        o.gemm(q, k, S, M=N, N=N, K=C, lda=C, ldw=C, ldo=ld, batch=frames, stride_a=N * C, stride_w=N * C, stride_o=N * ld,
+               out_scale=C ** -0.5)
+        o.softmax_rows(S, rows=frames * N, cols=N, ld=ld)
+        att = self.new(rows, C)
+        o.gemm(S, vt, att, M=N, N=C, K=ld, lda=ld, ldw=ld, ldo=C, batch=frames, stride_a=N * ld, stride_w=C * ld, stride_o=N * C)
+        return self.lin(att, a.o_w, rows, bias=a.o_b, residual=x)
+
+    def decode(self, z: Tensor) -> Tensor:
+        """z: (N, 4, h, w) f32 latents *already in model space* (not yet divided by the scaling factor);
+        returns (N, 3, 8h, 8w) f32 = clamp(decode(z / 0.18215) / 2 + 0.5, 0, 1)."""
+        P, cfg, o = self.P, self.cfg, self.ops
+        N, Cz, H, W = z.shape
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        cp = pad_channels(Cz)
+        x = self.new(N * H * W, cp)
+        o.nchw_to_nhwc(z, x, N=N, C_=Cz, HW=H * W, c_pad=cp, scale=1.0 / cfg.scaling_factor)
+        y = self.zeros(N * H * W, cp)
+        o.gemm(x, P.pq_w, y, M=N * H * W, N=Cz, K=cp, lda=cp, ldw=cp, ldo=cp, bias=P.pq_b)   # post_quant_conv (1x1)
+        x = self.conv(y, P.conv_in_w, P.conv_in_b, N, H, W)
+        x = self.resnet(P.mid_r0, x, N, H, W)
+        x = self.attention(P.attn, x, N, H, W)
+        x = self.resnet(P.mid_r1, x, N, H, W)
+        for blk in P.ups:
+            for r in blk.resnets:
+                x = self.resnet(r, x, N, H, W)
+            if blk.up is not None:
+                x = self.conv(x, blk.up.w, blk.up.b, N, H, W, up2=True)
+                H, W = 2 * H, 2 * W
+        c0 = cfg.block_out_channels[0]
+        h = self.group_norm(x, P.out_g, P.out_b, N * H * W, c0, H * W, 1e-6, True)
+        Co = cfg.out_channels
+        ldo = ((Co + 3) // 4) * 4
+        img = self.new(N * H * W, ldo)
+        Kc = P.conv_out_w.shape[1]
+        o.gemm(h, P.conv_out_w, img, M=N * H * W, N=Co, K=Kc, lda=Kc // 9, ldw=Kc, ldo=ldo, bias=P.conv_out_b, mode=L.GEMM_CONV3X3,
+               conv=dict(Hout=H, Wout=W, Hin=H, Win=W, Cin=Kc // 9, stride=1))
+        out = self.new(N, Co, H, W, dtype=torch.float32)
+        o.nhwc_to_nchw(img, out, N=N, C_=Co, HW=H * W, ld=ldo, mul=0.5, add=0.5, lo=0.0, hi=1.0)
+        return out
+
+    def decode_video(self, latents: Tensor, chunk: int = 16) -> Tensor:
+        """(b, 4, f, h, w) -> (b, 3, f, 8h, 8w) in [0, 1]  (decode_latents of the reference pipeline)."""
+        B, C, F, H, W = latents.shape
+        z = latents.to(self.device, torch.float32).permute(0, 2, 1, 3, 4).reshape(B * F, C, H, W).contiguous()
+        outs = [self.decode(z[i:i + chunk]) for i in range(0, B * F, chunk)]
+        vid = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        return vid.reshape(B, F, vid.shape[1], vid.shape[2], vid.shape[3]).permute(0, 2, 1, 3, 4)

@@ -1,0 +1,243 @@
+"""Weight packing: reference-layout state dicts -> kernel-friendly device buffers (done once at load).
+
+Reference layouts: conv OIHW, linear (out, in), 1x1 conv (O, I, 1, 1); see SURVEY.md 8a'' for the key
+schema (animatediff/models/unet.py, unet_blocks.py, attention.py, motion_module.py state dicts).
+Packed layouts (activation dtype unless noted):
+  conv3x3   [O][ky][kx][I_pad]  -> (O, 9*I_pad): K order matches the implicit-GEMM gather (gemm.hip)
+  linear    (O, I) row-major = the GEMM's W[n][k] operand as is
+  qkv       to_q | to_k | to_v stacked on O -> one GEMM per attention block
+  GEGLU     ff.net.0.proj rows interleaved in blocks of 16 (value rows 16b.., then their gate rows)
+            so that the value and its gate land in the same lane of the MFMA epilogue
+  biases, norm affine parameters, positional tables, time-embedding MLPs: f32
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .config import UNet3DConfig, VAEDecoderConfig
+
+Tensor = torch.Tensor
+K_ALIGN = 64  # channels are padded to this so every conv K tile (128 B) stays inside one filter tap
+
+
+def pad_channels(c: int) -> int:
+    return ((c + K_ALIGN - 1) // K_ALIGN) * K_ALIGN
+
+
+def pack_conv3x3(w: Tensor, dtype, device) -> Tensor:
+    O, I, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    Ip = pad_channels(I)
+    p = torch.zeros(O, 3, 3, Ip, dtype=torch.float32)
+    p[..., :I] = w.permute(0, 2, 3, 1)
+    return p.reshape(O, 9 * Ip).to(dtype).contiguous().to(device)
+
+
+def pack_linear(w: Tensor, dtype, device, k_pad: Optional[int] = None) -> Tensor:
+    w = w.reshape(w.shape[0], -1)  # also accepts (O, I, 1, 1)
+    if k_pad is not None and k_pad != w.shape[1]:
+        p = torch.zeros(w.shape[0], k_pad, dtype=torch.float32)
+        p[:, : w.shape[1]] = w
+        w = p
+    return w.to(dtype).contiguous().to(device)
+
+
+def pack_geglu(w: Tensor, b: Tensor, dtype, device):
+    """ff.net.0.proj: rows [0,4C) = value, [4C,8C) = gate (reference diffusers/models/attention.py:819-821)."""
+    O, I = w.shape
+    half = O // 2
+    assert half % 16 == 0
+    wv, wg = w[:half].reshape(half // 16, 16, I), w[half:].reshape(half // 16, 16, I)
+    bv, bg = b[:half].reshape(half // 16, 16), b[half:].reshape(half // 16, 16)
+    wp = torch.stack([wv, wg], dim=1).reshape(O, I)
+    bp = torch.stack([bv, bg], dim=1).reshape(O)
+    return wp.to(dtype).contiguous().to(device), bp.float().contiguous().to(device)
+
+
+def f32(t: Tensor, device) -> Tensor:
+    return t.detach().float().contiguous().to(device)
+
+
+class Packed(dict):
+    """dict with attribute access; leaves are device tensors."""
+    __getattr__ = dict.__getitem__
+
+
+def _resnet(sd: Dict[str, Tensor], p: str, dtype, device, temb: bool = True) -> Packed:
+    r = Packed(
+        n1_g=f32(sd[p + ".norm1.weight"], device), n1_b=f32(sd[p + ".norm1.bias"], device),
+        c1_w=pack_conv3x3(sd[p + ".conv1.weight"], dtype, device), c1_b=f32(sd[p + ".conv1.bias"], device),
+        n2_g=f32(sd[p + ".norm2.weight"], device), n2_b=f32(sd[p + ".norm2.bias"], device),
+        c2_w=pack_conv3x3(sd[p + ".conv2.weight"], dtype, device), c2_b=f32(sd[p + ".conv2.bias"], device),
+        cin=sd[p + ".conv1.weight"].shape[1], cout=sd[p + ".conv1.weight"].shape[0], sc_w=None, sc_b=None)
+    if (p + ".conv_shortcut.weight") in sd:
+        r["sc_w"] = pack_linear(sd[p + ".conv_shortcut.weight"], dtype, device)
+        r["sc_b"] = f32(sd[p + ".conv_shortcut.bias"], device)
+    return r
+
+
+def _ff(sd, p, dtype, device) -> Packed:
+    w1, b1 = pack_geglu(sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"], dtype, device)
+    return Packed(w1=w1, b1=b1, w2=pack_linear(sd[p + ".net.2.weight"], dtype, device), b2=f32(sd[p + ".net.2.bias"], device))
+
+
+def _ln(sd, p, device):
+    return f32(sd[p + ".weight"], device), f32(sd[p + ".bias"], device)
+
+
+def _transformer(sd, p: str, cfg: UNet3DConfig, dtype, device) -> Packed:
+    t = p + ".transformer_blocks.0"
+    a1, a2 = t + ".attn1", t + ".attn2"
+    d = Packed(
+        C=sd[p + ".proj_in.weight"].shape[0],
+        norm_g=f32(sd[p + ".norm.weight"], device), norm_b=f32(sd[p + ".norm.bias"], device),
+        pin_w=pack_linear(sd[p + ".proj_in.weight"], dtype, device), pin_b=f32(sd[p + ".proj_in.bias"], device),
+        pout_w=pack_linear(sd[p + ".proj_out.weight"], dtype, device), pout_b=f32(sd[p + ".proj_out.bias"], device),
+        ln1=_ln(sd, t + ".norm1", device), ln2=_ln(sd, t + ".norm2", device), ln3=_ln(sd, t + ".norm3", device),
+        qkv_w=pack_linear(torch.cat([sd[a1 + ".to_q.weight"], sd[a1 + ".to_k.weight"], sd[a1 + ".to_v.weight"]], 0), dtype, device),
+        o1_w=pack_linear(sd[a1 + ".to_out.0.weight"], dtype, device), o1_b=f32(sd[a1 + ".to_out.0.bias"], device),
+        q2_w=pack_linear(sd[a2 + ".to_q.weight"], dtype, device),
+        kv2_w=pack_linear(torch.cat([sd[a2 + ".to_k.weight"], sd[a2 + ".to_v.weight"]], 0), dtype, device),
+        o2_w=pack_linear(sd[a2 + ".to_out.0.weight"], dtype, device), o2_b=f32(sd[a2 + ".to_out.0.bias"], device),
+        ff=_ff(sd, t + ".ff", dtype, device), kvip_w=None)
+    if cfg.use_ip_cross_attention:
+        d["kvip_w"] = pack_linear(torch.cat([sd[a2 + ".to_k_ip.weight"], sd[a2 + ".to_v_ip.weight"]], 0), dtype, device)
+    return d
+
+
+def _motion(sd, p: str, cfg: UNet3DConfig, dtype, device) -> Packed:
+    p = p + ".temporal_transformer"
+    C = sd[p + ".proj_in.weight"].shape[0]
+    blocks = []
+    for b in range(cfg.motion_num_transformer_block):
+        t = f"{p}.transformer_blocks.{b}"
+        attns = []
+        for a in range(cfg.motion_attention_blocks):
+            ab = f"{t}.attention_blocks.{a}"
+            pe = None
+            if cfg.temporal_position_encoding:
+                # analytic table (== the persistent `pos_encoder.pe` buffer, reference motion_module.py:286-304);
+                # regenerated so that clips longer than a checkpoint's max_len still work
+                pe = sinusoidal_pe(C, max(cfg.temporal_position_encoding_max_len, 32)).to(device)
+            attns.append(Packed(
+                ln=_ln(sd, f"{t}.norms.{a}", device), pe=pe,
+                qkv_w=pack_linear(torch.cat([sd[ab + ".to_q.weight"], sd[ab + ".to_k.weight"], sd[ab + ".to_v.weight"]], 0), dtype, device),
+                o_w=pack_linear(sd[ab + ".to_out.0.weight"], dtype, device), o_b=f32(sd[ab + ".to_out.0.bias"], device)))
+        blocks.append(Packed(attns=attns, ff_ln=_ln(sd, t + ".ff_norm", device), ff=_ff(sd, t + ".ff", dtype, device)))
+    return Packed(C=C, norm_g=f32(sd[p + ".norm.weight"], device), norm_b=f32(sd[p + ".norm.bias"], device),
+                  pin_w=pack_linear(sd[p + ".proj_in.weight"], dtype, device), pin_b=f32(sd[p + ".proj_in.bias"], device),
+                  pout_w=pack_linear(sd[p + ".proj_out.weight"], dtype, device), pout_b=f32(sd[p + ".proj_out.bias"], device),
+                  blocks=blocks)
+
+
+def sinusoidal_pe(channels: int, length: int) -> Tensor:
+    """pe[p, 2i] = sin(p * exp(-2i ln(1e4)/C)), pe[p, 2i+1] = cos(...) (reference motion_module.py:295-301)."""
+    import math
+    pos = torch.arange(length, dtype=torch.float32)[:, None]
+    div = torch.exp(torch.arange(0, channels, 2, dtype=torch.float32) * (-math.log(10000.0) / channels))
+    pe = torch.zeros(length, channels)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.contiguous()
+
+
+def pack_unet(sd: Dict[str, Tensor], cfg: UNet3DConfig, dtype, device) -> Packed:
+    """sd: reference-schema state dict (fp32, CPU).  Returns the packed parameter tree."""
+    cfg.validate()
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    nb = len(cfg.block_out_channels)
+    P = Packed(cfg=cfg, dtype=dtype)
+    P["conv_in_w"] = pack_conv3x3(sd["conv_in.weight"], dtype, device)
+    P["conv_in_b"] = f32(sd["conv_in.bias"], device)
+    # time / fps / flow embedding MLPs stay f32 (M = batch rows only; precision matters, FLOPs do not)
+    emb = {}
+    for name in ["time_embedding"] + (["fps_embedding", "motion_embedding"] if cfg.use_fps_condition else []):
+        emb[name] = Packed(w1=f32(sd[name + ".linear_1.weight"], device), b1=f32(sd[name + ".linear_1.bias"], device),
+                           w2=f32(sd[name + ".linear_2.weight"], device), b2=f32(sd[name + ".linear_2.bias"], device))
+    P["emb"] = emb
+    resnets, temb_w, temb_b = [], [], []
+
+    def add_resnet(p):
+        r = _resnet(sd, p, dtype, device)
+        r["temb_off"] = sum(w.shape[0] for w in temb_w)
+        temb_w.append(sd[p + ".time_emb_proj.weight"])
+        temb_b.append(sd[p + ".time_emb_proj.bias"])
+        resnets.append(r)
+        return r
+
+    down = []
+    for i, bt in enumerate(cfg.down_block_types):
+        p = f"down_blocks.{i}"
+        layers = []
+        for j in range(cfg.layers_per_block):
+            layers.append(Packed(
+                resnet=add_resnet(f"{p}.resnets.{j}"),
+                attn=_transformer(sd, f"{p}.attentions.{j}", cfg, dtype, device) if bt.startswith("CrossAttn") else None,
+                motion=_motion(sd, f"{p}.motion_modules.{j}", cfg, dtype, device)
+                if cfg.use_motion_module and (2 ** i) in cfg.motion_module_resolutions else None))
+        ds = None
+        if i != nb - 1:
+            ds = Packed(w=pack_conv3x3(sd[f"{p}.downsamplers.0.conv.weight"], dtype, device), b=f32(sd[f"{p}.downsamplers.0.conv.bias"], device))
+        down.append(Packed(layers=layers, down=ds))
+    P["down"] = down
+    P["mid"] = Packed(r0=add_resnet("mid_block.resnets.0"), attn=_transformer(sd, "mid_block.attentions.0", cfg, dtype, device),
+                      motion=_motion(sd, "mid_block.motion_modules.0", cfg, dtype, device)
+                      if cfg.use_motion_module and cfg.motion_module_mid_block else None,
+                      r1=add_resnet("mid_block.resnets.1"))
+    up = []
+    for i, bt in enumerate(cfg.up_block_types):
+        p = f"up_blocks.{i}"
+        layers = []
+        for j in range(cfg.layers_per_block + 1):
+            layers.append(Packed(
+                resnet=add_resnet(f"{p}.resnets.{j}"),
+                attn=_transformer(sd, f"{p}.attentions.{j}", cfg, dtype, device) if bt.startswith("CrossAttn") else None,
+                motion=_motion(sd, f"{p}.motion_modules.{j}", cfg, dtype, device)
+                if cfg.use_motion_module and (2 ** (nb - 1 - i)) in cfg.motion_module_resolutions else None))
+        us = None
+        if i != nb - 1:
+            us = Packed(w=pack_conv3x3(sd[f"{p}.upsamplers.0.conv.weight"], dtype, device), b=f32(sd[f"{p}.upsamplers.0.conv.bias"], device))
+        up.append(Packed(layers=layers, up=us))
+    P["up"] = up
+    P["out_g"], P["out_b"] = f32(sd["conv_norm_out.weight"], device), f32(sd["conv_norm_out.bias"], device)
+    P["conv_out_w"] = pack_conv3x3(sd["conv_out.weight"], dtype, device)
+    P["conv_out_b"] = f32(sd["conv_out.bias"], device)
+    # all ResnetBlock3D.time_emb_proj stacked: one GEMM gives every block's time-embedding row
+    P["temb_w"] = f32(torch.cat(temb_w, 0), device)
+    P["temb_b"] = f32(torch.cat(temb_b, 0), device)
+    P["temb_total"] = P["temb_w"].shape[0]
+    return P
+
+
+def pack_vae_decoder(sd: Dict[str, Tensor], cfg: VAEDecoderConfig, dtype, device) -> Packed:
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    P = Packed(cfg=cfg, dtype=dtype)
+    # post_quant_conv (1x1, 4->4) is folded into decoder.conv_in (3x3, 4->C): both linear, no bias
+    # interaction except through the zero padding, so it is kept as its own tiny GEMM instead.
+    P["pq_w"] = pack_linear(sd["post_quant_conv.weight"], dtype, device, k_pad=pad_channels(cfg.latent_channels))
+    P["pq_b"] = f32(sd["post_quant_conv.bias"], device)
+    P["conv_in_w"] = pack_conv3x3(sd["decoder.conv_in.weight"], dtype, device)
+    P["conv_in_b"] = f32(sd["decoder.conv_in.bias"], device)
+    P["mid_r0"] = _resnet(sd, "decoder.mid_block.resnets.0", dtype, device)
+    a = "decoder.mid_block.attentions.0"
+    P["attn"] = Packed(g=f32(sd[a + ".group_norm.weight"], device), b=f32(sd[a + ".group_norm.bias"], device),
+                       qkv_w=pack_linear(torch.cat([sd[a + ".query.weight"], sd[a + ".key.weight"], sd[a + ".value.weight"]], 0), dtype, device),
+                       qkv_b=f32(torch.cat([sd[a + ".query.bias"], sd[a + ".key.bias"], sd[a + ".value.bias"]], 0), device),
+                       o_w=pack_linear(sd[a + ".proj_attn.weight"], dtype, device), o_b=f32(sd[a + ".proj_attn.bias"], device))
+    P["mid_r1"] = _resnet(sd, "decoder.mid_block.resnets.1", dtype, device)
+    ups = []
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        rs = [_resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", dtype, device) for j in range(cfg.layers_per_block + 1)]
+        us = None
+        if i != nb - 1:
+            k = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+            us = Packed(w=pack_conv3x3(sd[k + ".weight"], dtype, device), b=f32(sd[k + ".bias"], device))
+        ups.append(Packed(resnets=rs, up=us))
+    P["ups"] = ups
+    P["out_g"], P["out_b"] = f32(sd["decoder.conv_norm_out.weight"], device), f32(sd["decoder.conv_norm_out.bias"], device)
+    P["conv_out_w"] = pack_conv3x3(sd["decoder.conv_out.weight"], dtype, device)
+    P["conv_out_b"] = f32(sd["decoder.conv_out.bias"], device)
+    return P

@@ -78,14 +78,14 @@ class HipOps:
     # -- GEMM family -------------------------------------------------------------------------
     def gemm(self, a: Tensor, w: Tensor, out: Optional[Tensor], *, M: int, N: int, K: int, lda: int, ldw: int,
              ldo: int = 0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None, rows_per_batch: int = 1,
-             residual: Optional[Tensor] = None, ldr: int = 0, out_scale: float = 1.0, epilogue: int = L.EPI_LINEAR,
+             residual: Optional[Tensor] = None, ldr: int = 0, ldrb: int = 0, out_scale: float = 1.0, epilogue: int = L.EPI_LINEAR,
              mode: int = L.GEMM_PLAIN, conv: Optional[dict] = None, batch: int = 1, stride_a: int = 0,
              stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None) -> None:
         self.ensure_init(a.device)
         g = L.GemmArgs()
         g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
         g.residual, g.out = _p(residual), _p(out)
-        g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldr = M, N, K, lda, ldw, ldo, ldr
+        g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldr, g.ldrb = M, N, K, lda, ldw, ldo, ldr, ldrb
         g.stride_a, g.stride_w, g.stride_o, g.batch = stride_a, stride_w, stride_o, batch
         g.mode, g.epilogue, g.rows_per_batch, g.out_scale, g.dtype = mode, epilogue, rows_per_batch, out_scale, _dt(a)
         if a.dtype != w.dtype:

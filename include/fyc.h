@@ -56,7 +56,7 @@ typedef struct {
   const void* a;         /* PLAIN: [batch][M][lda]; CONV: NHWC input [frames][Hin][Win][Cin] */
   const void* w;         /* [batch?][Nw][ldw], K contiguous; conv: K = 9*Cin ordered (ky,kx,ci) */
   const float* bias;     /* [N] or NULL (GEGLU: packed order) */
-  const float* rowbias;  /* [M / rows_per_batch][N] or NULL (ResnetBlock3D time_emb_proj add) */
+  const float* rowbias;  /* [M / rows_per_batch][ldrb] or NULL (ResnetBlock3D time_emb_proj add) */
   const void* residual;  /* [M][ldr] or NULL */
   void* out;             /* LINEAR/GEGLU: [batch][M][ldo] */
   void* seg_out[3];      /* HEADS: per column segment (q,k,v): [b][heads][tok][d] or transposed [b][heads][d][tok] */
@@ -64,6 +64,7 @@ typedef struct {
   int32_t seg_ld[3];     /* transposed segments: row pitch in elements (>= tokens; 0 = tokens) */
   int32_t M, N, K;
   int32_t lda, ldw, ldo, ldr;
+  int32_t ldrb;          /* row pitch of rowbias in elements (0 = N) */
   int64_t stride_a, stride_w, stride_o; /* batch strides in elements (0 = shared) */
   int32_t batch;
   int32_t mode;          /* FYC_GEMM_* */

@@ -20,6 +20,11 @@ def _flat(t):
     return t.reshape(-1)
 
 
+def _strided(t, size, stride, off=0):
+    """as_strided relative to the tensor's own first element (t may be a view into a bigger buffer)"""
+    return torch.as_strided(t, size, stride, t.storage_offset() + off)
+
+
 class EmuOps:
     name = "emu"
 
@@ -34,14 +39,14 @@ class EmuOps:
 
     # ------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
-             ldr=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
+             ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
              heads=None):
         acc_t = self.acc
         af, wf = _flat(a), _flat(w)
         for z in range(batch):
-            W = torch.as_strided(wf, (N, K), (ldw, 1), z * stride_w).to(acc_t)
+            W = _strided(wf, (N, K), (ldw, 1), z * stride_w).to(acc_t)
             if mode == PLAIN:
-                A = torch.as_strided(af, (M, K), (lda, 1), z * stride_a).to(acc_t)
+                A = _strided(af, (M, K), (lda, 1), z * stride_a).to(acc_t)
                 acc = A @ W.t()
             else:
                 Hin, Win, Cin, Hout, Wout = conv["Hin"], conv["Win"], conv["Cin"], conv["Hout"], conv["Wout"]
@@ -59,18 +64,19 @@ class EmuOps:
             if bias is not None:
                 acc = acc + bias.to(acc_t)[None, :N]
             if rowbias is not None:
-                rb = rowbias.reshape(-1, N).to(acc_t)
+                nb_rows = (M + rows_per_batch - 1) // rows_per_batch
+                rb = _strided(rowbias, (nb_rows, N), (ldrb if ldrb > 0 else N, 1)).to(acc_t)
                 acc = acc + rb.repeat_interleave(rows_per_batch, dim=0)[:M]
             if epilogue == GEGLU:
                 blk = acc.reshape(M, N // 32, 2, 16)
                 y = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(M, N // 2)
-                o = torch.as_strided(_flat(out), (M, N // 2), (ldo, 1), z * stride_o)
+                o = _strided(_flat(out), (M, N // 2), (ldo, 1), z * stride_o)
                 o.copy_(y.to(out.dtype))
             elif epilogue == LINEAR:
                 if residual is not None:
-                    acc = acc + torch.as_strided(_flat(residual), (M, N), (ldr, 1), 0).to(acc_t)
+                    acc = acc + _strided(_flat(residual), (M, N), (ldr, 1), 0).to(acc_t)
                 acc = acc * out_scale
-                o = torch.as_strided(_flat(out), (M, N), (ldo, 1), z * stride_o)
+                o = _strided(_flat(out), (M, N), (ldo, 1), z * stride_o)
                 o.copy_(acc.to(out.dtype))
             else:
                 acc = acc * out_scale
@@ -82,7 +88,7 @@ class EmuOps:
                         _flat(t)[: Bn * H * T * d].reshape(Bn, H, T, d).copy_(seg.permute(0, 2, 1, 3).to(t.dtype))
                     else:
                         ld = ld if ld > 0 else T
-                        v = torch.as_strided(_flat(t), (Bn, H, d, T), (H * d * ld, d * ld, ld, 1), 0)
+                        v = _strided(_flat(t), (Bn, H, d, T), (H * d * ld, d * ld, ld, 1), 0)
                         v.copy_(seg.permute(0, 2, 3, 1).to(t.dtype))
 
     # ------------------------------------------------------------------------------------
@@ -92,7 +98,7 @@ class EmuOps:
         Q = _flat(q)[: batch * heads * n_q * d].reshape(batch, heads, n_q, d).to(acc_t)
         kvB = (batch + kv_batch_div - 1) // kv_batch_div
         Kt = _flat(k)[: kvB * heads * n_k * d].reshape(kvB, heads, n_k, d).to(acc_t)
-        Vt = torch.as_strided(_flat(vt), (kvB, heads, d, n_k), (heads * d * ldvt, d * ldvt, ldvt, 1), 0).to(acc_t)
+        Vt = _strided(_flat(vt), (kvB, heads, d, n_k), (heads * d * ldvt, d * ldvt, ldvt, 1), 0).to(acc_t)
         idx = torch.arange(batch) // kv_batch_div
         S = torch.matmul(Q, Kt[idx].transpose(-1, -2)) * scale
         P = S.softmax(dim=-1)
@@ -100,7 +106,7 @@ class EmuOps:
             P = P.to(torch.bfloat16).to(acc_t)  # the kernel feeds bf16 probabilities to the MFMA
         O = torch.matmul(P, Vt[idx].transpose(-1, -2))           # b h n d
         O = O.permute(0, 2, 1, 3).reshape(batch * n_q, heads * d)
-        dst = torch.as_strided(_flat(o), (batch * n_q, heads * d), (ldo, 1), 0)
+        dst = _strided(_flat(o), (batch * n_q, heads * d), (ldo, 1), 0)
         if accumulate:
             O = dst.to(acc_t) + o_scale * O
         dst.copy_(O.to(o.dtype))
@@ -147,7 +153,7 @@ class EmuOps:
         _flat(y)[: rows * C_].reshape(rows, C_).copy_(yv.to(y.dtype))
 
     def softmax_rows(self, x, *, rows, cols, ld):
-        v = torch.as_strided(_flat(x), (rows, cols), (ld, 1), 0)
+        v = _strided(_flat(x), (rows, cols), (ld, 1), 0)
         v.copy_(v.float().softmax(dim=-1).to(x.dtype))
 
     # ------------------------------------------------------------------------------------

@@ -1,0 +1,103 @@
+"""Host orchestration of the engine (weight packing, layouts, block wiring, time-embedding tables,
+cross-attention K/V cache, DDIM coefficients) checked on CPU against the oracle by running the engine
+on the op emulator (tests/emu_ops.py).  The HIP kernels themselves are covered by the -m gpu tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from emu_ops import EmuOps
+from followyourclick_amd.engine import DDIMConfig, UNet3DConfig, VAEDecoderConfig
+from followyourclick_amd.engine.sampler import DDIMSampler
+from followyourclick_amd.engine.scheduler import DDIMTables
+from followyourclick_amd.engine.unet3d import UNet3DEngine
+from followyourclick_amd.engine.vae import VAEDecoderEngine
+from followyourclick_amd.engine.weights import pack_unet, pack_vae_decoder
+from oracle import functional as Fn
+from oracle import weights as W
+
+
+def tiny_cfg(**kw):
+    return UNet3DConfig(block_out_channels=(64, 128, 256, 256), cross_attention_dim=64, sample_size=8, **kw)
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) if v.shape else v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_unet_forward_matches_golden(golden_dir, dtype, tol):
+    g = _load(golden_dir, "unet_tiny_fwd.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), dtype, "cpu"), ops=EmuOps())
+    x9 = g["sample"]                                    # (2, 9, F, h, w): CFG pair of identical inputs
+    B, C9, F, H, Wd = x9.shape
+    x = torch.zeros(B * F * H * Wd, 64)
+    x[:, :C9] = x9.permute(0, 2, 3, 4, 1).reshape(-1, C9)
+    eng.prepare_context(g["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), B)
+    out = eng.forward(x.to(dtype), temb, B, F, H, Wd)
+    out = out.float().reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    ref = g["out"]
+    rel = ((out - ref).norm() / ref.norm()).item()
+    assert rel < tol, rel
+
+
+def test_unet_forward_ip_matches_oracle():
+    """IP-Adapter decoupled cross-attention with the deployed (xformers) softmax temperature."""
+    ocfg = Fn.tiny_unet_config(use_ip_cross_attention=True, ip_scale=0.7)
+    sd = W.make_weights(W.unet_state_shapes(ocfg), 0)
+    inp = W.seeded_inputs(ocfg, 1, 4, 8, 8, seed=7)
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    with torch.no_grad():
+        ref = Fn.unet3d_forward(sd, ocfg, x9, torch.tensor(961), inp["text"], fps, flow, inp["ip_tokens"])
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(use_ip_cross_attention=True, ip_scale=0.7), torch.float32, "cpu"), ops=EmuOps())
+    B, C9, F, H, Wd = x9.shape
+    x = torch.zeros(B * F * H * Wd, 64)
+    x[:, :C9] = x9.permute(0, 2, 3, 4, 1).reshape(-1, C9)
+    eng.prepare_context(inp["text"], inp["ip_tokens"])
+    _, temb = eng.prepare_time_embeddings([961], [2, 2], [4, 4], B)
+    out = eng.forward(x, temb, B, F, H, Wd).reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    assert ((out - ref).norm() / ref.norm()).item() < 2e-4
+
+
+def test_ddim_tables_bit_exact(golden_dir):
+    g = _load(golden_dir, "ddim.npz")
+    tb = DDIMTables(DDIMConfig())
+    assert torch.equal(tb.alphas_cumprod, g["alphas_cumprod"])
+    for n in (5, 25, 50):
+        assert torch.equal(tb.timesteps(n), g[f"timesteps_{n}"])
+    c = tb.step_coefficients(1, 25)
+    assert c[2] == 1.0 and c[3] == 0.0          # last step returns x0 (final_alpha_cumprod = 1)
+
+
+def test_sampler_trajectory_matches_reference_pipeline(golden_dir):
+    """5 DDIM steps, CFG 8, mask + first-frame concat, fps/flow conditioning (the cfg1-shaped run)."""
+    g = _load(golden_dir, "pipeline_tiny.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["unet_weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), torch.float32, "cpu"), ops=EmuOps())
+    traj = []
+    lat = DDIMSampler(eng, DDIMConfig()).sample(g["latents"], g["text_embeddings"], 5, 8.0, g["first_image_latents"],
+                                                g["first_images_mask"], fps=[2], flow=[4],
+                                                callback=lambda i, t, l: traj.append(l.clone()))
+    traj = torch.stack(traj)
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < 5e-4, err
+    vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
+    sdv = W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["vae_weight_seed"]))
+    vae = VAEDecoderEngine(pack_vae_decoder(sdv, vcfg, torch.float32, "cpu"), ops=EmuOps())
+    vid = vae.decode_video(lat)
+    assert vid.shape == g["videos"].shape
+    assert (vid - g["videos"]).abs().max().item() < 2e-3
+
+
+def test_vae_decode_matches_golden(golden_dir):
+    g = _load(golden_dir, "vae_tiny.npz")
+    vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
+    sdv = W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["weight_seed"]))
+    vae = VAEDecoderEngine(pack_vae_decoder(sdv, vcfg, torch.float32, "cpu"), ops=EmuOps())
+    out = vae.decode(g["z"] * vcfg.scaling_factor)
+    ref = (g["out"] / 2 + 0.5).clamp(0, 1)
+    assert (out - ref).abs().max().item() < 1e-4
