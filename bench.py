@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Benchmark of the FollowYourClick denoising hot path on MI355X.
+
+metric  : denoised frames/sec, 16f x 512^2 clip @ 25 DDIM steps (BASELINE.json)
+step    : ONE clip per GPU = the whole 25-step DDIM loop (latents in -> latents out: 9-channel input
+          build, CFG-pair UNet3D forward, guidance, DDIM update) on synthetic (1,4,16,64,64) latents,
+          random-init SD-1.5 UNet3D + motion modules (no checkpoints exist offline), bf16.
+value   : whole-job frames/s = n_gpus * 16 * K / max-over-ranks(time of K clips); inputs are resident in
+          HBM when the timed region starts; VAE decode is outside the metric (reported in DESIGN.md).
+scaling : weak - every rank denoises its own clips; the only collective is the one-time RCCL
+          broadcast of the packed weights (outside the timed region).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+
+Adds to the JSON line: "roofline" (dominant kernel = the MFMA GEMM/implicit-conv family, timed per launch
+with HIP events in an instrumented extra pass) and "cpu_baseline" (the CPU oracle, one of the 25 steps at
+the same shape on the host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from followyourclick_amd import distributed as D  # noqa: E402
+from followyourclick_amd.engine import DDIMConfig, UNet3DConfig  # noqa: E402
+from followyourclick_amd.engine.sampler import DDIMSampler  # noqa: E402
+from followyourclick_amd.engine.schema import random_state_dict, unet_schema  # noqa: E402
+from followyourclick_amd.engine.unet3d import UNet3DEngine  # noqa: E402
+from followyourclick_amd.engine.weights import pack_unet  # noqa: E402
+from followyourclick_amd.profiling import TimedOps  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_inputs(cfg, frames, h, w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(1, cfg.in_channels, frames, h, w, generator=g)
+    first = 0.18215 * 5.0 * torch.randn(1, cfg.in_channels, h, w, generator=g)
+    mask = torch.zeros(1, 1, 1, h, w)
+    mask[..., h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 1.0          # centred rectangle
+    text = torch.randn(2, 77, cfg.cross_attention_dim, generator=torch.Generator().manual_seed(3000))
+    return dict(latents=lat.to(device), first=first.to(device), mask=mask.to(device), text=text.to(device))
+
+
+def cpu_baseline(sd, frames, h, w, ddim_steps):
+    """The oracle (CPU port of the reference math, fp32) on the host cores: ONE of the `ddim_steps`
+    CFG-pair UNet3D forwards at the benchmark shape, extrapolated x ddim_steps."""
+    from oracle import functional as Fn  # test infrastructure: used only as the reported CPU baseline
+    cfg = Fn.UNetConfig()
+    g = torch.Generator().manual_seed(1)
+    x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g)
+    text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961), text, fps, flow)
+    dt = time.time() - t0
+    return dict(value=frames / (ddim_steps * dt), unit="frames/s", cores=cores, kind="port",
+                sample=f"1 of {ddim_steps} DDIM steps (one CFG-pair UNet3D forward, {frames}f@{h * 8}x{w * 8}, fp32, {dt:.1f}s) extrapolated x{ddim_steps}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed clips per GPU (one step = one 25-step DDIM clip)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=25)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    cfg = UNet3DConfig()
+    if args.frames > cfg.temporal_position_encoding_max_len:
+        cfg.temporal_position_encoding_max_len = args.frames
+    schema = unet_schema(cfg)
+    sd = random_state_dict(schema, seed=0, materialize=(rank == 0))
+    packed = pack_unet(sd, cfg, dtype, device)
+    t_b = time.time()
+    moved = D.broadcast_packed(packed, src=0)          # one-time weight broadcast over RCCL/xGMI
+    torch.cuda.synchronize()
+    t_b = time.time() - t_b
+    if rank != 0:
+        sd = None
+    eng = UNet3DEngine(packed)
+    sampler = DDIMSampler(eng, DDIMConfig())
+    h = w = args.size // 8
+    clips = [synthetic_inputs(cfg, args.frames, h, w, 1000 + rank * 100 + i, device) for i in range(args.warmup + args.steps)]
+
+    def run(c):
+        return sampler.sample(c["latents"], c["text"], args.ddim_steps, 8.0, c["first"], c["mask"], fps=[2], flow=[4])
+
+    for c in clips[: args.warmup]:
+        run(c)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for c in clips[args.warmup:]:
+        out = run(c)
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.time() - t0, device)
+    assert torch.isfinite(out).all(), "non-finite latents"
+
+    result = None
+    if rank == 0:
+        value = world * args.frames * args.steps / elapsed
+        result = {
+            "metric": "denoised frames/sec, 16f x 512^2 clip @ 25 DDIM steps", "value": round(value, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "clips_per_sec": round(world * args.steps / elapsed, 4),
+            "config": {"workload": f"configs[1]: AnimationPipeline DDIM loop, SD-1.5 UNet3D + mm_sd_v15-shaped motion modules "
+                                   f"(random init), 1 clip/GPU of {args.frames} frames {args.size}x{args.size}, {args.ddim_steps} DDIM steps, "
+                                   f"CFG 8.0, mask + first-frame concat, fps/flow conditioning",
+                       "frames": args.frames, "height": args.size, "width": args.size, "ddim_steps": args.ddim_steps,
+                       "parallelism": f"dp{world} (independent clips, weight broadcast {moved / 2**30:.2f} GiB in {t_b:.2f}s)"},
+        }
+
+    # ---- roofline leg: one instrumented clip step, per-launch HIP-event timing (rank 0) ---------------
+    if rank == 0 and not args.no_roofline:
+        timed = TimedOps(eng.ops)
+        eng.ops = timed
+        c = clips[-1]
+        st = sampler.prepare(c["text"], args.ddim_steps, 1, 8.0, [2], [4])
+        lat = c["latents"].clone()
+        first, mask = c["first"].reshape(1, cfg.in_channels, h * w).contiguous(), c["mask"][:, :, 0].reshape(1, 1, h * w).contiguous()
+        timed.reset()
+        n_inst = 2
+        for i in range(n_inst):
+            sampler.step(st, i, lat, first, mask)
+        torch.cuda.synchronize()
+        summ = timed.summary()
+        eng.ops = timed.inner
+        mm = {k: v for k, v in summ.items() if k in ("gemm", "conv3x3")}
+        fl = sum(v["flops"] for v in mm.values())
+        ms = sum(v["ms"] for v in mm.values())
+        launches = sum(v["launches"] for v in mm.values())
+        ach = fl / (ms * 1e-3) / 1e12
+        result["roofline"] = {"kernel": "fyc_gemm_kernel (MFMA GEMM + implicit-GEMM conv3x3)", "bound": "mfma",
+                              "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                              "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
+                              "launches_per_ddim_step": launches // n_inst, "avg_launch_us": round(1e3 * ms / launches, 2),
+                              "algorithmic_tflop_per_ddim_step": round(fl / n_inst / 1e12, 3)}
+        fam = {}
+        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+            e = {"ms_per_ddim_step": round(v["ms"] / n_inst, 3), "launches": v["launches"] // n_inst}
+            if v["flops"]:
+                e["tflops"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
+            if v["bytes"]:
+                e["algorithmic_GBs"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+            fam[k] = e
+        result["kernel_families"] = fam
+        if "attn_self" in summ:
+            a = summ["attn_self"]
+            at = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            result["roofline_attention"] = {"kernel": "fyc_attn_kernel (spatial self-attention)", "bound": "mfma", "achieved": round(at, 1),
+                                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(at / PEAK_BF16_TFLOPS, 4)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and os.environ.get("FYC_BENCH_CPU", "1") != "0":
+        try:
+            result["cpu_baseline"] = cpu_baseline(sd, args.frames, h, w, args.ddim_steps)
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
+            result["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

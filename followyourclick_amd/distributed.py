@@ -1,0 +1,106 @@
+"""Data-parallel clip sharding: one process per GPU, zero collectives inside the DDIM loop.
+
+The reference shards prompts with DistributedSampler and makes every rank read every checkpoint from
+disk (reference scripts/inference.py:44-51, 260, 430; no collective is ever issued).  Here rank 0 loads /
+packs the weights once and the packed parameter tree is broadcast over RCCL (xGMI) - the only
+collective of a run; clips are then independent DDIM trajectories.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .engine.weights import Packed
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """(rank, world, local_rank); initialises torch.distributed from RANK/WORLD_SIZE/MASTER_* if world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """clip i -> rank i mod world (the CFG pair of a clip stays on one GPU)."""
+    return list(range(rank, n_items, world))
+
+
+def _leaves(node, prefix=""):
+    if isinstance(node, torch.Tensor):
+        yield prefix, node
+    elif isinstance(node, dict):
+        for k in sorted(node.keys(), key=str):
+            if k in ("cfg", "dtype"):
+                continue
+            yield from _leaves(node[k], f"{prefix}.{k}" if prefix else str(k))
+    elif isinstance(node, (list, tuple)):
+        for i, v in enumerate(node):
+            yield from _leaves(v, f"{prefix}.{i}")
+
+
+def packed_tensors(P: Packed) -> List[tuple]:
+    """deterministic (name, tensor) walk of a packed parameter tree"""
+    return list(_leaves(P))
+
+
+def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> int:
+    """Broadcast every tensor of the tree from `src`.  Small tensors are coalesced into flat buckets
+    (xGMI is point-to-point: few large transfers beat ~3000 tiny ones).  Returns bytes moved."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    total = 0
+    groups = {}
+    for name, t in packed_tensors(P):
+        groups.setdefault(t.dtype, []).append(t)
+    for dtype, ts in groups.items():
+        bucket, size = [], 0
+        def flush():
+            nonlocal bucket, size
+            if not bucket:
+                return
+            flat = torch.cat([t.reshape(-1) for t in bucket])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in bucket:
+                n = t.numel()
+                t.copy_(flat[off:off + n].reshape(t.shape))
+                off += n
+            bucket, size = [], 0
+        for t in ts:
+            nbytes = t.numel() * t.element_size()
+            total += nbytes
+            if nbytes >= bucket_bytes:
+                flush()
+                dist.broadcast(t, src=src)
+                continue
+            if size + nbytes > bucket_bytes:
+                flush()
+            bucket.append(t)
+            size += nbytes
+        flush()
+    return total
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

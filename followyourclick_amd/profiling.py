@@ -1,0 +1,115 @@
+"""Per-kernel timing with HIP events + algorithmic FLOP / byte accounting (bench.py's roofline leg).
+
+`TimedOps` wraps the ops backend: every C-ABI call is bracketed by two events recorded on the stream the
+kernel is launched on (torch's current stream == the stream handed to libfyc_hip.so), so after a
+synchronise each launch has its own duration.  FLOPs are *algorithmic* (2*M*N*K of the contraction the
+reference performs), never the padded work the kernel issues.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict
+
+import torch
+
+
+def _esize(t) -> int:
+    return t.element_size()
+
+
+class TimedOps:
+    def __init__(self, inner):
+        self.inner = inner
+        self.name = inner.name
+        self.records = []  # (family, start_evt, end_evt, flops, bytes)
+        self.enabled = True
+
+    # pass-through for non-kernel attributes
+    def ensure_init(self, device):
+        return self.inner.ensure_init(device)
+
+    def set_gemm_staging(self, s):
+        return self.inner.set_gemm_staging(s)
+
+    def device_caps(self):
+        return self.inner.device_caps()
+
+    def _timed(self, family: str, flops: float, nbytes: float, fn, *a, **kw):
+        if not self.enabled:
+            return fn(*a, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn(*a, **kw)
+        e.record()
+        self.records.append((family, s, e, flops, nbytes))
+        return r
+
+    def gemm(self, a, w, out, **kw):
+        M, N, K, batch = kw["M"], kw["N"], kw["K"], kw.get("batch", 1)
+        flops = 2.0 * M * N * K * batch
+        es = _esize(a)
+        mode = kw.get("mode", 0)
+        if mode == 0:
+            in_bytes = M * K * es * batch
+            fam = "gemm"
+        else:
+            c = kw["conv"]
+            frames = M // (c["Hout"] * c["Wout"])
+            in_bytes = frames * c["Hin"] * c["Win"] * c["Cin"] * es
+            fam = "conv3x3"
+        out_cols = N // 2 if kw.get("epilogue", 0) == 1 else N
+        nbytes = in_bytes + N * K * es * batch + M * out_cols * es * batch
+        if kw.get("residual") is not None:
+            nbytes += M * N * es
+        return self._timed(fam, flops, nbytes, self.inner.gemm, a, w, out, **kw)
+
+    def attention(self, q, k, vt, o, **kw):
+        B, H, nq, nk, d = kw["batch"], kw["heads"], kw["n_q"], kw["n_k"], kw["d"]
+        flops = 4.0 * B * H * nq * nk * d
+        kvb = (B + kw.get("kv_batch_div", 1) - 1) // kw.get("kv_batch_div", 1)
+        nbytes = (2 * B * H * nq * d + 2 * kvb * H * nk * d) * 2
+        fam = "attn_self" if nq == nk else "attn_cross"
+        return self._timed(fam, flops, nbytes, self.inner.attention, q, k, vt, o, **kw)
+
+    def temporal_attention(self, qkv, o, **kw):
+        n = kw["clips"] * kw["frames"] * kw["pixels"] * kw["heads"] * kw["d"]
+        flops = 4.0 * kw["clips"] * kw["pixels"] * kw["heads"] * kw["frames"] ** 2 * kw["d"]
+        return self._timed("attn_temporal", flops, 4.0 * n * _esize(qkv), self.inner.temporal_attention, qkv, o, **kw)
+
+    def gn_stats(self, x, stats, **kw):
+        return self._timed("gn_stats", 0.0, kw["rows"] * kw["C_"] * _esize(x), self.inner.gn_stats, x, stats, **kw)
+
+    def gn_apply(self, x, stats, g, b, y, **kw):
+        return self._timed("gn_apply", 0.0, 2.0 * kw["rows"] * kw["C_"] * _esize(x), self.inner.gn_apply, x, stats, g, b, y, **kw)
+
+    def layernorm(self, x, g, b, y, **kw):
+        return self._timed("layernorm", 0.0, 2.0 * kw["rows"] * kw["C_"] * _esize(x), self.inner.layernorm, x, g, b, y, **kw)
+
+    def softmax_rows(self, x, **kw):
+        return self._timed("softmax", 0.0, 2.0 * kw["rows"] * kw["cols"] * _esize(x), self.inner.softmax_rows, x, **kw)
+
+    def concat_channels(self, a, b, y, **kw):
+        return self._timed("concat", 0.0, 2.0 * kw["rows"] * (kw["c1"] + kw["c2"]) * _esize(a), self.inner.concat_channels, a, b, y, **kw)
+
+    def __getattr__(self, name):  # remaining small ops: timed under their own name, bytes unknown
+        fn = getattr(self.inner, name)
+        if not callable(fn):
+            return fn
+
+        def wrapper(*a, **kw):
+            return self._timed(name, 0.0, 0.0, fn, *a, **kw)
+        return wrapper
+
+    def reset(self):
+        self.records = []
+
+    def summary(self) -> Dict[str, dict]:
+        """call after torch.cuda.synchronize()"""
+        out = defaultdict(lambda: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for fam, s, e, fl, nb in self.records:
+            d = out[fam]
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return dict(out)

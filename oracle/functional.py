@@ -182,8 +182,15 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: Optional[
         return t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3)
 
     qh, kh, vh = split(q), split(k), split(v)
-    s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5 if scale is None else scale)
-    o = torch.matmul(s.softmax(dim=-1), vh)
+    sc = d ** -0.5 if scale is None else scale
+    # batch-chunked only to bound the (B, heads, N, Nk) score tensor at large shapes; same math
+    # (the reference exposes the same valve as CrossAttention._sliced_attention, attention.py:680-716)
+    step = max(1, int(2 ** 29 // max(1, heads * N * k.shape[1])))
+    outs = []
+    for b0 in range(0, B, step):
+        s = torch.matmul(qh[b0:b0 + step], kh[b0:b0 + step].transpose(-1, -2)) * sc
+        outs.append(torch.matmul(s.softmax(dim=-1), vh[b0:b0 + step]))
+    o = torch.cat(outs) if len(outs) > 1 else outs[0]
     return o.permute(0, 2, 1, 3).reshape(B, N, C)
 
 

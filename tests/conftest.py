@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _fresh_library():
+    """Rebuild libfyc_hip.so when a source changed (no-op when the object digests match)."""
+    import shutil
+    from followyourclick_amd import _build
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        _build.build(verbose=False)
+    yield

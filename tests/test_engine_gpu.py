@@ -46,6 +46,15 @@ def rel(a, b):
     return ((a.float().cpu() - b).norm() / b.norm()).item()
 
 
+def report(line):
+    """measured parity numbers are appended to gpurun_out/parity_report.txt (copied into DESIGN.md)"""
+    print(line)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_report.txt"), "a") as f:
+        f.write(line + "\n")
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
 def test_unet_forward_vs_reference_golden(golden_dir, dtype, tol):
     g = _load(golden_dir, "unet_tiny_fwd.npz")
@@ -60,7 +69,7 @@ def test_unet_forward_vs_reference_golden(golden_dir, dtype, tol):
     out = out.float().cpu().reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
     assert torch.isfinite(out).all()
     r = rel(out, g["out"])
-    print(f"unet fwd {dtype}: rel-L2 {r:.3e}")
+    report(f"unet fwd {dtype}: rel-L2 {r:.3e}")
     assert r < tol, r
 
 
@@ -78,11 +87,11 @@ def test_unet_forward_ip_adapter_vs_oracle(dtype, tol):
     _, temb = eng.prepare_time_embeddings([961], [2, 2], [4, 4], B)
     out = eng.forward(_nhwc(x9, dtype), temb, B, F, H, Wd).float().cpu().reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
     r = rel(out, ref)
-    print(f"unet ip fwd {dtype}: rel-L2 {r:.3e}")
+    report(f"unet ip fwd {dtype}: rel-L2 {r:.3e}")
     assert r < tol, r
 
 
-@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 1.5e-1, 1e-1)])
+@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1.5e-1, 1e-1)])
 def test_sampling_loop_vs_reference_pipeline(golden_dir, dtype, tol_lat, tol_vid):
     """AnimationPipeline.__call__ of the real reference: 5 DDIM steps, CFG 8, mask + first frame,
     fps/flow conditioning; per-step latents and the decoded video."""
@@ -96,15 +105,15 @@ def test_sampling_loop_vs_reference_pipeline(golden_dir, dtype, tol_lat, tol_vid
     torch.cuda.synchronize()
     traj = torch.stack(traj)
     err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
-    print(f"sampling {dtype}: per-step rel-L2 {[f'{e:.2e}' for e in err.tolist()]}")
+    report(f"sampling {dtype}: per-step rel-L2 {[f'{e:.2e}' for e in err.tolist()]}")
     assert err.max().item() < tol_lat, err
     vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
     sdv = W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["vae_weight_seed"]))
     vae = VAEDecoderEngine(pack_vae_decoder(sdv, vcfg, dtype, DEV))
     vid = vae.decode_video(lat).cpu()
     assert vid.shape == g["videos"].shape
-    e = (vid - g["videos"]).abs().max().item()
-    print(f"video {dtype}: max abs err {e:.3e}")
+    e = rel(vid, g["videos"])
+    report(f"video {dtype}: rel-L2 {e:.3e}, max abs err {(vid - g['videos']).abs().max().item():.3e}")
     assert e < tol_vid, e
 
 
@@ -117,5 +126,5 @@ def test_vae_decode_vs_reference_golden(golden_dir, dtype, tol):
     out = vae.decode(g["z"] * vcfg.scaling_factor).cpu()
     ref = (g["out"] / 2 + 0.5).clamp(0, 1)
     e = (out - ref).abs().max().item()
-    print(f"vae {dtype}: max abs err {e:.3e}")
+    report(f"vae {dtype}: max abs err {e:.3e}")
     assert e < tol, e
