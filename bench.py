@@ -56,6 +56,7 @@ def cpu_baseline(sd, frames, h, w, ddim_steps):
     from oracle import functional as Fn  # test infrastructure: used only as the reported CPU baseline
     cfg = Fn.UNetConfig()
     g = torch.Generator().manual_seed(1)
+    total_frames, frames = frames, min(frames, 2)   # bounded sample: 2 of the clip's frames (cost is linear in frames)
     x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g)
     text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
@@ -65,7 +66,8 @@ def cpu_baseline(sd, frames, h, w, ddim_steps):
         Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961), text, fps, flow)
     dt = time.time() - t0
     return dict(value=frames / (ddim_steps * dt), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 of {ddim_steps} DDIM steps (one CFG-pair UNet3D forward, {frames}f@{h * 8}x{w * 8}, fp32, {dt:.1f}s) extrapolated x{ddim_steps}")
+                sample=f"1 of {ddim_steps} DDIM steps on {frames} of the {total_frames} frames (one CFG-pair UNet3D forward at {h * 8}x{w * 8}, "
+                       f"fp32 oracle, {dt:.1f}s measured); frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
 
 
 def main():
@@ -153,6 +155,10 @@ def main():
         torch.cuda.synchronize()
         summ = timed.summary()
         eng.ops = timed.inner
+        if os.environ.get("FYC_BENCH_SHAPES"):
+            with open(os.environ["FYC_BENCH_SHAPES"], "w") as f:
+                for key, n, ms_, tf in timed.by_shape():
+                    f.write(f"{ms_ / n_inst:9.3f} ms/step  n={n // n_inst:4d}  {tf:7.1f} TF/s  {key}\n")
         mm = {k: v for k, v in summ.items() if k in ("gemm", "conv3x3")}
         fl = sum(v["flops"] for v in mm.values())
         ms = sum(v["ms"] for v in mm.values())

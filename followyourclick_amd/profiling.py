@@ -34,14 +34,14 @@ class TimedOps:
     def device_caps(self):
         return self.inner.device_caps()
 
-    def _timed(self, family: str, flops: float, nbytes: float, fn, *a, **kw):
+    def _timed(self, family: str, flops: float, nbytes: float, fn, *a, _key=None, **kw):
         if not self.enabled:
             return fn(*a, **kw)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = fn(*a, **kw)
         e.record()
-        self.records.append((family, s, e, flops, nbytes))
+        self.records.append((family, s, e, flops, nbytes, _key))
         return r
 
     def gemm(self, a, w, out, **kw):
@@ -61,7 +61,8 @@ class TimedOps:
         nbytes = in_bytes + N * K * es * batch + M * out_cols * es * batch
         if kw.get("residual") is not None:
             nbytes += M * N * es
-        return self._timed(fam, flops, nbytes, self.inner.gemm, a, w, out, **kw)
+        key = f"{fam} M={M} N={N} K={K} b={batch} epi={kw.get('epilogue', 0)} res={int(kw.get('residual') is not None)}"
+        return self._timed(fam, flops, nbytes, self.inner.gemm, a, w, out, _key=key, **kw)
 
     def attention(self, q, k, vt, o, **kw):
         B, H, nq, nk, d = kw["batch"], kw["heads"], kw["n_q"], kw["n_k"], kw["d"]
@@ -69,7 +70,7 @@ class TimedOps:
         kvb = (B + kw.get("kv_batch_div", 1) - 1) // kw.get("kv_batch_div", 1)
         nbytes = (2 * B * H * nq * d + 2 * kvb * H * nk * d) * 2
         fam = "attn_self" if nq == nk else "attn_cross"
-        return self._timed(fam, flops, nbytes, self.inner.attention, q, k, vt, o, **kw)
+        return self._timed(fam, flops, nbytes, self.inner.attention, q, k, vt, o, _key=f"{fam} B={B} H={H} nq={nq} nk={nk} d={d}", **kw)
 
     def temporal_attention(self, qkv, o, **kw):
         n = kw["clips"] * kw["frames"] * kw["pixels"] * kw["heads"] * kw["d"]
@@ -103,10 +104,21 @@ class TimedOps:
     def reset(self):
         self.records = []
 
+    def by_shape(self):
+        """per distinct call signature: (key, launches, total ms, TFLOP/s) sorted by time"""
+        out = defaultdict(lambda: [0, 0.0, 0.0])
+        for fam, s, e, fl, nb, key in self.records:
+            d = out[key or fam]
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+            d[2] += fl
+        rows = [(k, v[0], v[1], (v[2] / (v[1] * 1e-3) / 1e12) if v[1] > 0 and v[2] > 0 else 0.0) for k, v in out.items()]
+        return sorted(rows, key=lambda r: -r[2])
+
     def summary(self) -> Dict[str, dict]:
         """call after torch.cuda.synchronize()"""
         out = defaultdict(lambda: dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-        for fam, s, e, fl, nb in self.records:
+        for fam, s, e, fl, nb, _ in self.records:
             d = out[fam]
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
