@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
                 ("batch", i32), ("mode", i32), ("epilogue", i32),
                 ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32),
                 ("rows_per_batch", i32), ("seg_cols", i32), ("heads", i32), ("tokens", i32),
-                ("out_scale", f32), ("dtype", i32)]
+                ("out_scale", f32), ("dtype", i32), ("tile", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -101,7 +101,7 @@ OPS = {
     "fyc_cast_from_f32": CastArgs, "fyc_cast_to_f32": CastArgs, "fyc_unet_input": UnetInputArgs,
     "fyc_cfg_ddim_step": CfgDdimArgs, "fyc_nchw_to_nhwc": NchwInArgs, "fyc_nhwc_to_nchw": NhwcOutArgs,
 }
-MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_gemm_staging"]
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning"]
 
 _lib = None
 
@@ -123,7 +123,7 @@ def load() -> C.CDLL:
     lib.fyc_last_error.restype = C.c_char_p
     lib.fyc_init.argtypes = [vp]
     lib.fyc_device_caps.argtypes = [C.POINTER(i64)]
-    lib.fyc_set_gemm_staging.argtypes = [C.c_int]
+    lib.fyc_set_tuning.argtypes = [C.c_int, C.c_int]
     for name, st in OPS.items():
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(st), vp]

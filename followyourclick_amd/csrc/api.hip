@@ -3,7 +3,7 @@
 
 thread_local char g_fyc_err[512] = {0};
 const void* g_fyc_zero_page = nullptr;
-int g_fyc_gemm_staging = 0;
+int g_fyc_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" int fyc_version(void) { return FYC_VERSION; }
 
@@ -16,9 +16,9 @@ extern "C" int fyc_init(const void* zero_page) {
   return 0;
 }
 
-extern "C" int fyc_set_gemm_staging(int staging) {
-  FYC_REQUIRE(staging == 0 || staging == 1, "fyc_set_gemm_staging: %d", staging);
-  g_fyc_gemm_staging = staging;
+extern "C" int fyc_set_tuning(int key, int value) {
+  FYC_REQUIRE(key >= 0 && key < 8, "fyc_set_tuning: key %d", key);
+  g_fyc_tuning[key] = value;
   return 0;
 }
 

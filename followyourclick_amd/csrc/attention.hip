@@ -159,29 +159,40 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
         }
         float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
                          fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run[qt], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.sl2e);
-        m_run[qt] = m_new;
+        // max over the 4 lane quads that share this query: xor 16 inside each 32-lane half (ds_swizzle
+        // bit-mode, no LDS traffic), then across the halves (v_permlane32_swap)
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x401F)));
+        {
+          const unsigned u = __builtin_bit_cast(unsigned, mx);
+          auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+          mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        // lazy rescale: the running max only grows in the first few key tiles; skip the O^T rescale
+        // (12-40 multiplies + one exp per query tile) whenever no lane of the wave saw a new maximum
+        if (__builtin_amdgcn_ballot_w64(mx > m_run[qt]) != 0) {
+          const float m_new = fmaxf(m_run[qt], mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.sl2e);
+          m_run[qt] = m_new;
+          l_run[qt] *= alpha;
+#pragma unroll
+          for (int dv = 0; dv < DVT; ++dv) {
+            o[qt][dv][0] *= alpha; o[qt][dv][1] *= alpha; o[qt][dv][2] *= alpha; o[qt][dv][3] *= alpha;
+          }
+        }
+        const float msl = m_run[qt] * p.sl2e;
         float pv[8], sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f((s[t][qt][r] - m_new) * p.sl2e);
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][qt][r], p.sl2e, -msl));
             pv[4 * t + r] = e;
             sum += e;
           }
-        l_run[qt] = l_run[qt] * alpha + sum;
-#pragma unroll
-        for (int dv = 0; dv < DVT; ++dv) {
-          o[qt][dv][0] *= alpha; o[qt][dv][1] *= alpha; o[qt][dv][2] *= alpha; o[qt][dv][3] *= alpha;
-        }
+        l_run[qt] += sum;
         u32x4 pk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          pk[i] = (unsigned)f32_to_bf16_bits(pv[2 * i]) | ((unsigned)f32_to_bf16_bits(pv[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(pv[2 * i], pv[2 * i + 1]);
         pf[qt] = __builtin_bit_cast(bf16x8, pk);
       }
       // ---- O^T += V^T P^T

@@ -19,7 +19,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // ---- error plumbing (host) ----------------------------------------------------------------
 extern thread_local char g_fyc_err[512];
 extern const void* g_fyc_zero_page;
-extern int g_fyc_gemm_staging;
+extern int g_fyc_tuning[8];  // [1] forced GEMM tile config, [2] forced ring depth, [3] attention variant
 
 #define FYC_FAIL(code, ...)                                   \
   do {                                                        \
@@ -46,6 +46,15 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two f32 -> packed bf16x2 in one v_cvt_pk_bf16_f32 (round-to-nearest-even in hardware)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  f32x2 f = {a, b};
+  bf16x2 h = __builtin_convertvector(f, bf16x2);
+  return __builtin_bit_cast(unsigned, h);
 }
 
 template <typename T> struct ElemIO;
@@ -78,8 +87,8 @@ template <> struct ElemIO<bf16_t> {
   }
   __device__ static __forceinline__ void st4(bf16_t* p, const float v[4]) {
     u32x2 t;
-    t[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-    t[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    t[0] = pack_bf16x2(v[0], v[1]);
+    t[1] = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<u32x2*>(p) = t;
   }
 };
@@ -104,8 +113,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
   u32x4 t;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    t[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
   *reinterpret_cast<u32x4*>(p) = t;
 }
 

@@ -1,0 +1,346 @@
+// GEMM / implicit-GEMM 3x3 convolution on MFMA for gfx950 (CDNA4): kernel template.
+//
+//   out[m][n] = (sum_k A[m][k] * W[n][k] + bias[n] + rowbias[m/rpb][n] + residual[m][n]) * out_scale
+//
+// Data layout: activations channels-last, so a 3x3 convolution is a GEMM whose A rows are
+// gathered from shifted pixels: K is ordered (ky, kx, ci) and every 128-byte K-tile lies inside one
+// filter tap, i.e. an A-tile row is one contiguous 128-B channel slice of one input pixel (or the
+// zero page at the image border / beyond M).  Nearest-2x upsampling (Upsample3D) is folded into
+// that gather: no 4x tensor is ever written.
+//
+// Tile: BM x BN x 128 B of K per step, WGM x WGN wave64s, each wave a (BM/WGM) x (BN/WGN) sub-tile
+// of 16x16 MFMA blocks.  Operands are staged global -> LDS by direct DMA (global_load_lds, 16 B per
+// lane): the LDS image is lane-linear, so the bank-conflict XOR swizzle is applied to the *source*
+// chunk each lane fetches and again on the ds_read_b128 address (same involution on both sides).
+// NS-deep LDS ring: the DMA of tiles k+1 .. k+NS-1 is in flight while tile k feeds the matrix cores;
+// waits are counted (s_waitcnt vmcnt(N), never a drain in steady state) and the barrier is the raw
+// s_barrier so that in-flight DMA survives it (cdna_hip_programming.md: "Pipelining across barriers").
+//
+// MFMA orientation: acc = mfma(Wfrag, Afrag) computes the transposed block D[n][m], so every lane
+// ends up with 4 *consecutive output channels* of one row: the epilogue (bias, time-embedding row,
+// residual, GEGLU gate, head split) is vectorised over channels and stores 8/16 B per lane.
+//
+// f32 parity mode uses the same kernel with v_mfma_f32_16x16x4_f32 (exact f32, 1/16 rate).
+#pragma once
+#include "fyc_common.h"
+
+namespace fycg {
+
+struct GemmP {
+  const char* a; const char* w; const float* bias; const float* rowbias; const char* residual; char* out;
+  char* seg_out[3]; int seg_transposed[3]; int seg_ld[3];
+  int M, N, K, lda, ldw, ldo, ldr, ldrb;
+  long long stride_a, stride_w, stride_o;
+  int mode, epilogue;
+  int Hout, Wout, Hin, Win, Cin, conv_stride;
+  int rows_per_batch, seg_cols, heads, tokens, head_dim;
+  float out_scale;
+  int tiles_m, tiles_n;
+  const char* zero;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  typedef bf16x8 Frag;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  typedef f32x4 Frag;
+  // lane quad g holds k = 4*chunk + {0..3}; MFMA #j contracts element j of all four quads.
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS>
+__global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) {
+  typedef Mma<T> Tr;
+  typedef typename Tr::Frag Frag;
+  constexpr int NT = WGM * WGN * 64;
+  constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-B chunk
+  constexpr int BK = 8 * CH;               // elements per K tile (one 128-B LDS row)
+  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  constexpr int LOADS = A_IT + B_IT;       // DMA instructions per thread per K tile
+  constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  static_assert(A_IT * NT == BM * 8 && B_IT * NT == BN * 8, "tile/threads mismatch");
+  static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LOADS < 64, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles
+  // (n fastest) so the A panel of a row-block is fetched into one L2 only.  Bijective for any count.
+  int t = blockIdx.x;
+  {
+    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = t & 7, idx = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+  const long long bz = blockIdx.z;
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.a) + bz * p.stride_a;
+  const T* __restrict__ W = reinterpret_cast<const T*>(p.w) + bz * p.stride_w;
+  const T* zero = reinterpret_cast<const T*>(p.zero);
+
+  // ---- per-thread loader descriptors ------------------------------------------------------
+  int a_koff[A_IT];
+  long long a_row[A_IT];   // PLAIN: m*lda, or -1 when the row is outside M
+  int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int idx = tid + it * NT, row = idx >> 3, slot = idx & 7;
+    a_koff[it] = ((slot ^ (row & 7)) * CH);
+    const int m = tile_m * BM + row;
+    if (MODE == FYC_GEMM_PLAIN) {
+      a_row[it] = (m < p.M) ? (long long)m * p.lda : -1;
+      a_pix[it] = a_iy0[it] = a_ix0[it] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int fr = m / hw, rem = m - fr * hw, oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      a_row[it] = (m < p.M) ? 0 : -1;
+      a_pix[it] = fr * p.Hin * p.Win;
+      a_iy0[it] = oy * p.conv_stride - 1;
+      a_ix0[it] = ox * p.conv_stride - 1;
+    }
+  }
+  int b_koff[B_IT];
+  long long b_row[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int idx = tid + it * NT, row = idx >> 3, slot = idx & 7;
+    b_koff[it] = ((slot ^ (row & 7)) * CH);
+    const int n = tile_n * BN + row;
+    b_row[it] = (n < p.N) ? (long long)n * p.ldw : -1;
+  }
+
+  const int KT = (p.K + BK - 1) / BK;
+  int tap = 0, c0 = 0;  // conv: filter tap and channel offset of the K tile being *issued*
+
+  auto src_a = [&](int it, int k0) -> const T* {
+    if (MODE == FYC_GEMM_PLAIN) {
+      const int k = k0 + a_koff[it];
+      return (a_row[it] >= 0 && k < p.K) ? A + a_row[it] + k : zero;
+    } else {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int iy = a_iy0[it] + ky, ix = a_ix0[it] + kx;
+      if (MODE == FYC_GEMM_CONV3X3) {
+        const bool ok = a_row[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        return ok ? A + (long long)(a_pix[it] + iy * p.Win + ix) * p.Cin + c0 + a_koff[it] : zero;
+      } else {  // nearest-2x upsampled input: virtual size (2*Hin, 2*Win)
+        const bool ok = a_row[it] >= 0 && (unsigned)iy < (unsigned)(2 * p.Hin) && (unsigned)ix < (unsigned)(2 * p.Win);
+        return ok ? A + (long long)(a_pix[it] + (iy >> 1) * p.Win + (ix >> 1)) * p.Cin + c0 + a_koff[it] : zero;
+      }
+    }
+  };
+  auto src_b = [&](int it, int k0) -> const T* {
+    const int k = k0 + b_koff[it];
+    return (b_row[it] >= 0 && k < p.K) ? W + b_row[it] + k : zero;
+  };
+
+  f32x4 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = lane & 7, g = lane >> 4, r16 = lane & 15;
+  auto compute = [&](int stage) {
+    const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * 128;
+    const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int coff = ((4 * s + g) ^ sw) * 16;
+      Frag af[WTM], bf[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) af[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) bf[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bf[j], af[i], acc[i][j]);
+    }
+  };
+  auto issue = [&](int kt, int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + A_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) glds16(src_a(it, k0), sA + (it * NT + wave * 64) * 16);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) glds16(src_b(it, k0), sB + (it * NT + wave * 64) * 16);
+    if (MODE != FYC_GEMM_PLAIN) {
+      c0 += BK;
+      if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    }
+  };
+
+  // ---- main loop: NS-deep ring, counted waits ----------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < KT) issue(s, s);
+  int st_c = 0, st_i = NS - 1;  // stage being computed / issued
+  for (int kt = 0; kt < KT; ++kt) {
+    // tiles kt+1 .. min(kt+NS-2, KT-1) may stay in flight; tile kt must have landed
+    const int ahead = min(NS - 2, KT - 1 - kt);
+    if (NS >= 4 && ahead == 2) wait_vmcnt<2 * LOADS>();
+    else if (NS >= 3 && ahead == 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < KT) issue(kt + NS - 1, st_i);
+    compute(st_c);
+    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
+  }
+
+  // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
+  T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
+  const T* R = reinterpret_cast<const T*>(p.residual);
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
+    if (m >= p.M) continue;
+    if (EPI == FYC_EPI_GEGLU) {
+      // packed columns: [32b, 32b+16) = value channels 16b.., [32b+16, 32b+32) = their gates
+#pragma unroll
+      for (int j = 0; j + 1 < WTN; j += 2) {
+        const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;  // value column (packed index)
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float h = acc[i][j][r], gt = acc[i][j + 1][r];
+          if (p.bias) { h += p.bias[n + r]; gt += p.bias[n + 16 + r]; }
+          v[r] = h * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
+        }
+        const int oc = (n >> 5) * 16 + (n & 15);
+        ElemIO<T>::st4(O + (long long)m * p.ldo + oc, v);
+      }
+    } else {
+      const float* rb = p.rowbias ? p.rowbias + (long long)(m / p.rows_per_batch) * p.ldrb : nullptr;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        const bool full = (n + 3 < p.N);
+        if (p.bias) {
+          if (full) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += p.bias[n + r];
+          }
+        }
+        if (rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (full || n + r < p.N) v[r] += rb[n + r];
+        }
+        if (EPI == FYC_EPI_LINEAR) {
+          if (R) {
+            if (full) {
+              float rr[4];
+              ElemIO<T>::ld4(R + (long long)m * p.ldr + n, rr);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            } else {
+              for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += ElemIO<T>::ld(R + (long long)m * p.ldr + n + r);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
+          if (full) {
+            ElemIO<T>::st4(O + (long long)m * p.ldo + n, v);
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) ElemIO<T>::st(O + (long long)m * p.ldo + n + r, v[r]);
+          }
+        } else {  // FYC_EPI_HEADS: split columns into segments (q|k|v) and heads
+          const int seg = n / p.seg_cols, c = n - seg * p.seg_cols;
+          const int h = c / p.head_dim, di = c - h * p.head_dim;
+          const int b = m / p.tokens, tok = m - b * p.tokens;
+          T* S = reinterpret_cast<T*>(p.seg_out[seg]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
+          if (!p.seg_transposed[seg]) {
+            ElemIO<T>::st4(S + ((long long)(b * p.heads + h) * p.tokens + tok) * p.head_dim + di, v);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              ElemIO<T>::st(S + ((long long)(b * p.heads + h) * p.head_dim + di + r) * p.seg_ld[seg] + tok, v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS>
+int launch(const GemmP& p, int batch, hipStream_t st) {
+  constexpr int smem = NS * (BM + BN) * 128;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done = true;
+  }
+  GemmP q = p;
+  q.tiles_m = (p.M + BM - 1) / BM;
+  q.tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid(q.tiles_m * q.tiles_n, 1, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), smem, st, q);
+  FYC_CHECK_LAUNCH("fyc_gemm");
+  return 0;
+}
+
+// tile configurations: id -> (BM, BN, WGM, WGN)
+//   1: 128x128, 4 waves   2: 128x64, 4 waves   3: 256x128, 8 waves   4: 256x64, 4 waves
+//   5: 256x320, 8 waves   6: 128x320, 8 waves  7: 256x256, 8 waves   (5-7: 2-deep ring only, 1 block/CU)
+template <typename T, int MODE, int EPI, int NS>
+int dispatch_cfg(int cfg, const GemmP& p, int batch, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch<T, 128, 128, 2, 2, MODE, EPI, NS>(p, batch, st);
+    case 2: return launch<T, 128, 64, 2, 2, MODE, EPI, NS>(p, batch, st);
+    case 3: if constexpr (NS <= 3) return launch<T, 256, 128, 4, 2, MODE, EPI, NS>(p, batch, st); else break;
+    case 4: return launch<T, 256, 64, 4, 1, MODE, EPI, NS>(p, batch, st);
+    // N = 320*k (every layer width of SD-1.5): 320-wide tiles read the A panel once per 320 columns
+    case 5: if constexpr (NS == 2) return launch<T, 256, 320, 4, 2, MODE, EPI, NS>(p, batch, st); else break;
+    case 6: if constexpr (NS == 2) return launch<T, 128, 320, 2, 4, MODE, EPI, NS>(p, batch, st); else break;
+    case 7: if constexpr (NS == 2) return launch<T, 256, 256, 2, 4, MODE, EPI, NS>(p, batch, st); else break;
+  }
+  FYC_FAIL(-2, "fyc_gemm: tile config %d / ring depth %d not built", cfg, NS);
+}
+
+template <typename T, int MODE, int EPI>
+int dispatch_ns(int ns, int cfg, const GemmP& p, int batch, hipStream_t st) {
+  switch (ns) {
+    case 2: return dispatch_cfg<T, MODE, EPI, 2>(cfg, p, batch, st);
+    case 3: return dispatch_cfg<T, MODE, EPI, 3>(cfg, p, batch, st);
+    case 4: return dispatch_cfg<T, MODE, EPI, 4>(cfg, p, batch, st);
+  }
+  FYC_FAIL(-2, "fyc_gemm: ring depth %d not built", ns);
+}
+
+// one translation unit per (dtype, family) keeps the build parallel
+int run_bf16_plain(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
+int run_bf16_conv(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
+int run_f32(const GemmP& p, int batch, int cfg, hipStream_t st);
+
+}  // namespace fycg

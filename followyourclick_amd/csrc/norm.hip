@@ -60,80 +60,99 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
                                                        int rows_per_sample, float eps, int silu) {
   const int C8 = C >> 3, cpg = C / groups;
   const double inv_cnt = 1.0 / ((double)rows_per_sample * cpg);
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long long)gridDim.x * 256) {
-    const long long row = idx / C8;
-    const int c8 = (int)(idx - row * C8);
-    const int sample = (int)(row / rows_per_sample);
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < (unsigned)chunks; idx += gridDim.x * 256u) {
+    const unsigned row = idx / (unsigned)C8;
+    const int c8 = (int)(idx - row * (unsigned)C8);
+    const int sample = (int)(row / (unsigned)rows_per_sample);
     float v[8];
-    load8<T>(x + idx * 8, v);
-    int gprev = -1;
+    load8<T>(x + (size_t)idx * 8, v);
+    // one integer division per chunk; the group index then advances incrementally
+    int gi = (c8 * 8) / cpg, left = cpg - (c8 * 8 - gi * cpg);
     float mean = 0.f, rstd = 0.f;
+    bool fresh = true;
+    float g8[8], b8[8];
+    *reinterpret_cast<f32x4*>(g8) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8);
+    *reinterpret_cast<f32x4*>(g8 + 4) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
+    *reinterpret_cast<f32x4*>(b8) = *reinterpret_cast<const f32x4*>(beta + c8 * 8);
+    *reinterpret_cast<f32x4*>(b8 + 4) = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int c = c8 * 8 + i, gi = c / cpg;
-      if (gi != gprev) {
+      if (fresh) {
         const double s = stats[((long long)sample * groups + gi) * 2], q = stats[((long long)sample * groups + gi) * 2 + 1];
         const double m = s * inv_cnt;
-        double var = q * inv_cnt - m * m;
+        double var = q * inv_cnt - m * m;   // f64 subtraction keeps the cancellation harmless
         var = var > 0.0 ? var : 0.0;
         mean = (float)m;
-        rstd = (float)(1.0 / sqrt(var + (double)eps));
-        gprev = gi;
+        rstd = rsqrtf((float)var + eps);
+        fresh = false;
       }
-      float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      const float o = (v[i] - mean) * rstd * g8[i] + b8[i];
       v[i] = silu ? silu_f(o) : o;
+      if (--left == 0) { left = cpg; ++gi; fresh = true; }
     }
-    store8<T>(y + idx * 8, v);
+    store8<T>(y + (size_t)idx * 8, v);
   }
 }
 
-// ---- LayerNorm: one wave per row -----------------------------------------------------------
-template <typename T, int MAXC8>  // MAXC8 chunks of 8 per lane
+// ---- LayerNorm: 16 lanes per row (4 rows per wave, 16 rows per block) -----------------------------
+// A row of C = 320..1280 channels is only 640..2560 B: one wave per row leaves most lanes idle and
+// little memory in flight.  Here 16 lanes own a row (lane p takes 16-B chunks p, p+16, ...), the two
+// reductions are 4 xor-shuffles inside the 16-lane group, and a wave keeps 4 rows in flight.
+template <typename T, int MAXCH>
 __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ pe,
                                                         T* __restrict__ y, int rows, int C, float eps, int pe_div,
                                                         int pe_rows) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int p = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;
   const int C8 = C >> 3;
-  const T* xr = x + (long long)row * C;
-  float v[MAXC8][8];
+  const T* xr = x + (long long)(live ? row : 0) * C;
+  float v[MAXCH][8];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < MAXC8; ++k) {
-    const int c8 = lane + k * 64;
-    if (c8 < C8) {
+  for (int k = 0; k < MAXCH; ++k) {
+    const int c8 = p + k * 16;
+    if (live && c8 < C8) {
       load8<T>(xr + c8 * 8, v[k]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) s += v[k][i];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < MAXC8; ++k) {
-    const int c8 = lane + k * 64;
-    if (c8 < C8) {
+  for (int k = 0; k < MAXCH; ++k) {
+    const int c8 = p + k * 16;
+    if (live && c8 < C8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; q += d * d; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if (!live) return;
+  const float rstd = rsqrtf(q / (float)C + eps);
   const float* per = pe ? pe + (long long)((row / pe_div) % pe_rows) * C : nullptr;
   T* yr = y + (long long)row * C;
 #pragma unroll
-  for (int k = 0; k < MAXC8; ++k) {
-    const int c8 = lane + k * 64;
+  for (int k = 0; k < MAXCH; ++k) {
+    const int c8 = p + k * 16;
     if (c8 < C8) {
-      float o[8];
+      float o8[8], g8[8], b8[8];
+      *reinterpret_cast<f32x4*>(g8) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8);
+      *reinterpret_cast<f32x4*>(g8 + 4) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
+      *reinterpret_cast<f32x4*>(b8) = *reinterpret_cast<const f32x4*>(beta + c8 * 8);
+      *reinterpret_cast<f32x4*>(b8 + 4) = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c8 * 8 + i;
-        o[i] = (v[k][i] - mean) * rstd * gamma[c] + beta[c];
-        if (per) o[i] += per[c];
+      for (int i = 0; i < 8; ++i) o8[i] = (v[k][i] - mean) * rstd * g8[i] + b8[i];
+      if (per) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] += per[c8 * 8 + i];
       }
-      store8<T>(yr + c8 * 8, o);
+      store8<T>(yr + c8 * 8, o8);
     }
   }
 }
@@ -194,6 +213,7 @@ extern "C" int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream) {
   FYC_REQUIRE(a->rows_per_sample > 0 && a->rows % a->rows_per_sample == 0, "fyc_gn_apply: rows/rows_per_sample");
   hipStream_t st = (hipStream_t)stream;
   const long long chunks = (long long)a->rows * (a->C / 8);
+  FYC_REQUIRE(chunks < (1ll << 32) - 65536ll * 256, "fyc_gn_apply: tensor too large for 32-bit chunk index");
   int blocks = (int)(ceil_div64(chunks, 256) < 8192 ? ceil_div64(chunks, 256) : 8192);
   if (a->dtype == FYC_BF16)
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a->x, a->stats, a->gamma, a->beta,
@@ -211,14 +231,14 @@ extern "C" int fyc_layernorm(const fyc_layernorm_args* a, void* stream) {
   FYC_REQUIRE(a->C % 8 == 0 && a->C <= 2048 && a->rows > 0, "fyc_layernorm: C=%d (multiple of 8, <= 2048)", a->C);
   FYC_REQUIRE(a->pe == nullptr || (a->pe_div > 0 && a->pe_rows > 0), "fyc_layernorm: pe_div/pe_rows");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((a->rows + 3) / 4);
+  dim3 grid((a->rows + 15) / 16);
   const int pd = a->pe ? a->pe_div : 1, pr = a->pe ? a->pe_rows : 1;
 #define FYC_LN(T, MAXC8) hipLaunchKernelGGL((layernorm_kernel<T, MAXC8>), grid, dim3(256), 0, st, (const T*)a->x, a->gamma, a->beta, a->pe, (T*)a->y, a->rows, a->C, a->eps, pd, pr)
-  const int need = (a->C / 8 + 63) / 64;
+  const int need = (a->C / 8 + 15) / 16;  // 16-B chunks per lane
   if (a->dtype == FYC_BF16) {
-    if (need <= 1) FYC_LN(bf16_t, 1); else if (need <= 2) FYC_LN(bf16_t, 2); else FYC_LN(bf16_t, 4);
+    if (need <= 3) FYC_LN(bf16_t, 3); else if (need <= 5) FYC_LN(bf16_t, 5); else if (need <= 10) FYC_LN(bf16_t, 10); else FYC_LN(bf16_t, 16);
   } else if (a->dtype == FYC_F32) {
-    if (need <= 1) FYC_LN(float, 1); else if (need <= 2) FYC_LN(float, 2); else FYC_LN(float, 4);
+    if (need <= 3) FYC_LN(float, 3); else if (need <= 5) FYC_LN(float, 5); else if (need <= 10) FYC_LN(float, 10); else FYC_LN(float, 16);
   } else FYC_FAIL(-2, "fyc_layernorm: bad dtype");
 #undef FYC_LN
   FYC_CHECK_LAUNCH("fyc_layernorm");

@@ -65,8 +65,8 @@ class HipOps:
         L.check(self.lib.fyc_device_caps(caps), "fyc_device_caps")
         return list(caps)
 
-    def set_gemm_staging(self, staging: int) -> None:
-        L.check(self.lib.fyc_set_gemm_staging(staging), "fyc_set_gemm_staging")
+    def set_tuning(self, key: int, value: int) -> None:
+        L.check(self.lib.fyc_set_tuning(key, value), "fyc_set_tuning")
 
     @staticmethod
     def _stream() -> int:
@@ -80,7 +80,7 @@ class HipOps:
              ldo: int = 0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None, rows_per_batch: int = 1,
              residual: Optional[Tensor] = None, ldr: int = 0, ldrb: int = 0, out_scale: float = 1.0, epilogue: int = L.EPI_LINEAR,
              mode: int = L.GEMM_PLAIN, conv: Optional[dict] = None, batch: int = 1, stride_a: int = 0,
-             stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None) -> None:
+             stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None, tile: int = 0) -> None:
         self.ensure_init(a.device)
         g = L.GemmArgs()
         g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
@@ -88,6 +88,7 @@ class HipOps:
         g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldr, g.ldrb = M, N, K, lda, ldw, ldo, ldr, ldrb
         g.stride_a, g.stride_w, g.stride_o, g.batch = stride_a, stride_w, stride_o, batch
         g.mode, g.epilogue, g.rows_per_batch, g.out_scale, g.dtype = mode, epilogue, rows_per_batch, out_scale, _dt(a)
+        g.tile = tile
         if a.dtype != w.dtype:
             raise TypeError(f"gemm: activation {a.dtype} vs weight {w.dtype}")
         if conv is not None:

@@ -28,8 +28,8 @@ class TimedOps:
     def ensure_init(self, device):
         return self.inner.ensure_init(device)
 
-    def set_gemm_staging(self, s):
-        return self.inner.set_gemm_staging(s)
+    def set_tuning(self, key, value):
+        return self.inner.set_tuning(key, value)
 
     def device_caps(self):
         return self.inner.device_caps()

@@ -38,8 +38,9 @@ const char* fyc_last_error(void);
 int fyc_init(const void* zero_page);
 /* fills caps[0..7]: CU count, LDS bytes/CU, wave size, gfx arch number (950), clock kHz, L2 bytes, 0, 0 */
 int fyc_device_caps(int64_t* caps);
-/* staging: 0 = direct global->LDS DMA (default), 1 = register staging (A/B test + bring-up hedge) */
-int fyc_set_gemm_staging(int staging);
+/* tuning knobs for A/B measurements (0 = automatic): key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
+ * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant */
+int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------
  * out[m][n] = ( sum_k A[m][k] * W[n][k] + bias[n] + rowbias[m / rows_per_batch][n] + residual[m][n] ) * out_scale
@@ -74,6 +75,7 @@ typedef struct {
   int32_t seg_cols, heads, tokens; /* HEADS: columns per segment (=heads*d), tokens per batch element */
   float out_scale;
   int32_t dtype;
+  int32_t tile;          /* 0 = automatic; else tile config id | ring depth << 8 (see fyc_set_tuning) */
 } fyc_gemm_args;
 int fyc_gemm(const fyc_gemm_args* a, void* stream);
 

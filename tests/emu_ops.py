@@ -34,13 +34,13 @@ class EmuOps:
     def ensure_init(self, device):
         pass
 
-    def set_gemm_staging(self, s):
+    def set_tuning(self, key, value):
         pass
 
     # ------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
              ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
-             heads=None):
+             heads=None, tile=0):
         acc_t = self.acc
         af, wf = _flat(a), _flat(w)
         for z in range(batch):

@@ -75,4 +75,4 @@ def test_argument_validation_without_gpu(lib):
     rc = lib.fyc_gemm(ctypes.byref(g), None)
     assert rc != 0 and b"fyc" in lib.fyc_last_error()
     assert lib.fyc_init(None) != 0
-    assert lib.fyc_set_gemm_staging(7) != 0
+    assert lib.fyc_set_tuning(99, 1) != 0

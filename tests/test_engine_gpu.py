@@ -117,7 +117,7 @@ def test_sampling_loop_vs_reference_pipeline(golden_dir, dtype, tol_lat, tol_vid
     assert e < tol_vid, e
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 6e-2)])
 def test_vae_decode_vs_reference_golden(golden_dir, dtype, tol):
     g = _load(golden_dir, "vae_tiny.npz")
     vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
