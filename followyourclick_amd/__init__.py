@@ -1,0 +1,31 @@
+"""followyourclick_amd - MI355X-native denoising engine for FollowYourClick's AnimateDiff-style sampling loop.
+
+    import followyourclick_amd
+    followyourclick_amd.install_dropin()       # `animatediff`, `diffusers`, `ip_adapter` now resolve to this engine
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+
+The compute library (libfyc_hip.so, hand-written gfx950 HIP kernels behind the C ABI of include/fyc.h) is
+required: there is no CPU or eager-PyTorch fallback.
+"""
+import os
+import sys
+
+__version__ = "0.1.0"
+DROPIN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
+
+
+def install_dropin(force: bool = False) -> str:
+    """Put the drop-in `animatediff` / `diffusers` / `ip_adapter` packages first on sys.path so that the
+    reference's scripts import this engine instead of the reference's torch modules."""
+    loaded = [m for m in ("animatediff", "diffusers", "ip_adapter") if m in sys.modules
+              and not getattr(sys.modules[m], "__file__", "").startswith(DROPIN_DIR)]
+    if loaded and not force:
+        raise RuntimeError(f"{loaded} already imported from elsewhere; call install_dropin() before importing them "
+                           "(or pass force=True to evict them)")
+    for name in [k for k in sys.modules if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")]:
+        if force or name.split(".")[0] in loaded:
+            del sys.modules[name]
+    if DROPIN_DIR in sys.path:
+        sys.path.remove(DROPIN_DIR)
+    sys.path.insert(0, DROPIN_DIR)
+    return DROPIN_DIR

@@ -1,0 +1,4 @@
+"""Drop-in for the names the reference imports from its vendored diffusers 0.11.1 on the hot path."""
+__version__ = "0.11.1+fyc.mi355x"
+from .models.vae import AutoencoderKL  # noqa: F401,E402
+from .schedulers.scheduling_ddim import DDIMScheduler  # noqa: F401,E402

@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: two gloo ranks share weights by broadcast and denoise disjoint clips
+(the engine runs on the op emulator here; -m gpu covers the kernels)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from emu_ops import EmuOps
+    from followyourclick_amd import distributed as D
+    from followyourclick_amd.engine import DDIMConfig, UNet3DConfig
+    from followyourclick_amd.engine.sampler import DDIMSampler
+    from followyourclick_amd.engine.schema import random_state_dict, unet_schema
+    from followyourclick_amd.engine.unet3d import UNet3DEngine
+    from followyourclick_amd.engine.weights import pack_unet
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = UNet3DConfig(block_out_channels=(64, 128, 256, 256), cross_attention_dim=64, sample_size=8)
+    # only rank 0 has real weights; the others start from garbage and must receive the broadcast
+    sd = random_state_dict(unet_schema(cfg), seed=0, materialize=True) if rank == 0 else \
+        {k: torch.full_like(v, 7.0) for k, v in random_state_dict(unet_schema(cfg), seed=1).items()}
+    P = pack_unet(sd, cfg, torch.float32, "cpu")
+    moved = D.broadcast_packed(P, src=0, bucket_bytes=1 << 20)
+    assert moved > 0
+    eng = UNet3DEngine(P, ops=EmuOps())
+    n_clips = 3
+    mine = D.shard_indices(n_clips, rank, world)
+    res = {}
+    for i in mine:
+        g = torch.Generator().manual_seed(100 + i)
+        lat = torch.randn(1, 4, 2, 8, 8, generator=g)
+        first = torch.randn(1, 4, 8, 8, generator=g)
+        text = torch.randn(2, 77, 64, generator=g)
+        res[i] = DDIMSampler(eng, DDIMConfig()).sample(lat, text, 2, 8.0, first, None, fps=[2], flow=[4])
+    D.barrier()
+    t = D.max_over_ranks(float(rank + 1), "cpu")
+    assert t == float(world)
+    torch.save({"clips": res, "w": P.conv_in_w.clone(), "temb": P.temb_w[:4].clone()}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_weights_and_split_clips(tmp_path):
+    world, port = 2, 29741
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in (0, 1))
+    assert torch.equal(a["w"], b["w"]) and torch.equal(a["temb"], b["temb"])        # weights arrived bit-exact
+    assert sorted(a["clips"]) == [0, 2] and sorted(b["clips"]) == [1]                 # clip i -> rank i mod world
+    # a clip's result does not depend on which rank ran it: recompute clip 1 with rank 0's weights
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emu_ops import EmuOps
+    from followyourclick_amd.engine import DDIMConfig, UNet3DConfig
+    from followyourclick_amd.engine.sampler import DDIMSampler
+    from followyourclick_amd.engine.schema import random_state_dict, unet_schema
+    from followyourclick_amd.engine.unet3d import UNet3DEngine
+    from followyourclick_amd.engine.weights import pack_unet
+    cfg = UNet3DConfig(block_out_channels=(64, 128, 256, 256), cross_attention_dim=64, sample_size=8)
+    eng = UNet3DEngine(pack_unet(random_state_dict(unet_schema(cfg), 0), cfg, torch.float32, "cpu"), ops=EmuOps())
+    g = torch.Generator().manual_seed(101)
+    lat, first, text = torch.randn(1, 4, 2, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g), torch.randn(2, 77, 64, generator=g)
+    ref = DDIMSampler(eng, DDIMConfig()).sample(lat, text, 2, 8.0, first, None, fps=[2], flow=[4])
+    assert torch.allclose(ref, b["clips"][1], atol=1e-5)
+
+
+def test_shard_indices():
+    from followyourclick_amd.distributed import shard_indices
+    assert [shard_indices(8, r, 8) for r in range(8)] == [[r] for r in range(8)]
+    assert shard_indices(5, 1, 2) == [1, 3] and shard_indices(1, 3, 8) == []

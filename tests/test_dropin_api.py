@@ -1,0 +1,131 @@
+"""API surface of the drop-in packages (CPU): import paths, constructor / call signatures compared with the
+reference's (recorded from the reference source), state-dict schema, error behaviour."""
+import inspect
+import os
+import sys
+
+import pytest
+import torch
+
+import followyourclick_amd
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    followyourclick_amd.install_dropin(force=True)
+    yield
+    for name in [k for k in sys.modules if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")]:
+        del sys.modules[name]
+    if followyourclick_amd.DROPIN_DIR in sys.path:
+        sys.path.remove(followyourclick_amd.DROPIN_DIR)
+
+
+# parameter names of the reference signatures (animatediff/pipelines/pipeline_animation.py:547-584,
+# animatediff/models/unet.py:422-444)
+PIPE_CALL = ["prompt", "video_length", "height", "width", "num_inference_steps", "guidance_scale", "negative_prompt",
+             "num_videos_per_prompt", "eta", "generator", "latents", "output_type", "return_dict", "callback", "callback_steps",
+             "use_first_frame_condition", "use_first_frame_condition_concat", "use_first_frame_mask_condition_concat",
+             "use_first_frame_mask_condition_concat_image_partial_mask", "first_image_latents", "use_first_image_as_init_latents",
+             "video_scale", "use_ip_cross_attention", "condition_images", "use_uncond_images", "use_camera_motion_condition",
+             "camera_movement_type", "use_text_encoder_2", "use_uncond_text_2", "use_fps_condition", "fps_tensor",
+             "use_interpolate_noise", "first_images_mask", "flow_control", "kwargs"]
+UNET_FWD = ["sample", "timestep", "encoder_hidden_states", "class_labels", "attention_mask", "return_dict",
+            "use_first_frame_condition", "use_first_frame_condition_concat", "use_ip_cross_attention", "reference_images_latent",
+            "reference_images_clip_feat", "use_camera_motion_condition", "camera_movement_type_tensor", "use_image_concat_training",
+            "use_text_encoder_2", "encoder_hidden_states_2", "use_fps_condition", "fps_tensor", "first_images_mask", "flow_control"]
+
+MM = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+          temporal_position_encoding=True, temporal_position_encoding_max_len=24, temporal_attention_dim_div=1, zero_initialize=True)
+TINY = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(64, 128, 256, 256), layers_per_block=2,
+            cross_attention_dim=64, attention_head_dim=8, use_motion_module=True, motion_module_resolutions=(1, 2, 4, 8),
+            unet_use_cross_frame_attention=False, unet_use_temporal_attention=False, use_fps_condition=True,
+            use_first_frame_mask_condition_concat=True, motion_module_type="Vanilla", motion_module_kwargs=MM)
+
+
+def test_signatures_match_reference(dropin):
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    assert [p for p in inspect.signature(AnimationPipeline.__call__).parameters][1:] == PIPE_CALL
+    assert [p for p in inspect.signature(UNet3DConditionModel.forward).parameters][1:] == UNET_FWD
+    ctor = inspect.signature(AnimationPipeline.__init__).parameters
+    assert list(ctor)[1:] == ["vae", "text_encoder", "tokenizer", "unet", "scheduler", "image_encoder", "text_encoder_2", "tokenizer_2", "ip_adapter"]
+    from diffusers.utils.import_utils import is_xformers_available
+    assert is_xformers_available()
+
+
+def test_unet_state_dict_has_reference_keys(dropin, golden_dir):
+    import json
+    from animatediff.models.unet import UNet3DConditionModel
+    unet = UNet3DConditionModel(**TINY)
+    with open(os.path.join(golden_dir, "schema_unet_tiny.json")) as f:
+        ref = {k: tuple(v) for k, v in json.load(f).items()}
+    mine = {k: tuple(v.shape) for k, v in unet.state_dict().items()}
+    assert mine == ref
+    assert unet.in_channels == 4 and unet.config.sample_size == 8 and unet.config.cross_attention_dim == 64
+    # zero-initialised tensors of the reference (motion proj_out, fps/motion linear_2)
+    assert unet.state_dict()["down_blocks.0.motion_modules.0.temporal_transformer.proj_out.weight"].abs().sum() == 0
+    assert unet.state_dict()["fps_embedding.linear_2.weight"].abs().sum() == 0
+    # checkpoints with a `module.` prefix / partial key sets load the way scripts/inference.py:170-181 expects
+    sd = {"down_blocks.0.motion_modules.0.temporal_transformer.proj_out.weight": torch.ones(64, 64), "bogus.key": torch.zeros(1)}
+    missing, unexpected = unet.load_state_dict(sd, strict=False)
+    assert unexpected == ["bogus.key"] and len(missing) == len(ref) - 1
+    unet.enable_xformers_memory_efficient_attention()
+    unet.set_attention_slice("auto")
+
+
+def test_unsupported_options_fail_loudly(dropin):
+    from animatediff.models.unet import UNet3DConditionModel
+    with pytest.raises(NotImplementedError):
+        UNet3DConditionModel(**dict(TINY, use_inflated_groupnorm=True))
+    unet = UNet3DConditionModel(**TINY)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        unet(torch.zeros(2, 9, 4, 8, 8), torch.tensor(1), torch.zeros(2, 77, 64))
+
+
+def test_scheduler_surface(dropin, golden_dir):
+    import numpy as np
+    from diffusers import DDIMScheduler
+    g = np.load(os.path.join(golden_dir, "ddim.npz"))
+    s = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+                      clip_sample=False, prediction_type="v_prediction", rescale_betas_zero_snr=True)
+    assert s.order == 1 and s.init_noise_sigma == 1.0 and s.config.steps_offset == 1 and s.config.clip_sample is False
+    with pytest.raises(ValueError):
+        s.step(torch.zeros(1), 1, torch.zeros(1))
+    s.set_timesteps(25)
+    assert np.array_equal(s.timesteps.numpy(), g["timesteps_25"])
+    x, v = torch.from_numpy(g["step_sample"]), torch.from_numpy(g["step_model_output"])
+    assert torch.allclose(s.step(v, 961, x, eta=0.0).prev_sample, torch.from_numpy(g["step_out_t961"]), atol=1e-6)
+    assert torch.equal(s.scale_model_input(x, 5), x)
+
+
+def test_pipeline_argument_errors(dropin):
+    """the reference's ValueErrors (pipeline_animation.py:432-445, 517-518) before any GPU work"""
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import AutoencoderKL, DDIMScheduler
+    from oracle import stubs
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4)
+    pipe = AnimationPipeline(vae=vae, text_encoder=stubs.StubTextEncoder(64), tokenizer=stubs.FakeTokenizer(),
+                             unet=UNet3DConditionModel(**TINY), scheduler=DDIMScheduler(steps_offset=0, clip_sample=True))
+    assert pipe.scheduler.config.steps_offset == 1 and pipe.scheduler.config.clip_sample is False and pipe.vae_scale_factor == 8
+    with pytest.raises(ValueError, match="divisible by 8"):
+        pipe("x", video_length=4, height=60, width=64, use_first_frame_mask_condition_concat=True, first_image_latents=torch.zeros(1, 4, 8, 8))
+    with pytest.raises(ValueError, match="prompt"):
+        pipe(3, video_length=4, height=64, width=64)
+    with pytest.raises(ValueError, match="callback_steps"):
+        pipe("x", video_length=4, height=64, width=64, callback_steps=0)
+    with pytest.raises(ValueError, match="Unexpected latents shape"):
+        pipe("x", video_length=4, height=64, width=64, latents=torch.zeros(1, 4, 3, 8, 8), use_first_frame_mask_condition_concat=True,
+             first_image_latents=torch.zeros(1, 4, 8, 8))
+    with pytest.raises(NotImplementedError):
+        pipe("x", video_length=4, height=64, width=64, use_first_frame_condition=True)
+
+
+def test_attention_processor_surface(dropin):
+    import ip_adapter.attention_processor as ap
+    for n in ("AttnProcessor", "IPAttnProcessor", "AttnProcessor2_0", "IPAttnProcessor2_0", "CNAttnProcessor", "CNAttnProcessor2_0"):
+        assert hasattr(ap, n)
+    p = ap.IPAttnProcessor(hidden_size=320, cross_attention_dim=768, scale=0.5, num_tokens=16)
+    assert p.to_k_ip.weight.shape == (320, 768) and p.to_v_ip.bias is None and p.num_tokens == 16 and p.scale == 0.5
+    assert list(inspect.signature(p.__call__).parameters) == ["attn", "hidden_states", "encoder_hidden_states", "attention_mask", "temb"]
+    assert isinstance(p, torch.nn.Module) and not isinstance(ap.CNAttnProcessor(), torch.nn.Module)

@@ -1,0 +1,129 @@
+"""The drop-in API surface on a real MI355X: the same calls scripts/inference.py makes, compared with the
+REAL reference's outputs (tests/golden/pipeline_tiny.npz was produced by the reference AnimationPipeline
+with these very test doubles for tokenizer / text encoder)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import followyourclick_amd
+from oracle import functional as Fn
+from oracle import stubs
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+MM = dict(num_attention_heads=8, num_transformer_block=1, attention_block_types=["Temporal_Self", "Temporal_Self"],
+          temporal_position_encoding=True, temporal_position_encoding_max_len=24, temporal_attention_dim_div=1, zero_initialize=True)
+TINY = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(64, 128, 256, 256), layers_per_block=2,
+            cross_attention_dim=64, attention_head_dim=8, use_motion_module=True, motion_module_resolutions=(1, 2, 4, 8),
+            unet_use_cross_frame_attention=False, unet_use_temporal_attention=False, use_fps_condition=True,
+            use_first_frame_mask_condition_concat=True, motion_module_type="Vanilla", motion_module_kwargs=MM)
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    followyourclick_amd.install_dropin(force=True)
+    yield
+    for name in [k for k in sys.modules if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")]:
+        del sys.modules[name]
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) if v.shape else v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1.5e-1, 1e-1)])
+def test_animation_pipeline_call(dropin, golden_dir, dtype, tol_lat, tol_vid):
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import AutoencoderKL, DDIMScheduler
+    g = _load(golden_dir, "pipeline_tiny.npz")
+    unet = UNet3DConditionModel(**TINY, compute_dtype=dtype)
+    m, u = unet.load_state_dict(W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["unet_weight_seed"])), strict=False)
+    assert not m and not u
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4, compute_dtype=dtype)
+    vae.load_state_dict(W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["vae_weight_seed"])), strict=False)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+                          clip_sample=False, prediction_type="v_prediction", rescale_betas_zero_snr=True)
+    pipe = AnimationPipeline(vae=vae, text_encoder=stubs.StubTextEncoder(64), tokenizer=stubs.FakeTokenizer(), unet=unet,
+                             scheduler=sched).to("cuda")
+    traj = []
+    out = pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=5, guidance_scale=8.0,
+               negative_prompt="blurry", latents=g["latents"].clone(), first_image_latents=g["first_image_latents"].cuda(),
+               first_images_mask=g["first_images_mask"].cuda(), use_first_frame_mask_condition_concat=True,
+               use_fps_condition=True, fps_tensor=torch.tensor([2]), flow_control=torch.tensor([4]),
+               callback=lambda i, t, l: traj.append(l.clone().cpu()), callback_steps=1,
+               use_first_frame_mask_condition_concat_zero_padding=True)        # unknown kwarg swallowed like the reference
+    traj = torch.stack(traj)
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < tol_lat, err
+    assert isinstance(out.videos, torch.Tensor) and out.videos.dtype == torch.float32 and out.videos.device.type == "cpu"
+    assert out.videos.shape == g["videos"].shape
+    e = ((out.videos - g["videos"]).norm() / g["videos"].norm()).item()
+    assert e < tol_vid, e
+
+
+def test_unet_module_forward_and_reload(dropin, golden_dir):
+    from animatediff.models.unet import UNet3DConditionModel
+    g = _load(golden_dir, "unet_tiny_fwd.npz")
+    unet = UNet3DConditionModel(**TINY, compute_dtype=torch.float32).to("cuda")
+    unet.load_state_dict(W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"])))
+    out = unet(g["sample"].cuda(), torch.tensor(int(g["timestep"])), g["text"].cuda(), use_fps_condition=True,
+               fps_tensor=g["fps"].cuda(), flow_control=g["flow"].cuda()).sample.cpu()
+    assert ((out - g["out"]).norm() / g["out"].norm()).item() < 1e-3
+    # changing a weight must invalidate the packed engine copy
+    with torch.no_grad():
+        unet.conv_out.bias.add_(1.0)
+    out2 = unet(g["sample"].cuda(), torch.tensor(int(g["timestep"])), g["text"].cuda(), use_fps_condition=True,
+                fps_tensor=g["fps"].cuda(), flow_control=g["flow"].cuda()).sample.cpu()
+    assert torch.allclose(out2, out + 1.0, atol=2e-3)
+
+
+class _HostAttn(torch.nn.Module):
+    """the host attention module a diffusers>=0.17 UNet hands to a processor"""
+
+    def __init__(self, C, ctx, heads):
+        super().__init__()
+        self.heads, self.scale = heads, (C // heads) ** -0.5
+        self.to_q, self.to_k, self.to_v = (torch.nn.Linear(C, C, bias=False), torch.nn.Linear(ctx, C, bias=False), torch.nn.Linear(ctx, C, bias=False))
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(C, C), torch.nn.Dropout(0.0)])
+        self.spatial_norm = self.group_norm = None
+        self.norm_cross, self.residual_connection, self.rescale_output_factor = False, True, 1.0
+
+
+def _ref_core(q, k, v, heads, scale):
+    B, N, C = q.shape
+    d = C // heads
+    sp = lambda t: t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3)
+    o = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * scale, -1) @ sp(v)
+    return o.permute(0, 2, 1, 3).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_ip_attention_processors(dropin, dtype, tol):
+    import ip_adapter.attention_processor as ap
+    torch.manual_seed(0)
+    C, ctx, heads, ntok = 320, 768, 8, 4
+    attn = _HostAttn(C, ctx, heads).cuda().to(dtype)
+    proc = ap.IPAttnProcessor2_0(hidden_size=C, cross_attention_dim=ctx, scale=0.6, num_tokens=ntok).cuda().to(dtype)
+    x = torch.randn(2, C, 8, 8, device="cuda", dtype=dtype)          # 4-D input form
+    enc = torch.randn(2, 77 + ntok, ctx, device="cuda", dtype=dtype)
+    out = proc(attn, x, enc)
+    with torch.no_grad():                                            # the reference's math in torch fp32
+        import copy
+        a32, p32 = copy.deepcopy(attn).float(), copy.deepcopy(proc).float()
+        h = x.float().view(2, C, 64).transpose(1, 2)
+        q = a32.to_q(h)
+        t, ip = enc.float()[:, :77], enc.float()[:, 77:]
+        o = _ref_core(q, a32.to_k(t), a32.to_v(t), heads, a32.scale) + 0.6 * _ref_core(q, p32.to_k_ip(ip), p32.to_v_ip(ip), heads, a32.scale)
+        ref = a32.to_out[0](o).transpose(-1, -2).reshape(2, C, 8, 8) + x.float()
+    assert out.shape == x.shape
+    assert ((out.float() - ref).norm() / ref.norm()).item() < tol
+    attn_self = _HostAttn(C, C, heads).cuda().to(dtype)
+    plain = ap.AttnProcessor()(attn_self, x.view(2, C, 64).transpose(1, 2).contiguous(), None)       # self-attention, 3-D form
+    assert plain.shape == (2, 64, C) and torch.isfinite(plain.float()).all()
+    cn = ap.CNAttnProcessor(num_tokens=ntok)(attn, x, enc)
+    assert cn.shape == x.shape
