@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfyc_hip.so")
+LIB_PATH = os.environ.get("FYC_LIB_PATH") or os.path.join(HERE, "libfyc_hip.so")   # FYC_LIB_PATH: A/B builds
 
 FYC_F32, FYC_BF16 = 0, 1
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_CONV3X3_UP2 = 0, 1, 2

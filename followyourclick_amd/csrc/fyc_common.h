@@ -119,6 +119,20 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// exact-erf GELU, x * Phi(x) (F.gelu default, reference diffusers/models/attention.py:815), with erfc from
+// Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, no cancellation on the negative side): ~12 VALU ops
+// instead of ~40 for erff() - the GEGLU epilogue was 24 % of the K=320 FF GEMM (profiles/r01_gemm_epilogue_ablation.txt)
+__device__ __forceinline__ float gelu_erf_f(float g) {
+  const float z = fabsf(g) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float e = poly * t * __expf(-z * z);      // erfc(z)
+  return 0.5f * g * (g >= 0.f ? 2.0f - e : e);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

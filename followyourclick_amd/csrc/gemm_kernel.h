@@ -84,52 +84,68 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
+  // Persistent tile stream: a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and treats their
+  // K tiles as ONE continuous DMA stream, so the first K tiles of the next output tile are already in
+  // flight while the current tile runs its last MFMAs and its epilogue (hides launch + first-fill latency,
+  // which is ~1/4 of the time of the K=320 layers).
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles
   // (n fastest) so the A panel of a row-block is fetched into one L2 only.  Bijective for any count.
-  int t = blockIdx.x;
-  {
-    const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7, xcd = t & 7, idx = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  auto remap = [&](int t) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7, idx = t >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  };
   const long long bz = blockIdx.z;
   const T* __restrict__ A = reinterpret_cast<const T*>(p.a) + bz * p.stride_a;
   const T* __restrict__ W = reinterpret_cast<const T*>(p.w) + bz * p.stride_w;
   const T* zero = reinterpret_cast<const T*>(p.zero);
 
-  // ---- per-thread loader descriptors ------------------------------------------------------
+  // ---- per-thread loader descriptors of the tile being ISSUED ----------------------------------
   int a_koff[A_IT];
   long long a_row[A_IT];   // PLAIN: m*lda, or -1 when the row is outside M
   int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+  int b_koff[B_IT];
+  long long b_row[B_IT];
+  int tap = 0, c0 = 0;  // conv: filter tap and channel offset of the K tile being issued
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int idx = tid + it * NT, row = idx >> 3, slot = idx & 7;
     a_koff[it] = ((slot ^ (row & 7)) * CH);
-    const int m = tile_m * BM + row;
-    if (MODE == FYC_GEMM_PLAIN) {
-      a_row[it] = (m < p.M) ? (long long)m * p.lda : -1;
-      a_pix[it] = a_iy0[it] = a_ix0[it] = 0;
-    } else {
-      const int hw = p.Hout * p.Wout;
-      const int fr = m / hw, rem = m - fr * hw, oy = rem / p.Wout, ox = rem - oy * p.Wout;
-      a_row[it] = (m < p.M) ? 0 : -1;
-      a_pix[it] = fr * p.Hin * p.Win;
-      a_iy0[it] = oy * p.conv_stride - 1;
-      a_ix0[it] = ox * p.conv_stride - 1;
-    }
   }
-  int b_koff[B_IT];
-  long long b_row[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int idx = tid + it * NT, row = idx >> 3, slot = idx & 7;
     b_koff[it] = ((slot ^ (row & 7)) * CH);
-    const int n = tile_n * BN + row;
-    b_row[it] = (n < p.N) ? (long long)n * p.ldw : -1;
   }
+  auto setup_issue = [&](int tile) {
+    const int t = remap(tile);
+    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    tap = 0; c0 = 0;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int row = (tid + it * NT) >> 3;
+      const int m = tile_m * BM + row;
+      if (MODE == FYC_GEMM_PLAIN) {
+        a_row[it] = (m < p.M) ? (long long)m * p.lda : -1;
+        a_pix[it] = a_iy0[it] = a_ix0[it] = 0;
+      } else {
+        const int hw = p.Hout * p.Wout;
+        const int fr = m / hw, rem = m - fr * hw, oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        a_row[it] = (m < p.M) ? 0 : -1;
+        a_pix[it] = fr * p.Hin * p.Win;
+        a_iy0[it] = oy * p.conv_stride - 1;
+        a_ix0[it] = ox * p.conv_stride - 1;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int row = (tid + it * NT) >> 3;
+      const int n = tile_n * BN + row;
+      b_row[it] = (n < p.N) ? (long long)n * p.ldw : -1;
+    }
+  };
 
   const int KT = (p.K + BK - 1) / BK;
-  int tap = 0, c0 = 0;  // conv: filter tap and channel offset of the K tile being *issued*
 
   auto src_a = [&](int it, int k0) -> const T* {
     if (MODE == FYC_GEMM_PLAIN) {
@@ -153,10 +169,6 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   };
 
   f32x4 acc[WTM][WTN];
-#pragma unroll
-  for (int i = 0; i < WTM; ++i)
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int sw = lane & 7, g = lane >> 4, r16 = lane & 15;
   auto compute = [&](int stage) {
@@ -190,23 +202,44 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     }
   };
 
-  // ---- main loop: NS-deep ring, counted waits ----------------------------------------------------
+  // ---- main loop: NS-deep ring over the continuous K-tile stream, counted waits -------------------
+  int i_tile = blockIdx.x, i_kt = 0;      // issue side of the stream
+  int st_c = 0, st_i = 0;                 // stage being computed / issued
+  int n_ahead = 0;                        // stream elements issued and not yet consumed
+  auto issue_next = [&]() {
+    issue(i_kt, st_i);
+    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
+    ++n_ahead;
+    if (++i_kt == KT) {
+      i_kt = 0;
+      i_tile += gridDim.x;
+      if (i_tile < ntiles) setup_issue(i_tile);
+    }
+  };
+  if (i_tile < ntiles) setup_issue(i_tile);
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (s < KT) issue(s, s);
-  int st_c = 0, st_i = NS - 1;  // stage being computed / issued
-  for (int kt = 0; kt < KT; ++kt) {
-    // tiles kt+1 .. min(kt+NS-2, KT-1) may stay in flight; tile kt must have landed
-    const int ahead = min(NS - 2, KT - 1 - kt);
-    if (NS >= 4 && ahead == 2) wait_vmcnt<2 * LOADS>();
-    else if (NS >= 3 && ahead == 1) wait_vmcnt<LOADS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + NS - 1 < KT) issue(kt + NS - 1, st_i);
-    compute(st_c);
-    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
-    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
-  }
+    if (i_tile < ntiles) issue_next();
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) {
+      // the oldest in-flight element must have landed; up to NS-2 younger ones may stay in flight
+      const int ahead = min(NS - 2, n_ahead - 1);
+      if (NS >= 4 && ahead == 2) wait_vmcnt<2 * LOADS>();
+      else if (NS >= 3 && ahead == 1) wait_vmcnt<LOADS>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      --n_ahead;
+      if (i_tile < ntiles) issue_next();
+      compute(st_c);
+      st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    }
+    const int t = remap(tile);
+    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
 
   // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
@@ -226,7 +259,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
         for (int r = 0; r < 4; ++r) {
           float h = acc[i][j][r], gt = acc[i][j + 1][r];
           if (p.bias) { h += p.bias[n + r]; gt += p.bias[n + 16 + r]; }
-          v[r] = h * (0.5f * gt * (1.0f + erff(gt * 0.70710678118654752440f)));
+          v[r] = h * gelu_erf_f(gt);
         }
         const int oc = (n >> 5) * 16 + (n & 15);
         ElemIO<T>::st4(O + (long long)m * p.ldo + oc, v);
@@ -289,6 +322,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       }
     }
   }
+  }  // tile stream
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS>
@@ -304,7 +338,22 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   GemmP q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid(q.tiles_m * q.tiles_n, 1, batch);
+  // persistent grid: as many blocks as stay resident (LDS-limited), each walks a strided tile list
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  int occ = (160 * 1024) / smem;
+  const int wave_cap = 32 / (WGM * WGN);
+  if (occ > wave_cap) occ = wave_cap;
+  if (occ < 1) occ = 1;
+  long long resident = (long long)n_cu * occ / (batch > 0 ? batch : 1);
+  if (resident < n_cu) resident = n_cu;
+  const long long ntiles = (long long)q.tiles_m * q.tiles_n;
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident), 1, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), smem, st, q);
   FYC_CHECK_LAUNCH("fyc_gemm");
   return 0;
