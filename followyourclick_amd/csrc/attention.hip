@@ -272,10 +272,16 @@ extern "C" int fyc_attention(const fyc_attn_args* a, void* stream) {
   p.sl2e = a->scale * 1.44269504088896340736f; p.o_scale = a->o_scale;
   p.nqb = 0; p.zero = (const char*)g_fyc_zero_page;
   hipStream_t st = (hipStream_t)stream;
-  if (a->d <= 32) return launch_attn<32, 2, 2>(p, st);
-  if (a->d <= 48) return launch_attn<64, 3, 2>(p, st);
-  if (a->d <= 64) return launch_attn<64, 4, 2>(p, st);
-  if (a->d <= 80) return launch_attn<96, 5, 2>(p, st);
+  // 64 queries per wave (QT=4) amortises the K / V^T fragment reads over twice the MFMAs; it needs n_q large
+  // enough to still fill the chip.  tuning key 3 forces QT (A/B measurements).
+  const long long wg4 = (long long)a->batch * a->heads * ((a->n_q + 255) / 256);
+  bool qt4 = a->n_q >= 1024 && wg4 >= 512 && a->d <= 80;
+  if (g_fyc_tuning[3] == 2) qt4 = false;
+  if (g_fyc_tuning[3] == 4 && a->d <= 80) qt4 = true;
+  if (a->d <= 32) return qt4 ? launch_attn<32, 2, 4>(p, st) : launch_attn<32, 2, 2>(p, st);
+  if (a->d <= 48) return qt4 ? launch_attn<64, 3, 4>(p, st) : launch_attn<64, 3, 2>(p, st);
+  if (a->d <= 64) return qt4 ? launch_attn<64, 4, 4>(p, st) : launch_attn<64, 4, 2>(p, st);
+  if (a->d <= 80) return qt4 ? launch_attn<96, 5, 4>(p, st) : launch_attn<96, 5, 2>(p, st);
   if (a->d <= 96) return launch_attn<96, 6, 2>(p, st);
   if (a->d <= 128) return launch_attn<128, 8, 2>(p, st);
   return launch_attn<160, 10, 2>(p, st);

@@ -3,9 +3,11 @@
 //   out[m][n] = (sum_k A[m][k] * W[n][k] + bias[n] + rowbias[m/rpb][n] + residual[m][n]) * out_scale
 //
 // Data layout: activations channels-last, so a 3x3 convolution is a GEMM whose A rows are
-// gathered from shifted pixels: K is ordered (ky, kx, ci) and every 128-byte K-tile lies inside one
-// filter tap, i.e. an A-tile row is one contiguous 128-B channel slice of one input pixel (or the
-// zero page at the image border / beyond M).  Nearest-2x upsampling (Upsample3D) is folded into
+// gathered from shifted pixels: K is ordered (channel slab of 128 B, ky, kx, channel-in-slab), so every
+// K-tile lies inside one filter tap - an A-tile row is one contiguous 128-B channel slice of one input
+// pixel (or the zero page at the image border / beyond M) - and the 9 taps that re-read the same pixels
+// are consecutive K tiles: the ~6 image rows a block touches per slab stay in its XCD's 4 MiB L2
+// (tap-major order measured 58 % L2 hits on the 64x64 layers, profiles/r01_gemm_pmc.txt).  Nearest-2x upsampling (Upsample3D) is folded into
 // that gather: no 4x tensor is ever written.
 //
 // Tile: BM x BN x 128 B of K per step, WGM x WGN wave64s, each wave a (BM/WGM) x (BN/WGN) sub-tile
@@ -196,9 +198,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     for (int it = 0; it < A_IT; ++it) glds16(src_a(it, k0), sA + (it * NT + wave * 64) * 16);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) glds16(src_b(it, k0), sB + (it * NT + wave * 64) * 16);
-    if (MODE != FYC_GEMM_PLAIN) {
-      c0 += BK;
-      if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    if (MODE != FYC_GEMM_PLAIN) {  // K order = (channel slab, ky, kx, channel): the 9 taps of one 128-B slab are adjacent
+      if (++tap == 9) { tap = 0; c0 += BK; }
     }
   };
 

@@ -26,7 +26,21 @@ __global__ void __launch_bounds__(512) gn_stats_kernel(const T* __restrict__ x, 
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
-    for (int r = row_begin + r0; r < row_end; r += rpi) {
+    // 4 independent 16-B loads in flight per thread (the kernel is pure streaming: latency, not math, bounds it)
+    int r = row_begin + r0;
+    for (; r + 3 * rpi < row_end; r += 4 * rpi) {
+      float v0[8], v1[8], v2[8], v3[8];
+      load8<T>(base + (long long)r * C + c8 * 8, v0);
+      load8<T>(base + (long long)(r + rpi) * C + c8 * 8, v1);
+      load8<T>(base + (long long)(r + 2 * rpi) * C + c8 * 8, v2);
+      load8<T>(base + (long long)(r + 3 * rpi) * C + c8 * 8, v3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+        q[i] += (v0[i] * v0[i] + v1[i] * v1[i]) + (v2[i] * v2[i] + v3[i] * v3[i]);
+      }
+    }
+    for (; r < row_end; r += rpi) {
       float v[8];
       load8<T>(base + (long long)r * C + c8 * 8, v);
 #pragma unroll
@@ -189,10 +203,10 @@ extern "C" int fyc_gn_stats(const fyc_gn_stats_args* a, void* stream) {
   const int samples = a->rows / a->rows_per_sample;
   hipError_t e = hipMemsetAsync(a->stats, 0, sizeof(double) * 2 * samples * a->groups, st);
   if (e != hipSuccess) FYC_FAIL(-3, "fyc_gn_stats: memset failed: %s", hipGetErrorString(e));
-  // aim for >= ~2048 blocks in total, >= 32 rows per block
-  int chunks = (int)ceil_div64(2048, samples);
+  // aim for ~1024 blocks in total (4 per CU), >= 128 rows per block so the unrolled loop has work
+  int chunks = (int)ceil_div64(1024, samples);
   int rpb = (int)ceil_div64(a->rows_per_sample, chunks);
-  if (rpb < 32) rpb = 32;
+  if (rpb < 128) rpb = 128;
   chunks = (int)ceil_div64(a->rows_per_sample, rpb);
   dim3 grid(chunks, samples);
   const size_t sh = sizeof(float) * 2 * a->groups;

@@ -3,7 +3,7 @@
 Reference layouts: conv OIHW, linear (out, in), 1x1 conv (O, I, 1, 1); see SURVEY.md 8a'' for the key
 schema (animatediff/models/unet.py, unet_blocks.py, attention.py, motion_module.py state dicts).
 Packed layouts (activation dtype unless noted):
-  conv3x3   [O][ky][kx][I_pad]  -> (O, 9*I_pad): K order matches the implicit-GEMM gather (gemm.hip)
+  conv3x3   [O][slab][ky][kx][c]  -> (O, 9*I_pad): K order matches the implicit-GEMM gather (gemm_kernel.h)
   linear    (O, I) row-major = the GEMM's W[n][k] operand as is
   qkv       to_q | to_k | to_v stacked on O -> one GEMM per attention block
   GEGLU     ff.net.0.proj rows interleaved in blocks of 16 (value rows 16b.., then their gate rows)
@@ -26,12 +26,19 @@ def pad_channels(c: int) -> int:
     return ((c + K_ALIGN - 1) // K_ALIGN) * K_ALIGN
 
 
+def conv_slab(dtype) -> int:
+    """channels per 128-byte K tile of the implicit-GEMM conv (64 bf16 / 32 f32)"""
+    return 128 // torch.empty((), dtype=dtype).element_size()
+
+
 def pack_conv3x3(w: Tensor, dtype, device) -> Tensor:
+    """OIHW -> [O][slab][ky][kx][c in slab]: K order of gemm_kernel.h (the 9 taps of a slab are adjacent K tiles)"""
     O, I, kh, kw = w.shape
     assert kh == 3 and kw == 3
-    Ip = pad_channels(I)
-    p = torch.zeros(O, 3, 3, Ip, dtype=torch.float32)
-    p[..., :I] = w.permute(0, 2, 3, 1)
+    Ip, sl = pad_channels(I), conv_slab(dtype)
+    p = torch.zeros(O, Ip, 3, 3, dtype=torch.float32)
+    p[:, :I] = w
+    p = p.reshape(O, Ip // sl, sl, 3, 3).permute(0, 1, 3, 4, 2)
     return p.reshape(O, 9 * Ip).to(dtype).contiguous().to(device)
 
 

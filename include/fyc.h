@@ -55,7 +55,7 @@ enum { FYC_EPI_LINEAR = 0, FYC_EPI_GEGLU = 1, FYC_EPI_HEADS = 2 };
 
 typedef struct {
   const void* a;         /* PLAIN: [batch][M][lda]; CONV: NHWC input [frames][Hin][Win][Cin] */
-  const void* w;         /* [batch?][Nw][ldw], K contiguous; conv: K = 9*Cin ordered (ky,kx,ci) */
+  const void* w;         /* [batch?][Nw][ldw], K contiguous; conv: K = 9*Cin ordered (slab, ky, kx, c) with 128-byte channel slabs */
   const float* bias;     /* [N] or NULL (GEGLU: packed order) */
   const float* rowbias;  /* [M / rows_per_batch][ldrb] or NULL (ResnetBlock3D time_emb_proj add) */
   const void* residual;  /* [M][ldr] or NULL */
