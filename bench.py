@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=25)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--ip-tokens", type=int, default=0, help="configs[4]: IP-Adapter decoupled cross-attention with this many image tokens")
+    ap.add_argument("--vae", action="store_true", help="also time the VAE decode of the final latents (outside the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -93,7 +95,7 @@ def main():
     device = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
-    cfg = UNet3DConfig()
+    cfg = UNet3DConfig(use_ip_cross_attention=args.ip_tokens > 0, ip_num_tokens=max(args.ip_tokens, 4))
     if args.frames > cfg.temporal_position_encoding_max_len:
         cfg.temporal_position_encoding_max_len = args.frames
     schema = unet_schema(cfg)
@@ -110,8 +112,12 @@ def main():
     h = w = args.size // 8
     clips = [synthetic_inputs(cfg, args.frames, h, w, 1000 + rank * 100 + i, device) for i in range(args.warmup + args.steps)]
 
+    ip = None
+    if args.ip_tokens > 0:
+        ip = torch.randn(2, args.ip_tokens, cfg.cross_attention_dim, generator=torch.Generator().manual_seed(4000)).to(device)
+
     def run(c):
-        return sampler.sample(c["latents"], c["text"], args.ddim_steps, 8.0, c["first"], c["mask"], fps=[2], flow=[4])
+        return sampler.sample(c["latents"], c["text"], args.ddim_steps, 8.0, c["first"], c["mask"], fps=[2], flow=[4], ip_tokens=ip)
 
     for c in clips[: args.warmup]:
         run(c)
@@ -145,7 +151,7 @@ def main():
         timed = TimedOps(eng.ops)
         eng.ops = timed
         c = clips[-1]
-        st = sampler.prepare(c["text"], args.ddim_steps, 1, 8.0, [2], [4])
+        st = sampler.prepare(c["text"], args.ddim_steps, 1, 8.0, [2], [4], ip)
         lat = c["latents"].clone()
         first, mask = c["first"].reshape(1, cfg.in_channels, h * w).contiguous(), c["mask"][:, :, 0].reshape(1, 1, h * w).contiguous()
         timed.reset()
@@ -183,6 +189,22 @@ def main():
             at = a["flops"] / (a["ms"] * 1e-3) / 1e12
             result["roofline_attention"] = {"kernel": "fyc_attn_kernel (spatial self-attention)", "bound": "mfma", "achieved": round(at, 1),
                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(at / PEAK_BF16_TFLOPS, 4)}
+
+    if rank == 0 and args.vae:
+        from followyourclick_amd.engine import VAEDecoderConfig
+        from followyourclick_amd.engine.schema import vae_decoder_schema
+        from followyourclick_amd.engine.vae import VAEDecoderEngine
+        from followyourclick_amd.engine.weights import pack_vae_decoder
+        vcfg = VAEDecoderConfig()
+        vae = VAEDecoderEngine(pack_vae_decoder(random_state_dict(vae_decoder_schema(vcfg), 1), vcfg, dtype, device))
+        vae.decode_video(out)
+        torch.cuda.synchronize()
+        tv = time.time()
+        vid = vae.decode_video(out)
+        torch.cuda.synchronize()
+        result["vae_decode_ms"] = round(1000 * (time.time() - tv), 1)
+        result["end_to_end_frames_per_sec"] = round(args.frames / (elapsed / args.steps + result["vae_decode_ms"] / 1000), 3)
+        assert torch.isfinite(vid).all()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and os.environ.get("FYC_BENCH_CPU", "1") != "0":
         try:

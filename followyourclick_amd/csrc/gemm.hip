@@ -91,6 +91,10 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(a->epilogue == FYC_EPI_LINEAR, "fyc_gemm: bad epilogue %d", a->epilogue);
     FYC_REQUIRE(a->out != nullptr, "fyc_gemm: out is null");
   }
+  p.wide = (a->dtype == FYC_BF16 && a->epilogue == FYC_EPI_LINEAR && a->N % 8 == 0 && a->ldo % 8 == 0 && a->stride_o % 8 == 0 &&
+            ((uintptr_t)a->out % 16) == 0 && (a->residual == nullptr || (a->ldr % 8 == 0 && ((uintptr_t)a->residual % 16) == 0)) &&
+            (a->bias == nullptr || ((uintptr_t)a->bias % 16) == 0) &&
+            (a->rowbias == nullptr || (p.ldrb % 4 == 0 && ((uintptr_t)a->rowbias % 16) == 0)) && g_fyc_tuning[6] == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, (p.N % 128 == 0) ? 1 : 2, st);
   int cfg = 1, ns = 2;

@@ -38,6 +38,7 @@ struct GemmP {
   int rows_per_batch, seg_cols, heads, tokens, head_dim;
   float out_scale;
   int tiles_m, tiles_n;
+  int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
 };
 
@@ -245,6 +246,72 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
   const T* R = reinterpret_cast<const T*>(p.residual);
+  if (EPI == FYC_EPI_LINEAR && sizeof(T) == 2 && p.wide) {
+    // Wide epilogue (bf16 linear): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e. 32-B
+    // row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
+    // (profiles/r01_gemm_epilogue_ablation.txt).  Each wave therefore transposes its f32 accumulators
+    // through a private slice of the LDS stage that was consumed last and issues 16-B/lane accesses
+    // covering >=160-B contiguous row segments.  Single rounding: residual is added in f32 after staging.
+    constexpr int JG = (WTN + 1) / 2;                 // 16-column MFMA tiles per pass
+    constexpr int PITCH = JG * 64 + 16;               // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
+    static_assert(WGM * WGN * 16 * PITCH <= STAGE, "staging must fit in one ring stage");
+    __builtin_amdgcn_s_barrier();                     // every wave is done reading the stage we reuse
+    const int last = (st_c == 0) ? NS - 1 : st_c - 1;
+    char* stg = smem + last * STAGE + wave * (16 * PITCH);
+    const int n_w0 = tile_n * BN + wn * WTN * 16;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
+      const float* rb = (p.rowbias && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j0 = h * JG;
+        const int nj = (WTN - j0 < JG) ? (WTN - j0) : JG;
+        if (nj <= 0) continue;
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) {
+          const int j = j0 + jj;
+          if (j >= WTN) continue;
+          const int n = n_w0 + j * 16 + g * 4;
+          f32x4 v = acc[i][j];
+          if (n < p.N) {
+            if (p.bias) {
+              const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+              v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+            }
+            if (rb) {
+              const f32x4 r4 = *reinterpret_cast<const f32x4*>(rb + n);
+              v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+            }
+          }
+          *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int cpr = nj * 2;                         // 8-element chunks per staged row
+        for (int c = lane; c < 16 * cpr; c += 64) {
+          const int row = c / cpr, ch = c - row * cpr;
+          const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
+          const int n = n_w0 + j0 * 16 + ch * 8;
+          if (m < p.M && n < p.N) {
+            float v[8];
+            *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
+            *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
+            if (R) {
+              float rr[8];
+              load8<T>(R + (long long)m * p.ldr + n, rr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += rr[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+            store8<T>(O + (long long)m * p.ldo + n, v);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    continue;  // next tile of the stream
+  }
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
     const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
