@@ -11,7 +11,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // LDS ring, not the MFMA rate, bounds this kernel, so the widest tile that still fills the chip wins.
   ns = 2;
   if (p.N % 320 == 0) {
-    if (p.M >= 16384) cfg = (p.epilogue == FYC_EPI_GEGLU) ? 6 : 5;
+    if (p.M >= 16384) cfg = 5;
     else if (p.M >= 4096) cfg = (p.N >= 5120) ? 5 : 6;
     else cfg = 2;
   } else if (p.N % 256 == 0 && p.M >= 16384) {
@@ -91,7 +91,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(a->epilogue == FYC_EPI_LINEAR, "fyc_gemm: bad epilogue %d", a->epilogue);
     FYC_REQUIRE(a->out != nullptr, "fyc_gemm: out is null");
   }
-  p.wide = (a->dtype == FYC_BF16 && a->epilogue == FYC_EPI_LINEAR && a->N % 8 == 0 && a->ldo % 8 == 0 && a->stride_o % 8 == 0 &&
+  p.wide = (a->dtype == FYC_BF16 && a->epilogue != FYC_EPI_HEADS && a->N % (a->epilogue == FYC_EPI_GEGLU ? 32 : 8) == 0 && a->ldo % 8 == 0 && a->stride_o % 8 == 0 &&
             ((uintptr_t)a->out % 16) == 0 && (a->residual == nullptr || (a->ldr % 8 == 0 && ((uintptr_t)a->residual % 16) == 0)) &&
             (a->bias == nullptr || ((uintptr_t)a->bias % 16) == 0) &&
             (a->rowbias == nullptr || (p.ldrb % 4 == 0 && ((uintptr_t)a->rowbias % 16) == 0)) && g_fyc_tuning[6] == 0) ? 1 : 0;

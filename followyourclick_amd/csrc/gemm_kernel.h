@@ -246,42 +246,59 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
   const T* R = reinterpret_cast<const T*>(p.residual);
-  if (EPI == FYC_EPI_LINEAR && sizeof(T) == 2 && p.wide) {
-    // Wide epilogue (bf16 linear): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e. 32-B
-    // row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
-    // (profiles/r01_gemm_epilogue_ablation.txt).  Each wave therefore transposes its f32 accumulators
-    // through a private slice of the LDS stage that was consumed last and issues 16-B/lane accesses
-    // covering >=160-B contiguous row segments.  Single rounding: residual is added in f32 after staging.
-    constexpr int JG = (WTN + 1) / 2;                 // 16-column MFMA tiles per pass
-    constexpr int PITCH = JG * 64 + 16;               // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
+  if (EPI != FYC_EPI_HEADS && sizeof(T) == 2 && p.wide) {
+    // Wide epilogue (bf16 linear / GEGLU): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
+    // 32-B row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
+    // (profiles/r01_gemm_epilogue_ablation.txt).  Each wave therefore transposes its f32 results through a
+    // private slice of the LDS stage that was consumed last and issues 16-B/lane accesses covering >=128-B
+    // contiguous row segments.  Single rounding: the residual is added in f32 after staging.
+    constexpr bool GLU = (EPI == FYC_EPI_GEGLU);
+    constexpr int OT = GLU ? WTN / 2 : WTN;            // 16-column output tiles per wave
+    constexpr int JG = (OT + 1) / 2;                   // output tiles per pass
+    constexpr int PITCH = JG * 64 + 16;                // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
     static_assert(WGM * WGN * 16 * PITCH <= STAGE, "staging must fit in one ring stage");
-    __builtin_amdgcn_s_barrier();                     // every wave is done reading the stage we reuse
+    __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
     const int last = (st_c == 0) ? NS - 1 : st_c - 1;
     char* stg = smem + last * STAGE + wave * (16 * PITCH);
-    const int n_w0 = tile_n * BN + wn * WTN * 16;
+    const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
+    const int o_w0 = GLU ? (n_w0 >> 1) : n_w0;         // first output column of this wave
+    const int n_out = GLU ? (p.N >> 1) : p.N;
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
-      const float* rb = (p.rowbias && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
+      const float* rb = (!GLU && p.rowbias && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j0 = h * JG;
-        const int nj = (WTN - j0 < JG) ? (WTN - j0) : JG;
+        const int nj = (OT - j0 < JG) ? (OT - j0) : JG;
         if (nj <= 0) continue;
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) {
-          const int j = j0 + jj;
-          if (j >= WTN) continue;
-          const int n = n_w0 + j * 16 + g * 4;
-          f32x4 v = acc[i][j];
-          if (n < p.N) {
-            if (p.bias) {
-              const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-              v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+          const int jo = j0 + jj;
+          if (jo >= OT) continue;
+          f32x4 v;
+          if (GLU) {
+            const int np = n_w0 + (2 * jo) * 16 + g * 4;   // packed value column; its gate is 16 further
+            f32x4 hv = acc[i][2 * jo], gv = acc[i][2 * jo + 1];
+            if (np < p.N && p.bias) {
+              const f32x4 bh = *reinterpret_cast<const f32x4*>(p.bias + np), bg = *reinterpret_cast<const f32x4*>(p.bias + np + 16);
+              hv[0] += bh[0]; hv[1] += bh[1]; hv[2] += bh[2]; hv[3] += bh[3];
+              gv[0] += bg[0]; gv[1] += bg[1]; gv[2] += bg[2]; gv[3] += bg[3];
             }
-            if (rb) {
-              const f32x4 r4 = *reinterpret_cast<const f32x4*>(rb + n);
-              v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+            v[0] = hv[0] * gelu_erf_f(gv[0]); v[1] = hv[1] * gelu_erf_f(gv[1]);
+            v[2] = hv[2] * gelu_erf_f(gv[2]); v[3] = hv[3] * gelu_erf_f(gv[3]);
+          } else {
+            const int n = n_w0 + jo * 16 + g * 4;
+            v = acc[i][jo];
+            if (n < p.N) {
+              if (p.bias) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+              }
+              if (rb) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(rb + n);
+                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+              }
             }
           }
           *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
@@ -291,19 +308,21 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
         for (int c = lane; c < 16 * cpr; c += 64) {
           const int row = c / cpr, ch = c - row * cpr;
           const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
-          const int n = n_w0 + j0 * 16 + ch * 8;
-          if (m < p.M && n < p.N) {
+          const int n = o_w0 + j0 * 16 + ch * 8;
+          if (m < p.M && n < n_out) {
             float v[8];
             *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
             *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
-            if (R) {
-              float rr[8];
-              load8<T>(R + (long long)m * p.ldr + n, rr);
+            if (!GLU) {
+              if (R) {
+                float rr[8];
+                load8<T>(R + (long long)m * p.ldr + n, rr);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                for (int e = 0; e < 8; ++e) v[e] += rr[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
             store8<T>(O + (long long)m * p.ldo + n, v);
           }
         }
