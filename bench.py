@@ -170,9 +170,19 @@ def main():
         ms = sum(v["ms"] for v in mm.values())
         launches = sum(v["launches"] for v in mm.values())
         ach = fl / (ms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch from PMC counters (collected offline with rocprofv3 --pmc, see profiles/)
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and args.frames == 16 and args.size == 512 and args.dtype == "bf16":
+            try:
+                traffic = round(json.load(open(tpath))["families"]["gemm"]["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
+        alg_bytes = sum(v["bytes"] for v in mm.values()) / launches
         result["roofline"] = {"kernel": "fyc_gemm_kernel (MFMA GEMM + implicit-GEMM conv3x3)", "bound": "mfma",
                               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                              "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
+                              "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": traffic,
+                              "traffic_note": "avg HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r01_hbm_traffic.json",
+                              "algorithmic_bytes_per_launch": round(alg_bytes),
                               "launches_per_ddim_step": launches // n_inst, "avg_launch_us": round(1e3 * ms / launches, 2),
                               "algorithmic_tflop_per_ddim_step": round(fl / n_inst / 1e12, 3)}
         fam = {}
