@@ -67,7 +67,10 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
                   "fyc_gemm conv: output size mismatch");
     } else {
       p.conv_stride = 1;
-      FYC_REQUIRE(a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win, "fyc_gemm upconv: output must be 2x input");
+      FYC_REQUIRE(a->Hout >= a->Hin && a->Wout >= a->Win, "fyc_gemm upconv: output must not be smaller than the input");
+      p.up_exact2 = (a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win) ? 1 : 0;
+      p.up_sh = (float)a->Hin / (float)a->Hout;
+      p.up_sw = (float)a->Win / (float)a->Wout;
     }
   }
   if (a->epilogue == FYC_EPI_GEGLU) {

@@ -38,6 +38,7 @@ struct GemmP {
   int rows_per_batch, seg_cols, heads, tokens, head_dim;
   float out_scale;
   int tiles_m, tiles_n;
+  int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
 };
@@ -160,9 +161,15 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       if (MODE == FYC_GEMM_CONV3X3) {
         const bool ok = a_row[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
         return ok ? A + (long long)(a_pix[it] + iy * p.Win + ix) * p.Cin + c0 + a_koff[it] : zero;
-      } else {  // nearest-2x upsampled input: virtual size (2*Hin, 2*Win)
-        const bool ok = a_row[it] >= 0 && (unsigned)iy < (unsigned)(2 * p.Hin) && (unsigned)ix < (unsigned)(2 * p.Win);
-        return ok ? A + (long long)(a_pix[it] + (iy >> 1) * p.Win + (ix >> 1)) * p.Cin + c0 + a_koff[it] : zero;
+      } else {  // nearest-upsampled input of virtual size (Hout, Wout): F.interpolate(mode="nearest") folded into the gather
+        const bool ok = a_row[it] >= 0 && (unsigned)iy < (unsigned)p.Hout && (unsigned)ix < (unsigned)p.Wout;
+        int sy, sx;
+        if (p.up_exact2) { sy = iy >> 1; sx = ix >> 1; }
+        else {  // torch: src = min(floor(dst * (in / out)), in - 1), scale in f32
+          sy = min((int)floorf((float)iy * p.up_sh), p.Hin - 1);
+          sx = min((int)floorf((float)ix * p.up_sw), p.Win - 1);
+        }
+        return ok ? A + (long long)(a_pix[it] + sy * p.Win + sx) * p.Cin + c0 + a_koff[it] : zero;
       }
     }
   };

@@ -28,11 +28,11 @@ class EngineBase:
         return out
 
     def conv(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, stride: int = 1, up2: bool = False,
-             rowbias=None, rpb: int = 1, residual=None, ldrb: int = 0) -> Tensor:
+             rowbias=None, rpb: int = 1, residual=None, ldrb: int = 0, up_size=None) -> Tensor:
         Cout, K = w.shape
         Cin = K // 9
         if up2:
-            Ho, Wo = 2 * Hin, 2 * Win
+            Ho, Wo = up_size if up_size is not None else (2 * Hin, 2 * Win)
         else:
             Ho, Wo = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
         M = frames * Ho * Wo

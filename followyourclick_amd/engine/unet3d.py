@@ -236,6 +236,7 @@ class UNet3DEngine(EngineBase):
         if cfg.use_first_frame_condition_concat:
             raise NotImplementedError("use_first_frame_condition_concat (sample/2 path, reference unet.py:589-590)")
         skips = [(x, P.conv_in_w.shape[0])]
+        sizes = [(H, W)]                       # spatial size per resolution level (odd sizes: ceil-halving on the way down)
         for blk in P.down:
             for l in blk.layers:
                 x = self.resnet(l.resnet, x, temb, g)
@@ -248,6 +249,7 @@ class UNet3DEngine(EngineBase):
                 x = self.conv(x, blk.down.w, blk.down.b, frames, g["H"], g["W"], stride=2)
                 g = dict(g, H=(g["H"] - 1) // 2 + 1, W=(g["W"] - 1) // 2 + 1)
                 g["rows"] = B * F * g["H"] * g["W"]
+                sizes.append((g["H"], g["W"]))
                 skips.append((x, blk.down.w.shape[0]))
         x = self.resnet(P.mid.r0, x, temb, g)
         x = self.transformer(P.mid.attn, x, g)
@@ -267,8 +269,12 @@ class UNet3DEngine(EngineBase):
                 if l.motion is not None:
                     x = self.motion(l.motion, x, g)
             if blk.up is not None:
-                x = self.conv(x, blk.up.w, blk.up.b, frames, g["H"], g["W"], up2=True)
-                g = dict(g, H=2 * g["H"], W=2 * g["W"])
-                g["rows"] = B * F * g["H"] * g["W"]
+                # Upsample3D: nearest to the size of the next skip connection (exactly 2x unless a level was odd:
+                # the reference forwards `upsample_size`, unet.py:466-474, 644-645)
+                sizes.pop()
+                Hn, Wn = sizes[-1]
+                x = self.conv(x, blk.up.w, blk.up.b, frames, g["H"], g["W"], up2=True, up_size=(Hn, Wn))
+                g = dict(g, H=Hn, W=Wn)
+                g["rows"] = B * F * Hn * Wn
         h = self.group_norm(x, P.out_g, P.out_b, g["rows"], c_cur, F * g["H"] * g["W"], cfg.norm_eps, True)
         return self.conv(h, P.conv_out_w, P.conv_out_b, frames, g["H"], g["W"])

@@ -50,6 +50,8 @@ int fyc_set_tuning(int key, int value);
  * and the baddbmm/bmm of the materialised attention used in f32 parity mode and the VAE
  * (diffusers/models/attention.py:342-368, 649-678).
  */
+/* CONV3X3_UP2: 3x3 conv over the nearest-neighbour upsampling of the input to (Hout, Wout); 2x is the fast path,
+ * any Hout >= Hin works (Upsample3D with a forwarded `upsample_size`, reference resnet.py:152-157, unet.py:644-645) */
 enum { FYC_GEMM_PLAIN = 0, FYC_GEMM_CONV3X3 = 1, FYC_GEMM_CONV3X3_UP2 = 2 };
 enum { FYC_EPI_LINEAR = 0, FYC_EPI_GEGLU = 1, FYC_EPI_HEADS = 2 };
 

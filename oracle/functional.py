@@ -360,7 +360,13 @@ def unet3d_forward(sd: SD, cfg: UNetConfig, sample: Tensor, timestep: Tensor, ct
             if _has_motion(cfg, 2 ** (nb - 1 - i)):
                 x = motion_module(sd, f"{p}.motion_modules.{j}", x, cfg)
         if i != nb - 1:
-            x = upsample_nearest2x(x)
+            # scale_factor 2, or the next skip's size when a level is not a multiple of 2**3
+            # (`upsample_size` forwarding, unet.py:466-474, 644-645; resnet.py:152-157)
+            tgt = skips[-1].shape[2:]
+            if tuple(tgt[1:]) == (2 * x.shape[3], 2 * x.shape[4]):
+                x = upsample_nearest2x(x)
+            else:
+                x = F.interpolate(x, size=tuple(tgt), mode="nearest")
             x = conv_frames(x, sd[f"{p}.upsamplers.0.conv.weight"], sd[f"{p}.upsamplers.0.conv.bias"])
         tap(f"up{i}", x)
     x = F.silu(group_norm_cross_frame(x, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], g, eps))

@@ -113,6 +113,14 @@ def main():
                             weight_seed=np.int64(0), input_seed=np.int64(7))
         if not ip:
             unet_plain, sd_plain, cfg_plain = unet, sd, cfg
+            # odd latent size (10x12 -> 5x6 -> 3x3 -> 2x2): exercises the forwarded `upsample_size` path
+            go = torch.Generator().manual_seed(9)
+            xo = torch.randn(2, 9, 2, 10, 12, generator=go)
+            to = torch.randn(2, 77, cfg.cross_attention_dim, generator=go)
+            with torch.no_grad():
+                yo = unet(xo, torch.tensor(481), to, use_fps_condition=True, fps_tensor=fps, flow_control=flow).sample
+            np.savez_compressed(os.path.join(OUT, "unet_tiny_odd_fwd.npz"), sample=xo.numpy(), timestep=np.int64(481), text=to.numpy(),
+                                fps=fps.numpy(), flow=flow.numpy(), out=yo.numpy(), weight_seed=np.int64(0))
 
     # ---- VAE decode (tiny) ----------------------------------------------------------------
     vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))

@@ -53,7 +53,7 @@ class EmuOps:
                 frames = M // (Hout * Wout)
                 x = af[: frames * Hin * Win * Cin].reshape(frames, Hin, Win, Cin).permute(0, 3, 1, 2).to(acc_t)
                 if mode == CONV_UP2:
-                    x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+                    x = F.interpolate(x.float(), size=(Hout, Wout), mode="nearest").to(acc_t)
                     stride = 1
                 else:
                     stride = conv.get("stride", 1)

@@ -44,6 +44,19 @@ def test_unet_forward_matches_golden(golden_dir, dtype, tol):
     assert rel < tol, rel
 
 
+def test_unet_forward_odd_size(golden_dir):
+    g = _load(golden_dir, "unet_tiny_odd_fwd.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), torch.float32, "cpu"), ops=EmuOps())
+    B, C9, F, H, Wd = g["sample"].shape
+    x = torch.zeros(B * F * H * Wd, 64)
+    x[:, :C9] = g["sample"].permute(0, 2, 3, 4, 1).reshape(-1, C9)
+    eng.prepare_context(g["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), B)
+    out = eng.forward(x, temb, B, F, H, Wd).reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    assert ((out - g["out"]).norm() / g["out"].norm()).item() < 2e-4
+
+
 def test_unet_forward_ip_matches_oracle():
     """IP-Adapter decoupled cross-attention with the deployed (xformers) softmax temperature."""
     ocfg = Fn.tiny_unet_config(use_ip_cross_attention=True, ip_scale=0.7)

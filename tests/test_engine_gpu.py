@@ -74,6 +74,21 @@ def test_unet_forward_vs_reference_golden(golden_dir, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_unet_forward_odd_latent_size(golden_dir, dtype, tol):
+    """10x12 latent (not a multiple of 8): ceil-halving downsamples, upsampling to the skip's size"""
+    g = _load(golden_dir, "unet_tiny_odd_fwd.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), dtype, DEV))
+    B, _, F, H, Wd = g["sample"].shape
+    eng.prepare_context(g["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), B)
+    out = eng.forward(_nhwc(g["sample"], dtype), temb, B, F, H, Wd).float().cpu().reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    r = rel(out, g["out"])
+    report(f"unet fwd odd size {dtype}: rel-L2 {r:.3e}")
+    assert r < tol, r
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
 def test_unet_forward_ip_adapter_vs_oracle(dtype, tol):
     ocfg = Fn.tiny_unet_config(use_ip_cross_attention=True, ip_scale=0.7)
     sd = W.make_weights(W.unet_state_shapes(ocfg), 0)

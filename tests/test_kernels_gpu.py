@@ -75,10 +75,13 @@ def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("mode,stride,frames,H,W,Cin,Cout", [
     (1, 1, 3, 8, 8, 64, 64), (1, 1, 2, 16, 12, 128, 320), (1, 2, 2, 16, 16, 64, 128), (2, 1, 2, 6, 5, 64, 64),
-    (1, 1, 5, 1, 1, 64, 64), (1, 1, 1, 32, 32, 192, 4), (1, 2, 3, 2, 2, 64, 64)])
+    (1, 1, 5, 1, 1, 64, 64), (1, 1, 1, 32, 32, 192, 4), (1, 2, 3, 2, 2, 64, 64), (3, 1, 2, 3, 5, 64, 64), (3, 1, 1, 2, 2, 64, 128)])
 def test_gemm_conv(hip, emu, dt, tile_ring, mode, stride, frames, H, W, Cin, Cout):
     T = DT[dt]
-    Ho, Wo = (2 * H, 2 * W) if mode == 2 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+    if mode == 3:                      # nearest upsample to a forwarded, non-2x size (odd resolutions)
+        mode, Ho, Wo = 2, 2 * H - 1, 2 * W - 1
+    else:
+        Ho, Wo = (2 * H, 2 * W) if mode == 2 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
     M, K = frames * Ho * Wo, 9 * Cin
     x, w = rnd((frames * H * W, Cin), T, 1), rnd((Cout, K), T, 2, 1 / math.sqrt(K))
     bias = rnd((Cout,), torch.float32, 3)

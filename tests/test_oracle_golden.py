@@ -102,3 +102,13 @@ def test_pipeline_trajectory_tiny(golden_dir):
     with torch.no_grad():
         vid = Fn.decode_latents(sdv, vcfg, lat)
     assert (vid - g["videos"]).abs().max().item() < 1e-4
+
+
+def test_unet_forward_odd_size_upsample_forwarding(golden_dir):
+    """latent 10x12 -> 5x6 -> 3x3 -> 2x2: Upsample3D gets the skip's size instead of scale_factor=2"""
+    g = _load(golden_dir, "unet_tiny_odd_fwd.npz")
+    cfg = Fn.tiny_unet_config()
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["weight_seed"]))
+    with torch.no_grad():
+        y = Fn.unet3d_forward(sd, cfg, g["sample"], torch.tensor(int(g["timestep"])), g["text"], g["fps"], g["flow"])
+    assert (y - g["out"]).abs().max().item() < TOL
