@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
                 ("lda", i32), ("ldw", i32), ("ldo", i32), ("ldr", i32), ("ldrb", i32),
                 ("stride_a", i64), ("stride_w", i64), ("stride_o", i64),
                 ("batch", i32), ("mode", i32), ("epilogue", i32),
-                ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32),
+                ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32), ("conv_pad", i32),
                 ("rows_per_batch", i32), ("seg_cols", i32), ("heads", i32), ("tokens", i32),
                 ("out_scale", f32), ("dtype", i32), ("tile", i32)]
 

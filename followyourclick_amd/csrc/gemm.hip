@@ -45,7 +45,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
   p.stride_a = a->stride_a; p.stride_w = a->stride_w; p.stride_o = a->stride_o;
   p.mode = a->mode; p.epilogue = a->epilogue;
-  p.Hout = a->Hout; p.Wout = a->Wout; p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin; p.conv_stride = a->conv_stride;
+  p.Hout = a->Hout; p.Wout = a->Wout; p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin; p.conv_stride = a->conv_stride; p.conv_pad = a->conv_pad;
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
   p.ldrb = a->ldrb > 0 ? a->ldrb : a->N;
   p.out_scale = a->out_scale;
@@ -63,10 +63,12 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(batch == 1, "fyc_gemm conv: batch must be 1");
     if (a->mode == FYC_GEMM_CONV3X3) {
       FYC_REQUIRE(a->conv_stride == 1 || a->conv_stride == 2, "fyc_gemm conv: stride %d", a->conv_stride);
-      FYC_REQUIRE(a->Hout == (a->Hin + 2 - 3) / a->conv_stride + 1 && a->Wout == (a->Win + 2 - 3) / a->conv_stride + 1,
+      FYC_REQUIRE(a->conv_pad == 0 || a->conv_pad == 1, "fyc_gemm conv: conv_pad must be 0 or 1");
+      FYC_REQUIRE(a->Hout == (a->Hin + a->conv_pad + 1 - 3) / a->conv_stride + 1 && a->Wout == (a->Win + a->conv_pad + 1 - 3) / a->conv_stride + 1,
                   "fyc_gemm conv: output size mismatch");
     } else {
       p.conv_stride = 1;
+      p.conv_pad = 1;
       FYC_REQUIRE(a->Hout >= a->Hin && a->Wout >= a->Win, "fyc_gemm upconv: output must not be smaller than the input");
       p.up_exact2 = (a->Hout == 2 * a->Hin && a->Wout == 2 * a->Win) ? 1 : 0;
       p.up_sh = (float)a->Hin / (float)a->Hout;

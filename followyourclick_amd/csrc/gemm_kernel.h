@@ -34,7 +34,7 @@ struct GemmP {
   int M, N, K, lda, ldw, ldo, ldr, ldrb;
   long long stride_a, stride_w, stride_o;
   int mode, epilogue;
-  int Hout, Wout, Hin, Win, Cin, conv_stride;
+  int Hout, Wout, Hin, Win, Cin, conv_stride, conv_pad;
   int rows_per_batch, seg_cols, heads, tokens, head_dim;
   float out_scale;
   int tiles_m, tiles_n;
@@ -137,8 +137,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
         const int fr = m / hw, rem = m - fr * hw, oy = rem / p.Wout, ox = rem - oy * p.Wout;
         a_row[it] = (m < p.M) ? 0 : -1;
         a_pix[it] = fr * p.Hin * p.Win;
-        a_iy0[it] = oy * p.conv_stride - 1;
-        a_ix0[it] = ox * p.conv_stride - 1;
+        a_iy0[it] = oy * p.conv_stride - p.conv_pad;
+        a_ix0[it] = ox * p.conv_stride - p.conv_pad;
       }
     }
 #pragma unroll

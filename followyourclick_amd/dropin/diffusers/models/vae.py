@@ -1,8 +1,7 @@
-"""`diffusers.AutoencoderKL` surface for the sampling path: the DECODER half runs on the MI355X engine
-(reference diffusers/models/vae.py:147-224, 545-610).  Parameters are registered under the reference's
-names so SD-1.5 `vae/diffusion_pytorch_model.bin` loads with load_state_dict(strict=False) (encoder.* and
-quant_conv.* keys come back as `unexpected`: the encoder belongs to the conditioning front-end, the first
-"next" row of SURVEY.md 8f, and raises NotImplementedError here)."""
+"""`diffusers.AutoencoderKL` surface on the MI355X engine: `decode` (sampling path, reference
+diffusers/models/vae.py:147-224, 575-610) and `encode` (first-frame conditioning front-end, :67-144,
+565-573).  All parameters are registered under the reference's names so SD-1.5
+`vae/diffusion_pytorch_model.bin` loads with a plain load_state_dict."""
 from __future__ import annotations
 
 import json
@@ -15,14 +14,40 @@ import torch
 import torch.nn as nn
 
 from followyourclick_amd.engine import VAEDecoderConfig
-from followyourclick_amd.engine.schema import vae_decoder_schema
-from followyourclick_amd.engine.vae import VAEDecoderEngine
-from followyourclick_amd.engine.weights import pack_vae_decoder
+from followyourclick_amd.engine.schema import vae_decoder_schema, vae_encoder_schema
+from followyourclick_amd.engine.vae import VAEDecoderEngine, VAEEncoderEngine
+from followyourclick_amd.engine.weights import pack_vae_decoder, pack_vae_encoder
 
 
 @dataclass
 class DecoderOutput:
     sample: torch.Tensor
+
+
+class DiagonalGaussianDistribution:
+    """reference diffusers/models/vae.py:341-361 (mean | logvar moments, reparameterised sampling)"""
+
+    def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.parameters.device)
+        return self.mean + self.std * noise.to(self.parameters.dtype)
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: DiagonalGaussianDistribution
 
 
 class _Node(nn.Module):
@@ -44,7 +69,9 @@ class AutoencoderKL(nn.Module):
                                       norm_num_groups=norm_num_groups, sample_size=sample_size)
         self.compute_dtype = compute_dtype
         g = torch.Generator().manual_seed(0)
-        for name, shape in vae_decoder_schema(self.engine_config).items():
+        schema = dict(vae_encoder_schema(self.engine_config, in_channels))
+        schema.update(vae_decoder_schema(self.engine_config))
+        for name, shape in schema.items():
             *path, leaf = name.split(".")
             node = self
             for part in path:
@@ -58,7 +85,9 @@ class AutoencoderKL(nn.Module):
             node.register_parameter(leaf, nn.Parameter(init, requires_grad=False))
         self.use_slicing = False
         self._engine: Optional[VAEDecoderEngine] = None
+        self._encoder: Optional[VAEEncoderEngine] = None
         self._engine_key = None
+        self._encoder_key = None
 
     @property
     def dtype(self):
@@ -79,12 +108,27 @@ class AutoencoderKL(nn.Module):
         if self._engine is None or key != self._engine_key:
             if self.device.type != "cuda":
                 raise RuntimeError("AutoencoderKL.decode runs on an MI355X HIP device only (call .to('cuda')); no CPU fallback")
-            self._engine = VAEDecoderEngine(pack_vae_decoder(self.state_dict(), self.engine_config, self.compute_dtype, self.device))
+            sd = {k: v for k, v in self.state_dict().items() if k.startswith(("decoder.", "post_quant_conv."))}
+            self._engine = VAEDecoderEngine(pack_vae_decoder(sd, self.engine_config, self.compute_dtype, self.device))
             self._engine_key = key
         return self._engine
 
-    def encode(self, x, return_dict: bool = True):
-        raise NotImplementedError("AutoencoderKL.encode (first-frame conditioning front-end) is the next scope row (SURVEY.md 8f.1)")
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """x: (N, 3, H, W) in [-1, 1] -> AutoencoderKLOutput(latent_dist); `.latent_dist.sample() * 0.18215` gives the
+        first-frame latents exactly as scripts/inference.py:356-358 computes them."""
+        key = (self.device, self.compute_dtype) + tuple(p._version for p in self.parameters())
+        if self._encoder is None or key != self._encoder_key:
+            if self.device.type != "cuda":
+                raise RuntimeError("AutoencoderKL.encode runs on an MI355X HIP device only (call .to('cuda')); no CPU fallback")
+            sd = {k: v for k, v in self.state_dict().items() if k.startswith(("encoder.", "quant_conv."))}
+            self._encoder = VAEEncoderEngine(pack_vae_encoder(sd, self.engine_config, self.compute_dtype, self.device))
+            self._encoder_key = key
+        moments = self._encoder.encode_moments(x.float()).to(x.dtype)
+        posterior = DiagonalGaussianDistribution(moments)
+        if not return_dict:
+            return (posterior,)
+        return AutoencoderKLOutput(latent_dist=posterior)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):

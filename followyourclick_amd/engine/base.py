@@ -28,18 +28,18 @@ class EngineBase:
         return out
 
     def conv(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, stride: int = 1, up2: bool = False,
-             rowbias=None, rpb: int = 1, residual=None, ldrb: int = 0, up_size=None) -> Tensor:
+             rowbias=None, rpb: int = 1, residual=None, ldrb: int = 0, up_size=None, pad: int = 1) -> Tensor:
         Cout, K = w.shape
         Cin = K // 9
         if up2:
             Ho, Wo = up_size if up_size is not None else (2 * Hin, 2 * Win)
         else:
-            Ho, Wo = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+            Ho, Wo = (Hin + pad - 2) // stride + 1, (Win + pad - 2) // stride + 1
         M = frames * Ho * Wo
         out = self.new(M, Cout)
         self.ops.gemm(x, w, out, M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, bias=b, rowbias=rowbias, rows_per_batch=rpb, ldrb=ldrb,
                       residual=residual, ldr=Cout, mode=L.GEMM_CONV3X3_UP2 if up2 else L.GEMM_CONV3X3,
-                      conv=dict(Hout=Ho, Wout=Wo, Hin=Hin, Win=Win, Cin=Cin, stride=stride))
+                      conv=dict(Hout=Ho, Wout=Wo, Hin=Hin, Win=Win, Cin=Cin, stride=stride, pad=pad))
         return out
 
     def group_norm(self, x: Tensor, g: Tensor, b: Tensor, rows: int, C: int, rows_per_sample: int, eps: float, silu: bool) -> Tensor:

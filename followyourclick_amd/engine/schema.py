@@ -156,6 +156,31 @@ def vae_decoder_schema(cfg: VAEDecoderConfig) -> "OrderedDict[str, Tuple[int, ..
     return s
 
 
+def vae_encoder_schema(cfg: VAEDecoderConfig, in_channels: int = 3) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Encoder half + quant_conv (reference diffusers/models/vae.py:67-144, 560)."""
+    s = _S()
+    boc = cfg.block_out_channels
+    s.conv("encoder.conv_in", boc[0], in_channels, 3)
+    out = boc[0]
+    for i in range(len(boc)):
+        inp, out = out, boc[i]
+        for j in range(cfg.layers_per_block):
+            s.resnet(f"encoder.down_blocks.{i}.resnets.{j}", inp if j == 0 else out, out, 0)
+        if i != len(boc) - 1:
+            s.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", out, out, 3)
+    c = boc[-1]
+    s.resnet("encoder.mid_block.resnets.0", c, c, 0)
+    a = "encoder.mid_block.attentions.0"
+    s.norm(a + ".group_norm", c)
+    for n in ("query", "key", "value", "proj_attn"):
+        s.lin(f"{a}.{n}", c, c)
+    s.resnet("encoder.mid_block.resnets.1", c, c, 0)
+    s.norm("encoder.conv_norm_out", c)
+    s.conv("encoder.conv_out", 2 * cfg.latent_channels, c, 3)
+    s.conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return s
+
+
 def random_state_dict(schema: "OrderedDict[str, Tuple[int, ...]]", seed: int, materialize: bool = True) -> Dict[str, torch.Tensor]:
     """Random-initialised weights of the architecture (no checkpoints exist offline): N(0, 1/fan_in)
     kernels, norm gains 1 + 0.1 N, small biases; `pos_encoder.pe` buffers analytic.  With

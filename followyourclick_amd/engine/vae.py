@@ -96,3 +96,41 @@ class VAEDecoderEngine(EngineBase):
         outs = [self.decode(z[i:i + chunk]) for i in range(0, B * F, chunk)]
         vid = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
         return vid.reshape(B, F, vid.shape[1], vid.shape[2], vid.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+class VAEEncoderEngine(VAEDecoderEngine):
+    """AutoencoderKL.encode up to the Gaussian moments (reference diffusers/models/vae.py:128-144, 565-573;
+    DownEncoderBlock2D unet_2d_blocks.py:870-930; Downsample2D with padding=0 -> F.pad (0,1,0,1),
+    resnet.py:181-190).  The conditioning front-end row of SURVEY.md 8f.1: run once per clip on the first frame."""
+
+    def encode_moments(self, x: Tensor) -> Tensor:
+        """x: (N, 3, H, W) f32 image in [-1, 1]  ->  (N, 2*latent, H/8, W/8) f32 = [mean | logvar]"""
+        P, cfg, o = self.P, self.cfg, self.ops
+        N, Ci, H, W = x.shape
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        cp = pad_channels(Ci)
+        h = self.new(N * H * W, cp)
+        o.nchw_to_nhwc(x, h, N=N, C_=Ci, HW=H * W, c_pad=cp, scale=1.0)
+        h = self.conv(h, P.conv_in_w, P.conv_in_b, N, H, W)
+        for blk in P.downs:
+            for r in blk.resnets:
+                h = self.resnet(r, h, N, H, W)
+            if blk.down is not None:
+                h = self.conv(h, blk.down.w, blk.down.b, N, H, W, stride=2, pad=0)
+                H, W = H // 2, W // 2
+        h = self.resnet(P.mid_r0, h, N, H, W)
+        h = self.attention(P.attn, h, N, H, W)
+        h = self.resnet(P.mid_r1, h, N, H, W)
+        c = cfg.block_out_channels[-1]
+        h = self.group_norm(h, P.out_g, P.out_b, N * H * W, c, H * W, 1e-6, True)
+        C2 = 2 * cfg.latent_channels
+        cp2 = pad_channels(C2)
+        z = self.zeros(N * H * W, cp2)                      # conv_out into a zero-padded row so quant_conv (1x1) can read 128-B K tiles
+        Kc = P.conv_out_w.shape[1]
+        o.gemm(h, P.conv_out_w, z, M=N * H * W, N=C2, K=Kc, lda=Kc // 9, ldw=Kc, ldo=cp2, bias=P.conv_out_b, mode=L.GEMM_CONV3X3,
+               conv=dict(Hout=H, Wout=W, Hin=H, Win=W, Cin=Kc // 9, stride=1, pad=1))
+        m = self.new(N * H * W, 8 if C2 <= 8 else cp2)
+        o.gemm(z, P.q_w, m, M=N * H * W, N=C2, K=cp2, lda=cp2, ldw=cp2, ldo=m.shape[1], bias=P.q_b)
+        out = self.new(N, C2, H, W, dtype=torch.float32)
+        o.nhwc_to_nchw(m, out, N=N, C_=C2, HW=H * W, ld=m.shape[1])
+        return out

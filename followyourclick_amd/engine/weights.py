@@ -248,3 +248,38 @@ def pack_vae_decoder(sd: Dict[str, Tensor], cfg: VAEDecoderConfig, dtype, device
     P["conv_out_w"] = pack_conv3x3(sd["decoder.conv_out.weight"], dtype, device)
     P["conv_out_b"] = f32(sd["decoder.conv_out.bias"], device)
     return P
+
+
+def _vae_attn(sd, a: str, dtype, device) -> Packed:
+    return Packed(g=f32(sd[a + ".group_norm.weight"], device), b=f32(sd[a + ".group_norm.bias"], device),
+                  qkv_w=pack_linear(torch.cat([sd[a + ".query.weight"], sd[a + ".key.weight"], sd[a + ".value.weight"]], 0), dtype, device),
+                  qkv_b=f32(torch.cat([sd[a + ".query.bias"], sd[a + ".key.bias"], sd[a + ".value.bias"]], 0), device),
+                  o_w=pack_linear(sd[a + ".proj_attn.weight"], dtype, device), o_b=f32(sd[a + ".proj_attn.bias"], device))
+
+
+def pack_vae_encoder(sd: Dict[str, Tensor], cfg: VAEDecoderConfig, dtype, device) -> Packed:
+    """Encoder half of AutoencoderKL (reference diffusers/models/vae.py:67-144) + quant_conv."""
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    P = Packed(cfg=cfg, dtype=dtype)
+    P["conv_in_w"] = pack_conv3x3(sd["encoder.conv_in.weight"], dtype, device)
+    P["conv_in_b"] = f32(sd["encoder.conv_in.bias"], device)
+    downs = []
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        rs = [_resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", dtype, device) for j in range(cfg.layers_per_block)]
+        ds = None
+        if i != nb - 1:
+            k = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            ds = Packed(w=pack_conv3x3(sd[k + ".weight"], dtype, device), b=f32(sd[k + ".bias"], device))
+        downs.append(Packed(resnets=rs, down=ds))
+    P["downs"] = downs
+    P["mid_r0"] = _resnet(sd, "encoder.mid_block.resnets.0", dtype, device)
+    P["attn"] = _vae_attn(sd, "encoder.mid_block.attentions.0", dtype, device)
+    P["mid_r1"] = _resnet(sd, "encoder.mid_block.resnets.1", dtype, device)
+    P["out_g"], P["out_b"] = f32(sd["encoder.conv_norm_out.weight"], device), f32(sd["encoder.conv_norm_out.bias"], device)
+    P["conv_out_w"] = pack_conv3x3(sd["encoder.conv_out.weight"], dtype, device)
+    P["conv_out_b"] = f32(sd["encoder.conv_out.bias"], device)
+    C2 = 2 * cfg.latent_channels
+    P["q_w"] = pack_linear(sd["quant_conv.weight"], dtype, device, k_pad=pad_channels(C2))
+    P["q_b"] = f32(sd["quant_conv.bias"], device)
+    return P

@@ -94,6 +94,7 @@ class HipOps:
         if conv is not None:
             g.Hout, g.Wout, g.Hin, g.Win, g.Cin, g.conv_stride = (conv["Hout"], conv["Wout"], conv["Hin"], conv["Win"],
                                                                   conv["Cin"], conv.get("stride", 1))
+            g.conv_pad = conv.get("pad", 1)
         if heads is not None:
             g.seg_cols, g.heads, g.tokens = heads["seg_cols"], heads["heads"], heads["tokens"]
             for i, (t, tr, ld) in enumerate(zip(heads["outs"], heads["transposed"], heads["ld"])):

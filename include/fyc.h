@@ -73,6 +73,7 @@ typedef struct {
   int32_t mode;          /* FYC_GEMM_* */
   int32_t epilogue;      /* FYC_EPI_* */
   int32_t Hout, Wout, Hin, Win, Cin, conv_stride; /* conv modes */
+  int32_t conv_pad;      /* leading (top/left) zero padding: 1 (default conv) or 0 (diffusers Downsample2D padding=0: F.pad (0,1,0,1)); trailing pad is always 1 */
   int32_t rows_per_batch;
   int32_t seg_cols, heads, tokens; /* HEADS: columns per segment (=heads*d), tokens per batch element */
   float out_scale;

@@ -535,3 +535,23 @@ def decode_latents(sd: SD, cfg: VAEConfig, latents: Tensor) -> Tensor:
     frames = torch.cat([vae_decode(sd, cfg, z[i:i + 1]) for i in range(z.shape[0])])
     video = frames.reshape(B, Fr, frames.shape[1], frames.shape[2], frames.shape[3]).permute(0, 2, 1, 3, 4)
     return (video / 2 + 0.5).clamp(0, 1).float()
+
+
+def vae_encode_moments(sd: SD, cfg: VAEConfig, x: Tensor) -> Tensor:
+    """AutoencoderKL.encode(x) up to `moments` = quant_conv(encoder(x)) (diffusers/models/vae.py:128-144, 565-573);
+    Downsample2D(padding=0) pads (0,1,0,1) then conv stride 2 (diffusers/models/resnet.py:181-190)."""
+    g = cfg.norm_num_groups
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            h = resnet_block2d(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, g)
+        if i != nb - 1:
+            k = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[k + ".weight"], sd[k + ".bias"], stride=2)
+    h = resnet_block2d(sd, "encoder.mid_block.resnets.0", h, g)
+    h = vae_attention_block(sd, "encoder.mid_block.attentions.0", h, g)
+    h = resnet_block2d(sd, "encoder.mid_block.resnets.1", h, g)
+    h = F.silu(F.group_norm(h, g, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], 1e-6))
+    h = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])

@@ -132,6 +132,15 @@ def main():
     with torch.no_grad():
         img = vae.decode(z).sample
     np.savez_compressed(os.path.join(OUT, "vae_tiny.npz"), z=z.numpy(), out=img.numpy(), weight_seed=np.int64(3))
+    # encoder half (first-frame conditioning front-end): moments of vae.encode on a 64x48 image
+    dump_schema("schema_vae_enc_tiny.json", {k: v for k, v in vae.state_dict().items() if k.startswith(("encoder", "quant_conv"))})
+    sde = W.make_weights(W.vae_encoder_state_shapes(vcfg), seed=4)
+    vae.load_state_dict(sde, strict=False)
+    img_in = torch.rand(2, 3, 64, 48, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    with torch.no_grad():
+        post = vae.encode(img_in).latent_dist
+    np.savez_compressed(os.path.join(OUT, "vae_enc_tiny.npz"), x=img_in.numpy(), moments=post.parameters.numpy(), weight_seed=np.int64(4))
+    vae.load_state_dict(sdv, strict=False)
 
     # ---- full pipeline (tiny): the cfg1-shaped plumbing run -------------------------------
     tok, txt = stubs.FakeTokenizer(), stubs.StubTextEncoder(cfg_plain.cross_attention_dim)

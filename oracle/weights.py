@@ -172,6 +172,30 @@ def vae_decoder_state_shapes(cfg: VAEConfig) -> "OrderedDict[str, Tuple[int, ...
     return s
 
 
+def vae_encoder_state_shapes(cfg: VAEConfig, in_channels: int = 3) -> "OrderedDict[str, Tuple[int, ...]]":
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    boc = cfg.block_out_channels
+    _conv(s, "encoder.conv_in", boc[0], in_channels, 3)
+    out = boc[0]
+    for i in range(len(boc)):
+        inp, out = out, boc[i]
+        for j in range(cfg.layers_per_block):
+            _resnet(s, f"encoder.down_blocks.{i}.resnets.{j}", inp if j == 0 else out, out, 0)
+        if i != len(boc) - 1:
+            _conv(s, f"encoder.down_blocks.{i}.downsamplers.0.conv", out, out, 3)
+    c = boc[-1]
+    _resnet(s, "encoder.mid_block.resnets.0", c, c, 0)
+    a = "encoder.mid_block.attentions.0"
+    _norm(s, a + ".group_norm", c)
+    for n in ("query", "key", "value", "proj_attn"):
+        _lin(s, f"{a}.{n}", c, c)
+    _resnet(s, "encoder.mid_block.resnets.1", c, c, 0)
+    _norm(s, "encoder.conv_norm_out", c)
+    _conv(s, "encoder.conv_out", 2 * cfg.latent_channels, c, 3)
+    _conv(s, "quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return s
+
+
 def make_weights(shapes: "OrderedDict[str, Tuple[int, ...]]", seed: int, gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Deterministic fp32 weights: every tensor drawn in key order from one CPU generator.
 

@@ -59,7 +59,10 @@ class EmuOps:
                     stride = conv.get("stride", 1)
                 sl = 128 // a.element_size()                      # channels per 128-byte K slab
                 w4 = W.reshape(N, Cin // sl, 3, 3, sl).permute(0, 1, 4, 2, 3).reshape(N, Cin, 3, 3)
-                y = F.conv2d(x, w4, None, stride=stride, padding=1)
+                if mode == CONV and conv.get("pad", 1) == 0:
+                    y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w4, None, stride=stride, padding=0)
+                else:
+                    y = F.conv2d(x, w4, None, stride=stride, padding=1)
                 assert y.shape[2] == Hout and y.shape[3] == Wout, (y.shape, Hout, Wout)
                 acc = y.permute(0, 2, 3, 1).reshape(M, N)
             if bias is not None:

@@ -127,3 +127,18 @@ def test_ip_attention_processors(dropin, dtype, tol):
     assert plain.shape == (2, 64, C) and torch.isfinite(plain.float()).all()
     cn = ap.CNAttnProcessor(num_tokens=ntok)(attn, x, enc)
     assert cn.shape == x.shape
+
+
+def test_autoencoder_encode_then_decode_surface(dropin, golden_dir):
+    from diffusers import AutoencoderKL
+    g = _load(golden_dir, "vae_enc_tiny.npz")
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4, compute_dtype=torch.float32).to("cuda")
+    sd = W.make_weights(W.vae_encoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["weight_seed"]))
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("decoder.", "post_quant_conv.")) for k in missing)
+    dist = vae.encode(g["x"].cuda()).latent_dist
+    assert (dist.parameters.cpu() - g["moments"]).abs().max().item() < 1e-4
+    z = dist.sample(torch.Generator(device="cuda").manual_seed(0)) * 0.18215          # scripts/inference.py:356-358
+    assert z.shape == (2, 4, 8, 6) and torch.isfinite(z).all()
+    img = vae.decode(z / 0.18215).sample
+    assert img.shape == (2, 3, 64, 48)

@@ -114,3 +114,15 @@ def test_vae_decode_matches_golden(golden_dir):
     out = vae.decode(g["z"] * vcfg.scaling_factor)
     ref = (g["out"] / 2 + 0.5).clamp(0, 1)
     assert (out - ref).abs().max().item() < 1e-4
+
+
+def test_vae_encode_matches_golden(golden_dir):
+    from followyourclick_amd.engine.schema import vae_encoder_schema
+    from followyourclick_amd.engine.vae import VAEEncoderEngine
+    from followyourclick_amd.engine.weights import pack_vae_encoder
+    g = _load(golden_dir, "vae_enc_tiny.npz")
+    vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
+    sde = W.make_weights(W.vae_encoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["weight_seed"]))
+    assert set(vae_encoder_schema(vcfg)) == set(sde)
+    enc = VAEEncoderEngine(pack_vae_encoder(sde, vcfg, torch.float32, "cpu"), ops=EmuOps())
+    assert (enc.encode_moments(g["x"]) - g["moments"]).abs().max().item() < 1e-4

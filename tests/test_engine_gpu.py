@@ -143,3 +143,18 @@ def test_vae_decode_vs_reference_golden(golden_dir, dtype, tol):
     e = (out - ref).abs().max().item()
     report(f"vae {dtype}: max abs err {e:.3e}")
     assert e < tol, e
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 8e-2)])
+def test_vae_encode_vs_reference_golden(golden_dir, dtype, tol):
+    """first-frame conditioning front-end: moments of AutoencoderKL.encode (64x48 image, asymmetric-pad downsamples)"""
+    from followyourclick_amd.engine.vae import VAEEncoderEngine
+    from followyourclick_amd.engine.weights import pack_vae_encoder
+    g = _load(golden_dir, "vae_enc_tiny.npz")
+    vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
+    sde = W.make_weights(W.vae_encoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["weight_seed"]))
+    enc = VAEEncoderEngine(pack_vae_encoder(sde, vcfg, dtype, DEV))
+    out = enc.encode_moments(g["x"]).cpu()
+    e = (out - g["moments"]).abs().max().item()
+    report(f"vae encode {dtype}: max abs err {e:.3e} (moments max {g['moments'].abs().max().item():.2f})")
+    assert e < tol, e

@@ -112,3 +112,13 @@ def test_unet_forward_odd_size_upsample_forwarding(golden_dir):
     with torch.no_grad():
         y = Fn.unet3d_forward(sd, cfg, g["sample"], torch.tensor(int(g["timestep"])), g["text"], g["fps"], g["flow"])
     assert (y - g["out"]).abs().max().item() < TOL
+
+
+def test_vae_encode_tiny(golden_dir):
+    g = _load(golden_dir, "vae_enc_tiny.npz")
+    vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))
+    assert {k: tuple(v) for k, v in W.vae_encoder_state_shapes(vcfg).items()} == _schema(golden_dir, "schema_vae_enc_tiny.json")
+    sd = W.make_weights(W.vae_encoder_state_shapes(vcfg), int(g["weight_seed"]))
+    with torch.no_grad():
+        m = Fn.vae_encode_moments(sd, vcfg, g["x"])
+    assert (m - g["moments"]).abs().max().item() < TOL
