@@ -19,10 +19,10 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 
 class GemmArgs(C.Structure):
-    _fields_ = [("a", vp), ("w", vp), ("bias", vp), ("rowbias", vp), ("residual", vp), ("out", vp),
+    _fields_ = [("a", vp), ("a2", vp), ("w", vp), ("bias", vp), ("rowbias", vp), ("residual", vp), ("out", vp),
                 ("seg_out", vp * 3), ("seg_transposed", i32 * 3), ("seg_ld", i32 * 3),
                 ("M", i32), ("N", i32), ("K", i32),
-                ("lda", i32), ("ldw", i32), ("ldo", i32), ("ldr", i32), ("ldrb", i32),
+                ("lda", i32), ("ldw", i32), ("ldo", i32), ("ldr", i32), ("ldrb", i32), ("k_split", i32), ("lda2", i32),
                 ("stride_a", i64), ("stride_w", i64), ("stride_o", i64),
                 ("batch", i32), ("mode", i32), ("epilogue", i32),
                 ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32), ("conv_pad", i32),

@@ -40,7 +40,8 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   FYC_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0, "fyc_gemm: operands must be 16-B aligned");
   GemmP p;
   memset(&p, 0, sizeof(p));
-  p.a = (const char*)a->a; p.w = (const char*)a->w; p.bias = a->bias; p.rowbias = a->rowbias;
+  p.a = (const char*)a->a; p.a2 = (const char*)a->a2; p.w = (const char*)a->w;
+  p.k_split = a->k_split; p.lda2 = a->lda2; p.bias = a->bias; p.rowbias = a->rowbias;
   p.residual = (const char*)a->residual; p.out = (char*)a->out;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
   p.stride_a = a->stride_a; p.stride_w = a->stride_w; p.stride_o = a->stride_o;
@@ -53,6 +54,10 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   const int batch = a->batch > 0 ? a->batch : 1;
   if (a->mode == FYC_GEMM_PLAIN) {
     FYC_REQUIRE(a->lda % ch == 0 && a->stride_a % ch == 0, "fyc_gemm: lda/stride_a must keep 16-B alignment");
+    if (a->a2 != nullptr) {
+      FYC_REQUIRE(a->k_split > 0 && a->k_split < a->K && a->k_split % (8 * ch) == 0, "fyc_gemm: k_split=%d must be a multiple of %d inside (0, K)", a->k_split, 8 * ch);
+      FYC_REQUIRE(a->lda2 % ch == 0 && ((uintptr_t)a->a2 % 16) == 0 && batch == 1, "fyc_gemm: a2 alignment / batch");
+    }
   } else {
     const int bk = 8 * ch;
     FYC_REQUIRE(a->mode == FYC_GEMM_CONV3X3 || a->mode == FYC_GEMM_CONV3X3_UP2, "fyc_gemm: bad mode %d", a->mode);
@@ -61,6 +66,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(a->Hout > 0 && a->Wout > 0 && a->Hin > 0 && a->Win > 0, "fyc_gemm conv: bad spatial dims");
     FYC_REQUIRE(a->M % (a->Hout * a->Wout) == 0, "fyc_gemm conv: M=%d not a multiple of Hout*Wout", a->M);
     FYC_REQUIRE(batch == 1, "fyc_gemm conv: batch must be 1");
+    FYC_REQUIRE(a->a2 == nullptr, "fyc_gemm conv: a2 is a PLAIN-mode feature");
     if (a->mode == FYC_GEMM_CONV3X3) {
       FYC_REQUIRE(a->conv_stride == 1 || a->conv_stride == 2, "fyc_gemm conv: stride %d", a->conv_stride);
       FYC_REQUIRE(a->conv_pad == 0 || a->conv_pad == 1, "fyc_gemm conv: conv_pad must be 0 or 1");

@@ -29,9 +29,9 @@
 namespace fycg {
 
 struct GemmP {
-  const char* a; const char* w; const float* bias; const float* rowbias; const char* residual; char* out;
+  const char* a; const char* a2; const char* w; const float* bias; const float* rowbias; const char* residual; char* out;
   char* seg_out[3]; int seg_transposed[3]; int seg_ld[3];
-  int M, N, K, lda, ldw, ldo, ldr, ldrb;
+  int M, N, K, lda, ldw, ldo, ldr, ldrb, k_split, lda2;
   long long stride_a, stride_w, stride_o;
   int mode, epilogue;
   int Hout, Wout, Hin, Win, Cin, conv_stride, conv_pad;
@@ -102,11 +102,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   const long long bz = blockIdx.z;
   const T* __restrict__ A = reinterpret_cast<const T*>(p.a) + bz * p.stride_a;
   const T* __restrict__ W = reinterpret_cast<const T*>(p.w) + bz * p.stride_w;
+  const T* __restrict__ A2 = reinterpret_cast<const T*>(p.a2);   // optional second K source (PLAIN): A = [a | a2]
   const T* zero = reinterpret_cast<const T*>(p.zero);
 
   // ---- per-thread loader descriptors of the tile being ISSUED ----------------------------------
   int a_koff[A_IT];
   long long a_row[A_IT];   // PLAIN: m*lda, or -1 when the row is outside M
+  long long a_row2[A_IT];  // PLAIN dual source: m*lda2
   int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
   int b_koff[B_IT];
   long long b_row[B_IT];
@@ -131,11 +133,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       const int m = tile_m * BM + row;
       if (MODE == FYC_GEMM_PLAIN) {
         a_row[it] = (m < p.M) ? (long long)m * p.lda : -1;
+        a_row2[it] = (long long)m * p.lda2;
         a_pix[it] = a_iy0[it] = a_ix0[it] = 0;
       } else {
         const int hw = p.Hout * p.Wout;
         const int fr = m / hw, rem = m - fr * hw, oy = rem / p.Wout, ox = rem - oy * p.Wout;
         a_row[it] = (m < p.M) ? 0 : -1;
+        a_row2[it] = 0;
         a_pix[it] = fr * p.Hin * p.Win;
         a_iy0[it] = oy * p.conv_stride - p.conv_pad;
         a_ix0[it] = ox * p.conv_stride - p.conv_pad;
@@ -154,7 +158,9 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   auto src_a = [&](int it, int k0) -> const T* {
     if (MODE == FYC_GEMM_PLAIN) {
       const int k = k0 + a_koff[it];
-      return (a_row[it] >= 0 && k < p.K) ? A + a_row[it] + k : zero;
+      if (a_row[it] < 0 || k >= p.K) return zero;
+      if (A2 != nullptr && k >= p.k_split) return A2 + a_row2[it] + (k - p.k_split);
+      return A + a_row[it] + k;
     } else {
       const int ky = tap / 3, kx = tap - 3 * ky;
       const int iy = a_iy0[it] + ky, ix = a_ix0[it] + kx;

@@ -169,10 +169,16 @@ class UNet3DEngine(EngineBase):
         sc = self.lin(x, r.sc_w, rows, bias=r.sc_b) if r.sc_w is not None else x
         return self.conv(h, r.c2_w, r.c2_b, frames, g["H"], g["W"], residual=sc)
 
-    def feed_forward(self, ff: Packed, ln, tok: Tensor, rows: int, C: int) -> Tensor:
+    def feed_forward_out(self, ff: Packed, ln, tok: Tensor, residual: Tensor, rows: int, C: int) -> Tensor:
+        """LN -> GEGLU FF -> (+tok) -> output projection (+residual) with FF2 and the projection merged into one GEMM
+        over [tok | h] (see weights._ff): returns residual + Wp (tok + W2 h + b2) + bp."""
         n = self.layer_norm(tok, ln, rows, C)
         hmid = self.lin(n, ff.w1, rows, bias=ff.b1, geglu=True)
-        return self.lin(hmid, ff.w2, rows, bias=ff.b2, residual=tok)
+        out = self.new(rows, C)
+        K = ff.po_w.shape[1]
+        self.ops.gemm(tok, ff.po_w, out, M=rows, N=C, K=K, lda=C, ldw=K, ldo=C, bias=ff.po_b, residual=residual, ldr=C,
+                      a2=hmid, k_split=C, lda2=K - C)
+        return out
 
     def transformer(self, t: Packed, x: Tensor, g: dict) -> Tensor:
         """Transformer3DModel + BasicTransformerBlock (reference attention.py:217-308, 489-564)."""
@@ -204,8 +210,7 @@ class UNet3DEngine(EngineBase):
             self._attend(q2, ki, vti, att2, batch=BF, n_q=N, n_k=cache["n_ip"], d=d, ldvt=ldi, C=C, kv_div=g["F"],
                          accumulate=True, o_scale=self.cfg.ip_scale)
         tok = self.lin(att2, t.o2_w, rows, bias=t.o2_b, residual=tok)
-        tok = self.feed_forward(t.ff, t.ln3, tok, rows, C)
-        return self.lin(tok, t.pout_w, rows, bias=t.pout_b, residual=x)
+        return self.feed_forward_out(t.ff, t.ln3, tok, x, rows, C)
 
     def motion(self, m: Packed, x: Tensor, g: dict) -> Tensor:
         """VanillaTemporalModule (reference motion_module.py:157-208, 270-283, 371-464)."""
@@ -214,15 +219,16 @@ class UNet3DEngine(EngineBase):
         d = C // Hm
         h = self.group_norm(x, m.norm_g, m.norm_b, rows, C, N, 1e-6, False)
         tok = self.lin(h, m.pin_w, rows, bias=m.pin_b)
-        for blk in m.blocks:
+        for bi, blk in enumerate(m.blocks):
             for a in blk.attns:
                 n = self.layer_norm(tok, a.ln, rows, C, pe=a.pe, pe_div=N, pe_rows=g["F"])
                 qkv = self.lin(n, a.qkv_w, rows)
                 att = self.new(rows, C)
                 o.temporal_attention(qkv, att, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5)
                 tok = self.lin(att, a.o_w, rows, bias=a.o_b, residual=tok)
-            tok = self.feed_forward(blk.ff, blk.ff_ln, tok, rows, C)
-        return self.lin(tok, m.pout_w, rows, bias=m.pout_b, residual=x)
+            last = bi == len(m.blocks) - 1
+            tok = self.feed_forward_out(blk.ff, blk.ff_ln, tok, x if last else None, rows, C)   # inner blocks: identity projection
+        return tok
 
     # ---- forward -------------------------------------------------------------------------------
     def forward(self, x: Tensor, temb: Tensor, B: int, F: int, H: int, W: int) -> Tensor:

@@ -85,9 +85,20 @@ def _resnet(sd: Dict[str, Tensor], p: str, dtype, device, temb: bool = True) -> 
     return r
 
 
-def _ff(sd, p, dtype, device) -> Packed:
+def _ff(sd, p, dtype, device, proj_out_w: Tensor, proj_out_b: Tensor) -> Packed:
+    """GEGLU feed-forward followed by the block's output projection.
+
+    The reference computes tok' = tok + W2 h + b2 (FeedForward, diffusers/models/attention.py:772-775) and then
+    out = x + Wp tok' + bp (Transformer3DModel.proj_out attention.py:291-304 / TemporalTransformer3DModel.proj_out
+    motion_module.py:199-203); tok' is used nowhere else.  Both are linear, so they are merged at load time into ONE
+    GEMM over the K-concatenated operand [tok | h]:  out = x + (bp + Wp b2) + [Wp | Wp W2] [tok ; h]
+    (products in f32, then cast) - one launch and one full pass over the activations less per block."""
     w1, b1 = pack_geglu(sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"], dtype, device)
-    return Packed(w1=w1, b1=b1, w2=pack_linear(sd[p + ".net.2.weight"], dtype, device), b2=f32(sd[p + ".net.2.bias"], device))
+    w2, b2 = sd[p + ".net.2.weight"].double(), sd[p + ".net.2.bias"].double()
+    wp, bp = proj_out_w.reshape(proj_out_w.shape[0], -1).double(), proj_out_b.double()
+    merged_w = torch.cat([wp, wp @ w2], dim=1).float()
+    merged_b = (bp + wp @ b2).float()
+    return Packed(w1=w1, b1=b1, po_w=pack_linear(merged_w, dtype, device), po_b=f32(merged_b, device))
 
 
 def _ln(sd, p, device):
@@ -101,14 +112,13 @@ def _transformer(sd, p: str, cfg: UNet3DConfig, dtype, device) -> Packed:
         C=sd[p + ".proj_in.weight"].shape[0],
         norm_g=f32(sd[p + ".norm.weight"], device), norm_b=f32(sd[p + ".norm.bias"], device),
         pin_w=pack_linear(sd[p + ".proj_in.weight"], dtype, device), pin_b=f32(sd[p + ".proj_in.bias"], device),
-        pout_w=pack_linear(sd[p + ".proj_out.weight"], dtype, device), pout_b=f32(sd[p + ".proj_out.bias"], device),
         ln1=_ln(sd, t + ".norm1", device), ln2=_ln(sd, t + ".norm2", device), ln3=_ln(sd, t + ".norm3", device),
         qkv_w=pack_linear(torch.cat([sd[a1 + ".to_q.weight"], sd[a1 + ".to_k.weight"], sd[a1 + ".to_v.weight"]], 0), dtype, device),
         o1_w=pack_linear(sd[a1 + ".to_out.0.weight"], dtype, device), o1_b=f32(sd[a1 + ".to_out.0.bias"], device),
         q2_w=pack_linear(sd[a2 + ".to_q.weight"], dtype, device),
         kv2_w=pack_linear(torch.cat([sd[a2 + ".to_k.weight"], sd[a2 + ".to_v.weight"]], 0), dtype, device),
         o2_w=pack_linear(sd[a2 + ".to_out.0.weight"], dtype, device), o2_b=f32(sd[a2 + ".to_out.0.bias"], device),
-        ff=_ff(sd, t + ".ff", dtype, device), kvip_w=None)
+        ff=_ff(sd, t + ".ff", dtype, device, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]), kvip_w=None)
     if cfg.use_ip_cross_attention:
         d["kvip_w"] = pack_linear(torch.cat([sd[a2 + ".to_k_ip.weight"], sd[a2 + ".to_v_ip.weight"]], 0), dtype, device)
     return d
@@ -132,10 +142,14 @@ def _motion(sd, p: str, cfg: UNet3DConfig, dtype, device) -> Packed:
                 ln=_ln(sd, f"{t}.norms.{a}", device), pe=pe,
                 qkv_w=pack_linear(torch.cat([sd[ab + ".to_q.weight"], sd[ab + ".to_k.weight"], sd[ab + ".to_v.weight"]], 0), dtype, device),
                 o_w=pack_linear(sd[ab + ".to_out.0.weight"], dtype, device), o_b=f32(sd[ab + ".to_out.0.bias"], device)))
-        blocks.append(Packed(attns=attns, ff_ln=_ln(sd, t + ".ff_norm", device), ff=_ff(sd, t + ".ff", dtype, device)))
+        last = b == cfg.motion_num_transformer_block - 1
+        if last:   # the module's proj_out is merged into the last block's FF (see _ff)
+            ff = _ff(sd, t + ".ff", dtype, device, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+        else:      # inner blocks keep a plain FF2 + residual: identity "projection"
+            ff = _ff(sd, t + ".ff", dtype, device, torch.eye(C), torch.zeros(C))
+        blocks.append(Packed(attns=attns, ff_ln=_ln(sd, t + ".ff_norm", device), ff=ff))
     return Packed(C=C, norm_g=f32(sd[p + ".norm.weight"], device), norm_b=f32(sd[p + ".norm.bias"], device),
                   pin_w=pack_linear(sd[p + ".proj_in.weight"], dtype, device), pin_b=f32(sd[p + ".proj_in.bias"], device),
-                  pout_w=pack_linear(sd[p + ".proj_out.weight"], dtype, device), pout_b=f32(sd[p + ".proj_out.bias"], device),
                   blocks=blocks)
 
 

@@ -80,7 +80,8 @@ class HipOps:
              ldo: int = 0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None, rows_per_batch: int = 1,
              residual: Optional[Tensor] = None, ldr: int = 0, ldrb: int = 0, out_scale: float = 1.0, epilogue: int = L.EPI_LINEAR,
              mode: int = L.GEMM_PLAIN, conv: Optional[dict] = None, batch: int = 1, stride_a: int = 0,
-             stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None, tile: int = 0) -> None:
+             stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None, tile: int = 0,
+             a2: Optional[Tensor] = None, k_split: int = 0, lda2: int = 0) -> None:
         self.ensure_init(a.device)
         g = L.GemmArgs()
         g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
@@ -89,6 +90,7 @@ class HipOps:
         g.stride_a, g.stride_w, g.stride_o, g.batch = stride_a, stride_w, stride_o, batch
         g.mode, g.epilogue, g.rows_per_batch, g.out_scale, g.dtype = mode, epilogue, rows_per_batch, out_scale, _dt(a)
         g.tile = tile
+        g.a2, g.k_split, g.lda2 = _p(a2), k_split, lda2
         if a.dtype != w.dtype:
             raise TypeError(f"gemm: activation {a.dtype} vs weight {w.dtype}")
         if conv is not None:

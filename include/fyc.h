@@ -57,6 +57,7 @@ enum { FYC_EPI_LINEAR = 0, FYC_EPI_GEGLU = 1, FYC_EPI_HEADS = 2 };
 
 typedef struct {
   const void* a;         /* PLAIN: [batch][M][lda]; CONV: NHWC input [frames][Hin][Win][Cin] */
+  const void* a2;        /* PLAIN only, optional: K columns >= k_split come from a2[m][k - k_split] (row pitch lda2): A = [a | a2] */
   const void* w;         /* [batch?][Nw][ldw], K contiguous; conv: K = 9*Cin ordered (slab, ky, kx, c) with 128-byte channel slabs */
   const float* bias;     /* [N] or NULL (GEGLU: packed order) */
   const float* rowbias;  /* [M / rows_per_batch][ldrb] or NULL (ResnetBlock3D time_emb_proj add) */
@@ -68,6 +69,7 @@ typedef struct {
   int32_t M, N, K;
   int32_t lda, ldw, ldo, ldr;
   int32_t ldrb;          /* row pitch of rowbias in elements (0 = N) */
+  int32_t k_split, lda2; /* dual-source A (a2 != NULL): k_split must be a multiple of 64 elements */
   int64_t stride_a, stride_w, stride_o; /* batch strides in elements (0 = shared) */
   int32_t batch;
   int32_t mode;          /* FYC_GEMM_* */

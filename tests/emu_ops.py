@@ -40,13 +40,17 @@ class EmuOps:
     # ------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
              ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
-             heads=None, tile=0):
+             heads=None, tile=0, a2=None, k_split=0, lda2=0):
         acc_t = self.acc
         af, wf = _flat(a), _flat(w)
         for z in range(batch):
             W = _strided(wf, (N, K), (ldw, 1), z * stride_w).to(acc_t)
             if mode == PLAIN:
-                A = _strided(af, (M, K), (lda, 1), z * stride_a).to(acc_t)
+                if a2 is None:
+                    A = _strided(af, (M, K), (lda, 1), z * stride_a).to(acc_t)
+                else:  # dual-source A = [a | a2]
+                    A = torch.cat([_strided(af, (M, k_split), (lda, 1), 0).to(acc_t),
+                                   _strided(_flat(a2), (M, K - k_split), (lda2, 1), 0).to(acc_t)], dim=1)
                 acc = A @ W.t()
             else:
                 Hin, Win, Cin, Hout, Wout = conv["Hin"], conv["Win"], conv["Cin"], conv["Hout"], conv["Wout"]

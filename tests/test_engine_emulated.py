@@ -126,3 +126,21 @@ def test_vae_encode_matches_golden(golden_dir):
     assert set(vae_encoder_schema(vcfg)) == set(sde)
     enc = VAEEncoderEngine(pack_vae_encoder(sde, vcfg, torch.float32, "cpu"), ops=EmuOps())
     assert (enc.encode_moments(g["x"]) - g["moments"]).abs().max().item() < 1e-4
+
+
+def test_two_transformer_blocks_per_motion_module():
+    """num_transformer_block=2 (VanillaTemporalModule default): inner block keeps a plain FF residual"""
+    ocfg = Fn.tiny_unet_config(motion_num_transformer_block=2)
+    sd = W.make_weights(W.unet_state_shapes(ocfg), 2)
+    inp = W.seeded_inputs(ocfg, 1, 3, 8, 8, seed=5)
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    with torch.no_grad():
+        ref = Fn.unet3d_forward(sd, ocfg, x9, torch.tensor(321), inp["text"], torch.tensor([2, 2]), torch.tensor([4, 4]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(motion_num_transformer_block=2), torch.float32, "cpu"), ops=EmuOps())
+    B, C9, F, H, Wd = x9.shape
+    x = torch.zeros(B * F * H * Wd, 64)
+    x[:, :C9] = x9.permute(0, 2, 3, 4, 1).reshape(-1, C9)
+    eng.prepare_context(inp["text"])
+    _, temb = eng.prepare_time_embeddings([321], [2, 2], [4, 4], B)
+    out = eng.forward(x, temb, B, F, H, Wd).reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    assert ((out - ref).norm() / ref.norm()).item() < 2e-4

@@ -140,6 +140,22 @@ def test_gemm_heads(hip, emu, dt, tokens, heads, d):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("M,C", [(300, 64), (1000, 320)])
+def test_gemm_dual_source_k(hip, emu, dt, M, C):
+    """A = [tok | hidden]: the merged FF2 + output projection GEMM (K = C + 4C)"""
+    T = DT[dt]
+    tok, hid = rnd((M, C), T, 1), rnd((M, 4 * C), T, 2)
+    w, bias, res = rnd((C, 5 * C), T, 3, 1 / math.sqrt(5 * C)), rnd((C,), torch.float32, 4), rnd((M, C), T, 5)
+    kw = dict(M=M, N=C, K=5 * C, lda=C, ldw=5 * C, ldo=C, ldr=C, k_split=C, lda2=4 * C)
+    o_h = torch.full((M, C), float("nan"), dtype=T, device="cuda")
+    hip.gemm(tok.cuda(), w.cuda(), o_h, bias=bias.cuda(), residual=res.cuda(), a2=hid.cuda(), **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(M, C, dtype=T)
+    emu.gemm(tok, w, o_e, bias=bias, residual=res, a2=hid, **kw)
+    close(o_h, o_e, f"dual-source gemm {dt} M={M} C={C}", RTOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_gemm_batched(hip, emu, dt):
     """the materialised-attention shape: S[z] = q[z] k[z]^T * scale, d = 40"""
     T = DT[dt]
