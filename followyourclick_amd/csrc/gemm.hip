@@ -25,7 +25,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   if (g_fyc_tuning[1] > 0) cfg = g_fyc_tuning[1];
   if (g_fyc_tuning[2] > 0) ns = g_fyc_tuning[2];
   if (cfg == 3 && ns > 3) ns = 3;
-  if (cfg >= 5) ns = 2;
+  if (cfg >= 5) ns = 2;   // configs 5+ fix their own ring depth
 }
 }  // namespace
 

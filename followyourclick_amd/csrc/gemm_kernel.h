@@ -69,18 +69,27 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS>
+// swizzle key of an LDS row: 128-B rows (8 chunks) use row&7; 64-B rows (4 chunks) use a 4-entry table over (row>>2)&3 -
+// both make the ds_read_b128 of 16 consecutive rows x one chunk conflict-free under the real 16-lane service groups
+template <int RB> __device__ __forceinline__ int swz_key(int row) {
+  if (RB == 128) return row & 7;
+  return (0x78 >> (((row >> 2) & 3) * 2)) & 3;   // {0, 2, 3, 1}
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128>
 __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) {
   typedef Mma<T> Tr;
   typedef typename Tr::Frag Frag;
   constexpr int NT = WGM * WGN * 64;
   constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-B chunk
-  constexpr int BK = 8 * CH;               // elements per K tile (one 128-B LDS row)
-  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  constexpr int CPR = RB / 16;             // 16-B chunks per LDS row (8 or 4)
+  constexpr int BK = CPR * CH;             // elements per K tile (one RB-byte LDS row)
+  constexpr int KSTEPS = RB / 64;          // MFMA k-steps (4 chunks each) per K tile
+  constexpr int A_IT = BM * CPR / NT, B_IT = BN * CPR / NT;
   constexpr int LOADS = A_IT + B_IT;       // DMA instructions per thread per K tile
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-  static_assert(A_IT * NT == BM * 8 && B_IT * NT == BN * 8, "tile/threads mismatch");
+  constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB;
+  static_assert(A_IT * NT == BM * CPR && B_IT * NT == BN * CPR, "tile/threads mismatch");
   static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LOADS < 64, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -115,13 +124,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   int tap = 0, c0 = 0;  // conv: filter tap and channel offset of the K tile being issued
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    const int idx = tid + it * NT, row = idx >> 3, slot = idx & 7;
-    a_koff[it] = ((slot ^ (row & 7)) * CH);
+    const int idx = tid + it * NT, row = idx / CPR, slot = idx % CPR;
+    a_koff[it] = ((slot ^ swz_key<RB>(row)) * CH);
   }
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
-    const int idx = tid + it * NT, row = idx >> 3, slot = idx & 7;
-    b_koff[it] = ((slot ^ (row & 7)) * CH);
+    const int idx = tid + it * NT, row = idx / CPR, slot = idx % CPR;
+    b_koff[it] = ((slot ^ swz_key<RB>(row)) * CH);
   }
   auto setup_issue = [&](int tile) {
     const int t = remap(tile);
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     tap = 0; c0 = 0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      const int row = (tid + it * NT) >> 3;
+      const int row = (tid + it * NT) / CPR;
       const int m = tile_m * BM + row;
       if (MODE == FYC_GEMM_PLAIN) {
         a_row[it] = (m < p.M) ? (long long)m * p.lda : -1;
@@ -147,7 +156,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int row = (tid + it * NT) >> 3;
+      const int row = (tid + it * NT) / CPR;
       const int n = tile_n * BN + row;
       b_row[it] = (n < p.N) ? (long long)n * p.ldw : -1;
     }
@@ -186,18 +195,19 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 
   f32x4 acc[WTM][WTN];
 
-  const int sw = lane & 7, g = lane >> 4, r16 = lane & 15;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int sw = swz_key<RB>(r16);   // all fragment rows are r16 + multiples of 16: same key
   auto compute = [&](int stage) {
-    const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * 128;
-    const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * 128;
+    const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * RB;
+    const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * RB;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KSTEPS; ++s) {
       const int coff = ((4 * s + g) ^ sw) * 16;
       Frag af[WTM], bf[WTN];
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) af[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * 128 + coff);
+      for (int i = 0; i < WTM; ++i) af[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * RB + coff);
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) bf[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * 128 + coff);
+      for (int j = 0; j < WTN; ++j) bf[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * RB + coff);
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
@@ -212,8 +222,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     for (int it = 0; it < A_IT; ++it) glds16(src_a(it, k0), sA + (it * NT + wave * 64) * 16);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) glds16(src_b(it, k0), sB + (it * NT + wave * 64) * 16);
-    if (MODE != FYC_GEMM_PLAIN) {  // K order = (channel slab, ky, kx, channel): the 9 taps of one 128-B slab are adjacent
-      if (++tap == 9) { tap = 0; c0 += BK; }
+    if (MODE != FYC_GEMM_PLAIN) {  // K order = (128-B channel slab, ky, kx, channel): the 9 taps of a slab are adjacent
+      if (RB == 128) {
+        if (++tap == 9) { tap = 0; c0 += BK; }
+      } else {                       // 64-B tiles: two tiles per (slab, tap) unit
+        if (c0 & BK) { c0 -= BK; if (++tap == 9) { tap = 0; c0 += 2 * BK; } }
+        else c0 += BK;
+      }
     }
   };
 
@@ -425,11 +440,11 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   }  // tile stream
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128>
 int launch(const GemmP& p, int batch, hipStream_t st) {
-  constexpr int smem = NS * (BM + BN) * 128;
+  constexpr int smem = NS * (BM + BN) * RB;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS>;
+  auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS, RB>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -473,6 +488,9 @@ int dispatch_cfg(int cfg, const GemmP& p, int batch, hipStream_t st) {
     case 5: if constexpr (NS == 2) return launch<T, 256, 320, 4, 2, MODE, EPI, NS>(p, batch, st); else break;
     case 6: if constexpr (NS == 2) return launch<T, 128, 320, 2, 4, MODE, EPI, NS>(p, batch, st); else break;
     case 7: if constexpr (NS == 2) return launch<T, 256, 256, 2, 4, MODE, EPI, NS>(p, batch, st); else break;
+    // 64-byte K tiles: half the LDS per stage -> two independent 4-wave blocks per CU with 64x160 wave tiles (8)
+    case 8: if constexpr (NS == 2 && sizeof(T) == 2) return launch<T, 128, 320, 2, 2, MODE, EPI, 2, 64>(p, batch, st); else break;
+    case 10: if constexpr (NS == 2 && sizeof(T) == 2) return launch<T, 128, 128, 2, 2, MODE, EPI, 2, 64>(p, batch, st); else break;
   }
   FYC_FAIL(-2, "fyc_gemm: tile config %d / ring depth %d not built", cfg, NS);
 }

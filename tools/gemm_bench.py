@@ -17,7 +17,7 @@ SHAPES = [
     ("conv", 8192, 1280, 11520, 0, 1, (16, 16, 1280, 1, 0)), ("conv", 2048, 1280, 11520, 0, 1, (8, 8, 1280, 1, 0)),
     ("conv", 131072, 320, 5760, 0, 0, (64, 64, 640, 1, 0)), ("conv", 8192, 1280, 23040, 0, 0, (16, 16, 2560, 1, 0)),
 ]
-CFGS = [(1, 2), (2, 2), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2)]
+CFGS = [(1, 2), (2, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)]
 
 
 def main():
