@@ -1,1 +1,2 @@
 from .vae import AutoencoderKL  # noqa: F401
+from .unet_2d_condition import UNet2DConditionModel  # noqa: F401

@@ -3,6 +3,9 @@ engine's host-side tables.  AnimationPipeline does NOT call `step()` in its loop
 update are one fused kernel there - but the method is kept for scripts that drive a scheduler by hand."""
 from __future__ import annotations
 
+import inspect
+import json
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Optional, Union
@@ -36,6 +39,26 @@ class DDIMScheduler:
         self.init_noise_sigma = 1.0
         self.num_inference_steps = None
         self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.int64)
+
+    @classmethod
+    def from_config(cls, config: dict, **kwargs):
+        """Keeps the keys this scheduler's constructor knows and drops the rest (a checkpoint's scheduler_config.json
+        usually belongs to another scheduler class, e.g. PNDM's `skip_prk_steps`) - reference configuration_utils.py:189-226."""
+        known = set(inspect.signature(cls.__init__).parameters) - {"self", "kwargs"}
+        cfg = {k: v for k, v in dict(config).items() if k in known}
+        cfg.update({k: v for k, v in kwargs.items() if k in known})
+        return cls(**cfg)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, **kwargs):
+        """`DDIMScheduler.from_pretrained(path, subfolder="scheduler")` (scripts/inference.py:198): local directory only."""
+        if subfolder is not None:
+            pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
+        config_file = os.path.join(pretrained_model_path, "scheduler_config.json")
+        if not os.path.isfile(config_file):
+            raise EnvironmentError(f"Error no file named scheduler_config.json found in directory {pretrained_model_path}.")
+        with open(config_file) as f:
+            return cls.from_config(json.load(f), **kwargs)
 
     def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
         return sample

@@ -2,7 +2,8 @@
 
 Restates the hot loop of AnimationPipeline.__call__ (reference
 animatediff/pipelines/pipeline_animation.py:686-773) for the mask + first-frame concat conditioning
-with classifier-free guidance.  Per step: build the 9-channel channels-last input (one kernel instead
+with classifier-free guidance, and - for a UNet built without the concat conditioning - the loop of
+StableDiffusionPipeline.__call__ (reference diffusers/pipelines/stable_diffusion/pipeline_stable_diffusion.py:522-541).  Per step: build the 9-channel channels-last input (one kernel instead
 of 3 zeros_like + 2 cat), UNet forward on the CFG pair, guidance + DDIM update (one kernel, no host
 sync).  Everything that is constant over the loop (text/IP K/V, all time embeddings, DDIM
 coefficients) is prepared once per clip.
@@ -64,8 +65,14 @@ class DDIMSampler:
         if u.cfg.use_first_frame_mask_condition_concat:
             o.unet_input(latents, mask, first_image_latents, x, B=B, F=F, HW=H * W, c_latent=CL, c_pad=cp, cfg_dup=dupn,
                          mask_frames=1)
+        elif u.cfg.use_first_frame_condition_concat:
+            raise NotImplementedError("use_first_frame_condition_concat (reference pipeline_animation.py:705-706) is not implemented")
         else:
-            raise NotImplementedError("only the mask + first-frame concat conditioning path is implemented")
+            # plain latents (the 2-D Stable Diffusion first-image path, reference pipeline_stable_diffusion.py:527-528)
+            n = B * F * H * W
+            frames = latents.permute(0, 2, 1, 3, 4).reshape(B * F, CL, H * W).contiguous()
+            for d in range(dupn):
+                o.nchw_to_nhwc(frames, x[d * n:(d + 1) * n], N=B * F, C_=CL, HW=H * W, c_pad=cp, scale=1.0)
         pred = u.forward(x, st["temb"][i], dupn * B, F, H, W)
         o.cfg_ddim_step(pred, latents, st["coef"][i], B=B, F=F, HW=H * W, c_latent=CL, ld=pred.shape[1], cfg=st["cfg"],
                         guidance=st["guidance"], pred_type=self.tables.pred_type, clip_sample=self.clip_sample)

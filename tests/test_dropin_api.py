@@ -129,3 +129,68 @@ def test_attention_processor_surface(dropin):
     assert p.to_k_ip.weight.shape == (320, 768) and p.to_v_ip.bias is None and p.num_tokens == 16 and p.scale == 0.5
     assert list(inspect.signature(p.__call__).parameters) == ["attn", "hidden_states", "encoder_hidden_states", "attention_mask", "temb"]
     assert isinstance(p, torch.nn.Module) and not isinstance(ap.CNAttnProcessor(), torch.nn.Module)
+
+
+# ---- 2-D first-image path: diffusers.UNet2DConditionModel / StableDiffusionPipeline / DDIMScheduler.from_pretrained ----
+TINY_2D = dict(sample_size=8, block_out_channels=(64, 128, 256, 256), cross_attention_dim=64)
+
+
+def test_unet2d_state_dict_and_loading(dropin, golden_dir, tmp_path):
+    import json
+    from diffusers import UNet2DConditionModel
+    from diffusers.models import UNet2DConditionModel as M2
+    assert M2 is UNet2DConditionModel
+    unet = UNet2DConditionModel(**TINY_2D)
+    with open(os.path.join(golden_dir, "schema_unet2d_tiny.json")) as f:
+        ref = {k: tuple(v) for k, v in json.load(f).items()}
+    assert {k: tuple(v.shape) for k, v in unet.state_dict().items()} == ref        # the REAL reference 2-D UNet's state dict
+    assert unet.config.down_block_types[0] == "CrossAttnDownBlock2D" and unet.in_channels == 4
+    assert [p for p in inspect.signature(UNet2DConditionModel.forward).parameters][1:] == \
+        ["sample", "timestep", "encoder_hidden_states", "class_labels", "attention_mask", "return_dict"]
+    # from_pretrained on a diffusers-style directory (config.json + diffusion_pytorch_model.bin)
+    d = tmp_path / "unet"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(dict(TINY_2D, _class_name="UNet2DConditionModel", _diffusers_version="0.11.1")))
+    torch.save(unet.state_dict(), d / "diffusion_pytorch_model.bin")
+    again = UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+    assert all(torch.equal(a, b) for a, b in zip(unet.state_dict().values(), again.state_dict().values()))
+    with pytest.raises(EnvironmentError):
+        UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="nope")
+    with pytest.raises(NotImplementedError):
+        UNet2DConditionModel(**TINY_2D, down_block_types=("AttnDownBlock2D",) * 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        unet(torch.zeros(1, 4, 8, 8), 1, torch.zeros(1, 77, 64))
+
+
+def test_sd_pipeline_surface(dropin, tmp_path):
+    import json
+    from diffusers import AutoencoderKL, DDIMScheduler, StableDiffusionPipeline, UNet2DConditionModel
+    from diffusers.pipelines import StableDiffusionPipeline as P2
+    assert P2 is StableDiffusionPipeline
+    assert [p for p in inspect.signature(StableDiffusionPipeline.__call__).parameters][1:] == \
+        ["prompt", "height", "width", "num_inference_steps", "guidance_scale", "negative_prompt", "num_images_per_prompt", "eta",
+         "generator", "latents", "output_type", "return_dict", "callback", "callback_steps"]
+    # a checkpoint's scheduler_config.json written by another scheduler class (SD-1.5 ships PNDM's)
+    d = tmp_path / "scheduler"
+    d.mkdir()
+    (d / "scheduler_config.json").write_text(json.dumps(dict(
+        _class_name="PNDMScheduler", _diffusers_version="0.6.0", beta_end=0.012, beta_schedule="scaled_linear", beta_start=0.00085,
+        num_train_timesteps=1000, set_alpha_to_one=False, skip_prk_steps=True, steps_offset=1, trained_betas=None, clip_sample=False)))
+    sch = DDIMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")
+    assert sch.config.beta_schedule == "scaled_linear" and sch.config.set_alpha_to_one is False and sch.config.prediction_type == "epsilon"
+    assert float(sch.final_alpha_cumprod) == float(sch.alphas_cumprod[0])
+    from oracle import stubs
+    unet, vae = UNet2DConditionModel(**TINY_2D), AutoencoderKL(block_out_channels=(64, 128, 128, 128))
+    with pytest.raises(ValueError, match="needs"):
+        StableDiffusionPipeline.from_pretrained("unused", unet=unet)
+    pipe = StableDiffusionPipeline.from_pretrained("unused", unet=unet, vae=vae, tokenizer=stubs.FakeTokenizer(),
+                                                   text_encoder=stubs.StubTextEncoder(64), scheduler=sch, safety_checker=None)
+    assert pipe.vae_scale_factor == 8
+    with pytest.raises(ValueError, match="divisible by 8"):
+        pipe("x", height=60, width=64)
+    with pytest.raises(ValueError, match="`prompt` has to be"):
+        pipe(3, height=64, width=64)
+    with pytest.raises(ValueError, match="Unexpected latents shape"):
+        pipe("x", height=64, width=64, latents=torch.zeros(1, 4, 4, 4))
+    with pytest.raises(NotImplementedError):
+        StableDiffusionPipeline(vae, stubs.StubTextEncoder(64), stubs.FakeTokenizer(), unet, sch, safety_checker=object())

@@ -142,3 +142,47 @@ def test_autoencoder_encode_then_decode_surface(dropin, golden_dir):
     assert z.shape == (2, 4, 8, 6) and torch.isfinite(z).all()
     img = vae.decode(z / 0.18215).sample
     assert img.shape == (2, 3, 64, 48)
+
+
+# ---- 2-D first-image path against the REAL reference's UNet2DConditionModel / StableDiffusionPipeline ----------
+TINY_2D = dict(sample_size=8, block_out_channels=(64, 128, 256, 256), cross_attention_dim=64)
+CFG_2D = dict(use_motion_module=False, use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_unet2d_forward(dropin, golden_dir, dtype, tol):
+    from diffusers import UNet2DConditionModel
+    g = _load(golden_dir, "sd2d_unet_fwd.npz")
+    unet = UNet2DConditionModel(**TINY_2D, compute_dtype=dtype).to("cuda")
+    unet.load_state_dict(W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config(**CFG_2D)), int(g["weight_seed"])))
+    for s, t, o in (("sample", "timestep", "out"), ("sample_odd", "timestep_odd", "out_odd")):
+        out = unet(g[s].cuda(), torch.tensor(int(g[t])), g["text"].cuda()).sample.cpu()
+        assert out.shape == g[o].shape
+        assert ((out - g[o]).norm() / g[o].norm()).item() < tol
+
+
+@pytest.mark.parametrize("dtype,tol_lat,tol_img", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 1e-1, 6e-2)])
+def test_stable_diffusion_pipeline_call(dropin, golden_dir, dtype, tol_lat, tol_img):
+    from diffusers import AutoencoderKL, DDIMScheduler, StableDiffusionPipeline, UNet2DConditionModel
+    g = _load(golden_dir, "sd2d_pipeline.npz")
+    unet = UNet2DConditionModel(**TINY_2D, compute_dtype=dtype)
+    unet.load_state_dict(W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config(**CFG_2D)), int(g["unet_weight_seed"])))
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4, compute_dtype=dtype)
+    vae.load_state_dict(W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["vae_weight_seed"])), strict=False)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                          set_alpha_to_one=False, steps_offset=1, prediction_type="epsilon")
+    pipe = StableDiffusionPipeline.from_pretrained("unused", vae=vae, text_encoder=stubs.StubTextEncoder(64), tokenizer=stubs.FakeTokenizer(),
+                                                   unet=unet, scheduler=sched, safety_checker=None).to("cuda")
+    pipe.enable_vae_slicing()
+    traj = []
+    out = pipe("a corgi on the beach", height=64, width=64, num_inference_steps=4, guidance_scale=8.0, negative_prompt="blurry",
+               latents=g["latents"].clone(), output_type="np", callback=lambda i, t, l: traj.append(l.clone().cpu()), callback_steps=1)
+    traj = torch.stack(traj)
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < tol_lat, err
+    assert out.images.shape == g["images"].shape and out.nsfw_content_detected is None
+    ref = g["images"].numpy()                                   # images in [0,1]: relative L2 (max-abs is dominated by bf16 rounding)
+    e = float(np.linalg.norm(out.images - ref) / np.linalg.norm(ref))
+    assert e < tol_img, e
+    pil = pipe("a corgi on the beach", height=64, width=64, num_inference_steps=2, latents=g["latents"].clone()).images
+    assert len(pil) == 1 and pil[0].size == (64, 64)

@@ -144,3 +144,48 @@ def test_two_transformer_blocks_per_motion_module():
     _, temb = eng.prepare_time_embeddings([321], [2, 2], [4, 4], B)
     out = eng.forward(x, temb, B, F, H, Wd).reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
     assert ((out - ref).norm() / ref.norm()).item() < 2e-4
+
+
+# ---- 2-D Stable Diffusion first-image path -------------------------------------------------------------
+def cfg_2d():
+    return tiny_cfg(use_motion_module=False, use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+
+
+def oracle_cfg_2d():
+    return Fn.tiny_unet_config(use_motion_module=False, use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+
+
+SCHED_2D = dict(beta_schedule="scaled_linear", set_alpha_to_one=False, prediction_type="epsilon", rescale_betas_zero_snr=False)
+
+
+def test_unet2d_forward_matches_reference(golden_dir):
+    """UNet2DConditionModel.forward of the real reference == the engine run as a one-frame clip without motion modules."""
+    g = _load(golden_dir, "sd2d_unet_fwd.npz")
+    sd = W.make_weights(W.unet_state_shapes(oracle_cfg_2d()), int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, cfg_2d(), torch.float32, "cpu"), ops=EmuOps())
+    eng.prepare_context(g["text"])
+    for s, t, o in (("sample", "timestep", "out"), ("sample_odd", "timestep_odd", "out_odd")):
+        B, C, H, Wd = g[s].shape
+        x = torch.zeros(B * H * Wd, 64)
+        x[:, :C] = g[s].permute(0, 2, 3, 1).reshape(-1, C)
+        _, temb = eng.prepare_time_embeddings([int(g[t])], None, None, B)
+        out = eng.forward(x, temb, B, 1, H, Wd).reshape(B, H, Wd, 4).permute(0, 3, 1, 2)
+        assert ((out - g[o]).norm() / g[o].norm()).item() < 2e-4
+
+
+def test_sampler_plain_latents_matches_reference_sd_pipeline(golden_dir):
+    """StableDiffusionPipeline.__call__ of the real reference: 4 DDIM steps, epsilon prediction, scaled_linear betas."""
+    g = _load(golden_dir, "sd2d_pipeline.npz")
+    sd = W.make_weights(W.unet_state_shapes(oracle_cfg_2d()), int(g["unet_weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, cfg_2d(), torch.float32, "cpu"), ops=EmuOps())
+    traj = []
+    lat = DDIMSampler(eng, DDIMConfig(**SCHED_2D)).sample(g["latents"][:, :, None], g["text_embeddings"], 4, 8.0,
+                                                          callback=lambda i, t, l: traj.append(l[:, :, 0].clone()))
+    traj = torch.stack(traj)
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < 5e-4, err
+    vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
+    sdv = W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["vae_weight_seed"]))
+    vae = VAEDecoderEngine(pack_vae_decoder(sdv, vcfg, torch.float32, "cpu"), ops=EmuOps())
+    img = vae.decode_video(lat)[:, :, 0].permute(0, 2, 3, 1)
+    assert (img - g["images"]).abs().max().item() < 2e-3

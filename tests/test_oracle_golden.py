@@ -122,3 +122,43 @@ def test_vae_encode_tiny(golden_dir):
     with torch.no_grad():
         m = Fn.vae_encode_moments(sd, vcfg, g["x"])
     assert (m - g["moments"]).abs().max().item() < TOL
+
+
+# ---- 2-D Stable Diffusion first-image path: the reference's UNet2DConditionModel / StableDiffusionPipeline ----
+def _cfg2d():
+    return Fn.tiny_unet_config(use_motion_module=False, use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+
+
+SCHED_2D = dict(beta_schedule="scaled_linear", set_alpha_to_one=False, prediction_type="epsilon", rescale_betas_zero_snr=False)
+
+
+def test_schema_unet2d(golden_dir):
+    ref = _schema(golden_dir, "schema_unet2d_tiny.json")
+    mine = {k: tuple(v) for k, v in W.unet_state_shapes(_cfg2d()).items()}
+    assert mine == ref
+
+
+def test_unet2d_forward(golden_dir):
+    g = _load(golden_dir, "sd2d_unet_fwd.npz")
+    cfg = _cfg2d()
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["weight_seed"]))
+    for s, t, o in (("sample", "timestep", "out"), ("sample_odd", "timestep_odd", "out_odd")):
+        x = g[s][:, :, None]                          # (B,4,H,W) -> one-frame clip (B,4,1,H,W)
+        y = Fn.unet3d_forward(sd, cfg, x, torch.tensor(int(g[t])), g["text"])[:, :, 0]
+        assert torch.allclose(y, g[o], atol=2e-5, rtol=1e-4), (y - g[o]).abs().max()
+
+
+def test_sd2d_pipeline_trajectory(golden_dir):
+    g = _load(golden_dir, "sd2d_pipeline.npz")
+    cfg = _cfg2d()
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["unet_weight_seed"]))
+    sched = Fn.DDIMConfig(**SCHED_2D)
+    traj = []
+    lat = Fn.denoise(sd, cfg, sched, g["latents"][:, :, None], g["text_embeddings"], 4, 8.0,
+                     callback=lambda i, t, l: traj.append(l[:, :, 0].clone()))
+    traj = torch.stack(traj)
+    assert torch.allclose(traj, g["trajectory"], atol=5e-5, rtol=1e-4), (traj - g["trajectory"]).abs().max()
+    vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))
+    sdv = W.make_weights(W.vae_decoder_state_shapes(vcfg), int(g["vae_weight_seed"]))
+    img = (Fn.vae_decode(sdv, vcfg, lat[:, :, 0] / 0.18215) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
+    assert torch.allclose(img, g["images"], atol=2e-5), (img - g["images"]).abs().max()
