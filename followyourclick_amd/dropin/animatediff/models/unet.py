@@ -160,6 +160,10 @@ class UNet3DConditionModel(nn.Module):
     def set_attention_slice(self, slice_size) -> None:
         """no-op: attention never materialises the score matrix, there is nothing to slice"""
 
+    def invalidate_engine(self) -> None:
+        """force re-packing on the next forward (for in-place `.data` edits, which do not bump tensor versions)"""
+        self._engine_key = None
+
     def _weights_key(self):
         return (self.device, self.compute_dtype) + tuple(p._version for p in self.parameters(recurse=True) if p.dim() > 0)
 
