@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("FYC_LIB_PATH") or os.path.join(HERE, "libfyc_hip.so")
 FYC_F32, FYC_BF16 = 0, 1
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_CONV3X3_UP2 = 0, 1, 2
 EPI_LINEAR, EPI_GEGLU, EPI_HEADS = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -27,7 +28,7 @@ class GemmArgs(C.Structure):
                 ("batch", i32), ("mode", i32), ("epilogue", i32),
                 ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32), ("conv_pad", i32),
                 ("rows_per_batch", i32), ("seg_cols", i32), ("heads", i32), ("tokens", i32),
-                ("out_scale", f32), ("dtype", i32), ("tile", i32)]
+                ("out_scale", f32), ("dtype", i32), ("tile", i32), ("act", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -57,7 +58,7 @@ class LayerNormArgs(C.Structure):
 
 
 class SoftmaxArgs(C.Structure):
-    _fields_ = [("x", vp), ("rows", i64), ("cols", i32), ("ld", i32), ("dtype", i32)]
+    _fields_ = [("x", vp), ("rows", i64), ("cols", i32), ("ld", i32), ("dtype", i32), ("causal_rows", i32)]
 
 
 class ConcatArgs(C.Structure):
@@ -93,6 +94,15 @@ class NhwcOutArgs(C.Structure):
                 ("mul", f32), ("add", f32), ("lo", f32), ("hi", f32), ("dtype", i32)]
 
 
+class EmbedArgs(C.Structure):
+    _fields_ = [("ids", vp), ("table", vp), ("pos", vp), ("out", vp), ("rows", i64), ("seq", i32), ("C", i32), ("vocab", i32),
+                ("dtype", i32)]
+
+
+class PatchifyArgs(C.Structure):
+    _fields_ = [("image", vp), ("out", vp), ("B", i32), ("Cin", i32), ("H", i32), ("W", i32), ("P", i32), ("ld", i32), ("dtype", i32)]
+
+
 # name -> args struct for every `int fyc_<op>(const args*, void* stream)` entry point
 OPS = {
     "fyc_gemm": GemmArgs, "fyc_attention": AttnArgs, "fyc_temporal_attention": TAttnArgs,
@@ -100,6 +110,7 @@ OPS = {
     "fyc_softmax_rows": SoftmaxArgs, "fyc_concat_channels": ConcatArgs, "fyc_silu_f32": SiluArgs,
     "fyc_cast_from_f32": CastArgs, "fyc_cast_to_f32": CastArgs, "fyc_unet_input": UnetInputArgs,
     "fyc_cfg_ddim_step": CfgDdimArgs, "fyc_nchw_to_nhwc": NchwInArgs, "fyc_nhwc_to_nchw": NhwcOutArgs,
+    "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs,
 }
 MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning"]
 

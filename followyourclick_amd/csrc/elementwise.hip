@@ -128,6 +128,47 @@ inline int grid_for(long long n) {
   return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
 }
 
+
+// out[r][c8..] = table[ids[r]][c8..] + pos[r % seq][c8..]: one thread per 8 channels
+template <typename T>
+__global__ void __launch_bounds__(256) embed_tokens_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, T* __restrict__ out, long long rows,
+                                                           int seq, int C, int vocab) {
+  const int C8 = C >> 3;
+  const long long total = rows * C8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C8;
+    const int c = (int)(i - r * C8) * 8;
+    long long id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // host validates ids; clamp keeps a bad id from reading out of bounds
+    const float* t = table + id * C + c;
+    const float* pp = pos + (long long)(r % seq) * C + c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = t[e] + pp[e];
+    store8<T>(out + r * C + c, v);
+  }
+}
+
+// one thread per output element; reads are P-contiguous runs of the image rows
+template <typename T>
+__global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int Cin, int H,
+                                                       int W, int P, int ld) {
+  const int gh = H / P, gw = W / P, K = Cin * P * P;
+  const long long total = (long long)B * gh * gw * ld;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % ld);
+    const long long patch = i / ld;
+    float v = 0.f;
+    if (k < K) {
+      const int px = k % P, py = (k / P) % P, c = k / (P * P);
+      const int gx = (int)(patch % gw), gy = (int)((patch / gw) % gh), b = (int)(patch / ((long long)gw * gh));
+      v = img[(((long long)b * Cin + c) * H + gy * P + py) * W + gx * P + px];
+    }
+    ElemIO<T>::st(out + i, v);
+  }
+}
+
 }  // namespace
 
 #define FYC_DT(a, call_bf16, call_f32)                         \
@@ -225,5 +266,31 @@ extern "C" int fyc_nhwc_to_nchw(const fyc_nhwc_out_args* a, void* stream) {
          hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->x, a->y, a->N, a->C, a->HW, a->ld, a->mul, a->add, a->lo, a->hi),
          hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->x, a->y, a->N, a->C, a->HW, a->ld, a->mul, a->add, a->lo, a->hi));
   FYC_CHECK_LAUNCH("fyc_nhwc_to_nchw");
+  return 0;
+}
+
+extern "C" int fyc_embed_tokens(const fyc_embed_args* a, void* stream) {
+  FYC_REQUIRE(a && a->ids && a->table && a->pos && a->out, "fyc_embed_tokens: null pointer");
+  FYC_REQUIRE(a->rows > 0 && a->seq > 0 && a->vocab > 0 && a->C > 0 && a->C % 8 == 0, "fyc_embed_tokens: bad dims rows=%lld seq=%d C=%d", (long long)a->rows, a->seq, a->C);
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = a->rows * (a->C / 8);
+  FYC_DT(a,
+         hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const long long*)a->ids, a->table, a->pos, (bf16_t*)a->out, (long long)a->rows, a->seq, a->C, a->vocab),
+         hipLaunchKernelGGL(embed_tokens_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const long long*)a->ids, a->table, a->pos, (float*)a->out, (long long)a->rows, a->seq, a->C, a->vocab));
+  FYC_CHECK_LAUNCH("fyc_embed_tokens");
+  return 0;
+}
+
+extern "C" int fyc_patchify(const fyc_patchify_args* a, void* stream) {
+  FYC_REQUIRE(a && a->image && a->out, "fyc_patchify: null pointer");
+  FYC_REQUIRE(a->B > 0 && a->Cin > 0 && a->P > 0 && a->H > 0 && a->W > 0 && a->H % a->P == 0 && a->W % a->P == 0,
+              "fyc_patchify: image %dx%d is not a multiple of the patch size %d", a->H, a->W, a->P);
+  FYC_REQUIRE(a->ld >= a->Cin * a->P * a->P, "fyc_patchify: ld=%d < Cin*P*P", a->ld);
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)a->B * (a->H / a->P) * (a->W / a->P) * a->ld;
+  FYC_DT(a,
+         hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->image, (bf16_t*)a->out, a->B, a->Cin, a->H, a->W, a->P, a->ld),
+         hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->image, (float*)a->out, a->B, a->Cin, a->H, a->W, a->P, a->ld));
+  FYC_CHECK_LAUNCH("fyc_patchify");
   return 0;
 }

@@ -35,6 +35,8 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   FYC_REQUIRE(a->dtype == FYC_F32 || a->dtype == FYC_BF16, "fyc_gemm: bad dtype %d", a->dtype);
   const int es = a->dtype == FYC_BF16 ? 2 : 4, ch = 16 / es;
   FYC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "fyc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+  FYC_REQUIRE(a->act >= FYC_ACT_NONE && a->act <= FYC_ACT_QUICK_GELU && (a->act == FYC_ACT_NONE || a->epilogue == FYC_EPI_LINEAR),
+              "fyc_gemm: act=%d needs the LINEAR epilogue", a->act);
   FYC_REQUIRE(a->K % ch == 0, "fyc_gemm: K=%d must be a multiple of %d", a->K, ch);
   FYC_REQUIRE(a->ldw % ch == 0 && a->stride_w % ch == 0, "fyc_gemm: ldw/stride_w must keep 16-B alignment");
   FYC_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0, "fyc_gemm: operands must be 16-B aligned");
@@ -50,6 +52,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
   p.ldrb = a->ldrb > 0 ? a->ldrb : a->N;
   p.out_scale = a->out_scale;
+  p.act = a->act;
   p.zero = (const char*)g_fyc_zero_page;
   const int batch = a->batch > 0 ? a->batch : 1;
   if (a->mode == FYC_GEMM_PLAIN) {
@@ -110,6 +113,10 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, (p.N % 128 == 0) ? 1 : 2, st);
   int cfg = 1, ns = 2;
   choose(p, batch, a->tile, cfg, ns);
+  if (p.act != FYC_ACT_NONE) {
+    FYC_REQUIRE(a->mode == FYC_GEMM_PLAIN, "fyc_gemm: act needs the PLAIN mode");
+    return fycg::run_bf16_act(p, batch, cfg, st);
+  }
   if (a->mode == FYC_GEMM_PLAIN) return fycg::run_bf16_plain(p, batch, cfg, ns, st);
   return fycg::run_bf16_conv(p, batch, cfg, ns, st);
 }

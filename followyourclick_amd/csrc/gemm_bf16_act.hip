@@ -1,0 +1,10 @@
+// bf16 plain GEMM with a pointwise activation in the epilogue (conditioning encoders: CLIP MLPs, Resampler feed-forward).
+// Off the denoising hot path, so only three tile shapes are built.
+#include "gemm_kernel.h"
+namespace fycg {
+int run_bf16_act(const GemmP& p, int batch, int cfg, hipStream_t st) {
+  if (cfg == 6 || cfg == 5) return launch<bf16_t, 128, 320, 2, 4, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2>(p, batch, st);
+  if (cfg == 1 || cfg == 3 || cfg == 7) return launch<bf16_t, 128, 128, 2, 2, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2>(p, batch, st);
+  return launch<bf16_t, 128, 64, 2, 2, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2>(p, batch, st);
+}
+}  // namespace fycg

@@ -9,6 +9,7 @@ static int run_tile(const GemmP& p, int batch, int cfg, hipStream_t st) {
 int run_f32(const GemmP& p, int batch, int cfg, hipStream_t st) {
   if (p.mode == FYC_GEMM_CONV3X3) return run_tile<FYC_GEMM_CONV3X3, FYC_EPI_LINEAR>(p, batch, cfg, st);
   if (p.mode == FYC_GEMM_CONV3X3_UP2) return run_tile<FYC_GEMM_CONV3X3_UP2, FYC_EPI_LINEAR>(p, batch, cfg, st);
+  if (p.epilogue == FYC_EPI_LINEAR && p.act != FYC_ACT_NONE) return run_tile<FYC_GEMM_PLAIN, EPI_LINEAR_ACT>(p, batch, cfg, st);
   switch (p.epilogue) {
     case FYC_EPI_LINEAR: return run_tile<FYC_GEMM_PLAIN, FYC_EPI_LINEAR>(p, batch, cfg, st);
     case FYC_EPI_GEGLU: return run_tile<FYC_GEMM_PLAIN, FYC_EPI_GEGLU>(p, batch, cfg, st);

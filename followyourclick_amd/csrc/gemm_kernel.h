@@ -37,6 +37,7 @@ struct GemmP {
   int Hout, Wout, Hin, Win, Cin, conv_stride, conv_pad;
   int rows_per_batch, seg_cols, heads, tokens, head_dim;
   float out_scale;
+  int act;    // FYC_ACT_* (LINEAR epilogue)
   int tiles_m, tiles_n;
   int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
@@ -65,6 +66,14 @@ template <> struct Mma<float> {
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// internal epilogue id: LINEAR with the pointwise activation p.act compiled in.  A separate instantiation so that the
+// hot-path LINEAR kernels do not carry the GELU code (it costs the 256x320 tile 80 B/lane of scratch).
+constexpr int EPI_LINEAR_ACT = 3;
+
+__device__ __forceinline__ float activate(float x, int act) {
+  return act == FYC_ACT_GELU ? gelu_erf_f(x) : x / (1.0f + __expf(-1.702f * x));
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -328,6 +337,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
                 v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
               }
             }
+            if (EPI == EPI_LINEAR_ACT) { v[0] = activate(v[0], p.act); v[1] = activate(v[1], p.act); v[2] = activate(v[2], p.act); v[3] = activate(v[3], p.act); }
           }
           *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
         }
@@ -401,7 +411,11 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (full || n + r < p.N) v[r] += rb[n + r];
         }
-        if (EPI == FYC_EPI_LINEAR) {
+        if (EPI == FYC_EPI_LINEAR || EPI == EPI_LINEAR_ACT) {
+          if (EPI == EPI_LINEAR_ACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
+          }
           if (R) {
             if (full) {
               float rr[4];
@@ -508,6 +522,7 @@ int dispatch_ns(int ns, int cfg, const GemmP& p, int batch, hipStream_t st) {
 // one translation unit per (dtype, family) keeps the build parallel
 int run_bf16_plain(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
 int run_bf16_conv(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
+int run_bf16_act(const GemmP& p, int batch, int cfg, hipStream_t st);   // LINEAR + activation: tile configs 1, 2, 6
 int run_f32(const GemmP& p, int batch, int cfg, hipStream_t st);
 
 }  // namespace fycg

@@ -173,10 +173,13 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
 
 // ---- row softmax in place: one block per row -------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) softmax_rows_kernel(T* __restrict__ x, int cols, int ld) {
+__global__ void __launch_bounds__(256) softmax_rows_kernel(T* __restrict__ x, int cols_all, int ld, int causal_rows) {
   __shared__ float red[8];
   T* xr = x + (long long)blockIdx.x * ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // causal: query i = row % causal_rows attends to keys 0..i; masked probabilities are written as exact zeros
+  const int cols = causal_rows > 0 ? min(cols_all, (int)(blockIdx.x % (unsigned)causal_rows) + 1) : cols_all;
+  for (int c = cols + tid; c < cols_all; c += 256) ElemIO<T>::st(xr + c, 0.f);
   float m = -INFINITY;
   for (int c = tid; c < cols; c += 256) m = fmaxf(m, ElemIO<T>::ld(xr + c));
   m = wave_max(m);
@@ -261,12 +264,12 @@ extern "C" int fyc_layernorm(const fyc_layernorm_args* a, void* stream) {
 
 extern "C" int fyc_softmax_rows(const fyc_softmax_args* a, void* stream) {
   FYC_REQUIRE(a && a->x && a->rows > 0 && a->cols > 0 && a->ld >= a->cols, "fyc_softmax_rows: bad args");
-  FYC_REQUIRE(a->rows < (1ll << 31), "fyc_softmax_rows: too many rows");
+  FYC_REQUIRE(a->rows < (1ll << 31) && a->causal_rows >= 0, "fyc_softmax_rows: too many rows / negative causal_rows");
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == FYC_BF16)
-    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)a->rows), dim3(256), 0, st, (bf16_t*)a->x, a->cols, a->ld);
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)a->rows), dim3(256), 0, st, (bf16_t*)a->x, a->cols, a->ld, a->causal_rows);
   else if (a->dtype == FYC_F32)
-    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)a->rows), dim3(256), 0, st, (float*)a->x, a->cols, a->ld);
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)a->rows), dim3(256), 0, st, (float*)a->x, a->cols, a->ld, a->causal_rows);
   else FYC_FAIL(-2, "fyc_softmax_rows: bad dtype");
   FYC_CHECK_LAUNCH("fyc_softmax_rows");
   return 0;

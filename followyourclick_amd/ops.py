@@ -81,7 +81,7 @@ class HipOps:
              residual: Optional[Tensor] = None, ldr: int = 0, ldrb: int = 0, out_scale: float = 1.0, epilogue: int = L.EPI_LINEAR,
              mode: int = L.GEMM_PLAIN, conv: Optional[dict] = None, batch: int = 1, stride_a: int = 0,
              stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None, tile: int = 0,
-             a2: Optional[Tensor] = None, k_split: int = 0, lda2: int = 0) -> None:
+             a2: Optional[Tensor] = None, k_split: int = 0, lda2: int = 0, act: int = L.ACT_NONE) -> None:
         self.ensure_init(a.device)
         g = L.GemmArgs()
         g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
@@ -89,7 +89,7 @@ class HipOps:
         g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldr, g.ldrb = M, N, K, lda, ldw, ldo, ldr, ldrb
         g.stride_a, g.stride_w, g.stride_o, g.batch = stride_a, stride_w, stride_o, batch
         g.mode, g.epilogue, g.rows_per_batch, g.out_scale, g.dtype = mode, epilogue, rows_per_batch, out_scale, _dt(a)
-        g.tile = tile
+        g.tile, g.act = tile, act
         g.a2, g.k_split, g.lda2 = _p(a2), k_split, lda2
         if a.dtype != w.dtype:
             raise TypeError(f"gemm: activation {a.dtype} vs weight {w.dtype}")
@@ -144,9 +144,9 @@ class HipOps:
         a.rows, a.C, a.eps, a.pe_div, a.pe_rows, a.dtype = rows, C_, eps, pe_div, pe_rows, _dt(x)
         self._call("fyc_layernorm", a)
 
-    def softmax_rows(self, x: Tensor, *, rows: int, cols: int, ld: int) -> None:
+    def softmax_rows(self, x: Tensor, *, rows: int, cols: int, ld: int, causal_rows: int = 0) -> None:
         a = L.SoftmaxArgs()
-        a.x, a.rows, a.cols, a.ld, a.dtype = _p(x), rows, cols, ld, _dt(x)
+        a.x, a.rows, a.cols, a.ld, a.dtype, a.causal_rows = _p(x), rows, cols, ld, _dt(x), causal_rows
         self._call("fyc_softmax_rows", a)
 
     # -- elementwise / layout ------------------------------------------------------------------
@@ -154,6 +154,21 @@ class HipOps:
         a = L.ConcatArgs()
         a.a, a.b, a.y, a.rows, a.c1, a.c2, a.dtype = _p(a_), _p(b_), _p(y), rows, c1, c2, _dt(a_)
         self._call("fyc_concat_channels", a)
+
+    def embed_tokens(self, ids: Tensor, table: Tensor, pos: Tensor, out: Tensor, *, rows: int, seq: int, C_: int) -> None:
+        if ids.dtype != torch.int64 or table.dtype != torch.float32 or pos.dtype != torch.float32:
+            raise TypeError("embed_tokens: ids must be int64, tables float32")
+        a = L.EmbedArgs()
+        a.ids, a.table, a.pos, a.out = _p(ids), _p(table), _p(pos), _p(out)
+        a.rows, a.seq, a.C, a.vocab, a.dtype = rows, seq, C_, table.shape[0], _dt(out)
+        self._call("fyc_embed_tokens", a)
+
+    def patchify(self, image: Tensor, out: Tensor, *, B: int, Cin: int, H: int, W: int, P: int, ld: int) -> None:
+        if image.dtype != torch.float32:
+            raise TypeError("patchify: image must be float32 NCHW")
+        a = L.PatchifyArgs()
+        a.image, a.out, a.B, a.Cin, a.H, a.W, a.P, a.ld, a.dtype = _p(image), _p(out), B, Cin, H, W, P, ld, _dt(out)
+        self._call("fyc_patchify", a)
 
     def silu_f32(self, x: Tensor, y: Tensor) -> None:
         a = L.SiluArgs()

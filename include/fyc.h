@@ -54,6 +54,9 @@ int fyc_set_tuning(int key, int value);
  * any Hout >= Hin works (Upsample3D with a forwarded `upsample_size`, reference resnet.py:152-157, unet.py:644-645) */
 enum { FYC_GEMM_PLAIN = 0, FYC_GEMM_CONV3X3 = 1, FYC_GEMM_CONV3X3_UP2 = 2 };
 enum { FYC_EPI_LINEAR = 0, FYC_EPI_GEGLU = 1, FYC_EPI_HEADS = 2 };
+/* pointwise activation of the LINEAR epilogue (conditioning encoders): exact erf GELU (CLIP-ViT-H `gelu`, ip_adapter/resampler.py:17)
+ * and x*sigmoid(1.702x) (CLIP-ViT-L text encoder `quick_gelu`) */
+enum { FYC_ACT_NONE = 0, FYC_ACT_GELU = 1, FYC_ACT_QUICK_GELU = 2 };
 
 typedef struct {
   const void* a;         /* PLAIN: [batch][M][lda]; CONV: NHWC input [frames][Hin][Win][Cin] */
@@ -81,6 +84,7 @@ typedef struct {
   float out_scale;
   int32_t dtype;
   int32_t tile;          /* 0 = automatic; else tile config id | ring depth << 8 (see fyc_set_tuning) */
+  int32_t act;           /* LINEAR epilogue only: FYC_ACT_* applied to (acc + bias + rowbias) before residual / out_scale */
 } fyc_gemm_args;
 int fyc_gemm(const fyc_gemm_args* a, void* stream);
 
@@ -152,8 +156,10 @@ typedef struct {
 } fyc_layernorm_args;
 int fyc_layernorm(const fyc_layernorm_args* a, void* stream);
 
-/* row softmax (in place, f32 math): x [rows][ld], first `cols` columns (materialised attention) */
-typedef struct { void* x; int64_t rows; int32_t cols, ld; int32_t dtype; } fyc_softmax_args;
+/* row softmax (in place, f32 math): x [rows][ld], first `cols` columns (materialised attention).
+ * causal_rows = n > 0: row r belongs to query (r % n) and only columns <= r % n take part, the rest become 0
+ * (CLIP text encoder's causal mask, transformers CLIPTextTransformer) */
+typedef struct { void* x; int64_t rows; int32_t cols, ld; int32_t dtype; int32_t causal_rows; } fyc_softmax_args;
 int fyc_softmax_rows(const fyc_softmax_args* a, void* stream);
 
 /* ---- elementwise / layout ---------------------------------------------------------------- */
@@ -200,6 +206,18 @@ typedef struct { const float* z; void* x; int32_t N, C, HW, c_pad; float scale; 
 int fyc_nchw_to_nhwc(const fyc_nchw_in_args* a, void* stream);
 typedef struct { const void* x; float* y; int32_t N, C, HW, ld; float mul, add, lo, hi; int32_t dtype; } fyc_nhwc_out_args;
 int fyc_nhwc_to_nchw(const fyc_nhwc_out_args* a, void* stream);
+
+/* ---- conditioning encoders: CLIP text / vision front-ends ------------------------------------------
+ * out[r][:] = table[ids[r]][:] + pos[r % seq][:]   (transformers CLIPTextEmbeddings.forward: token + position embedding;
+ * called from the reference at pipeline_animation.py:183-186).  Tables f32 [vocab][C] / [seq][C]; ids int64; out [rows][C]. */
+typedef struct { const int64_t* ids; const float* table; const float* pos; void* out; int64_t rows; int32_t seq, C, vocab; int32_t dtype; } fyc_embed_args;
+int fyc_embed_tokens(const fyc_embed_args* a, void* stream);
+
+/* Non-overlapping patch unfold (the im2col of CLIPVisionEmbeddings' Conv2d(3, C, kernel=stride=P, bias=False); reference
+ * ip_adapter/my_ip_adapter.py:132, 280-283 calls the vision tower): image (B,Cin,H,W) f32 NCHW ->
+ * out [B*(H/P)*(W/P)][ld], column c*P*P + py*P + px (= the flattened conv weight's K order), columns >= Cin*P*P zero. */
+typedef struct { const float* image; void* out; int32_t B, Cin, H, W, P, ld; int32_t dtype; } fyc_patchify_args;
+int fyc_patchify(const fyc_patchify_args* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ class EmuOps:
     # ------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
              ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
-             heads=None, tile=0, a2=None, k_split=0, lda2=0):
+             heads=None, tile=0, a2=None, k_split=0, lda2=0, act=0):
         acc_t = self.acc
         af, wf = _flat(a), _flat(w)
         for z in range(batch):
@@ -81,6 +81,10 @@ class EmuOps:
                 o = _strided(_flat(out), (M, N // 2), (ldo, 1), z * stride_o)
                 o.copy_(y.to(out.dtype))
             elif epilogue == LINEAR:
+                if act == 1:
+                    acc = F.gelu(acc)
+                elif act == 2:
+                    acc = acc * torch.sigmoid(1.702 * acc)
                 if residual is not None:
                     acc = acc + _strided(_flat(residual), (M, N), (ldr, 1), 0).to(acc_t)
                 acc = acc * out_scale
@@ -160,9 +164,24 @@ class EmuOps:
             yv = yv + pe.reshape(-1, C_)[idx].float()
         _flat(y)[: rows * C_].reshape(rows, C_).copy_(yv.to(y.dtype))
 
-    def softmax_rows(self, x, *, rows, cols, ld):
+    def softmax_rows(self, x, *, rows, cols, ld, causal_rows=0):
         v = _strided(_flat(x), (rows, cols), (ld, 1), 0)
-        v.copy_(v.float().softmax(dim=-1).to(x.dtype))
+        s = v.float()
+        if causal_rows > 0:
+            q = (torch.arange(rows) % causal_rows)[:, None]
+            s = s.masked_fill(torch.arange(cols)[None, :] > q, float("-inf"))
+        v.copy_(s.softmax(dim=-1).to(x.dtype))
+
+    def embed_tokens(self, ids, table, pos, out, *, rows, seq, C_):
+        pidx = torch.arange(rows) % seq
+        _flat(out)[: rows * C_].reshape(rows, C_).copy_((table[ids.reshape(-1)[:rows]] + pos[pidx]).to(out.dtype))
+
+    def patchify(self, image, out, *, B, Cin, H, W, P, ld):
+        gh, gw = H // P, W // P
+        cols = image.reshape(B, Cin, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, Cin * P * P)
+        v = _flat(out)[: B * gh * gw * ld].reshape(B * gh * gw, ld)
+        v.zero_()
+        v[:, : Cin * P * P].copy_(cols.to(out.dtype))
 
     # ------------------------------------------------------------------------------------
     def concat_channels(self, a_, b_, y, *, rows, c1, c2):

@@ -347,3 +347,63 @@ def test_missing_device_tensor_raises(hip):
     from followyourclick_amd._lib import FycError
     with pytest.raises(FycError):
         hip.silu_f32(torch.zeros(4), torch.zeros(4))
+
+
+# ---- conditioning-encoder ops ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(154, 3072, 768), (514, 320, 1280), (32, 64, 64), (77, 264, 72)])
+def test_gemm_activation(hip, emu, dt, act, M, N, K):
+    """LINEAR epilogue with erf-GELU / quick-GELU (CLIP MLP fc1, Resampler FF): act(a w^T + bias), then residual, then scale"""
+    T = DT[dt]
+    a, w = rnd((M, K), T, 1), rnd((N, K), T, 2, 2 / math.sqrt(K))
+    bias, res = rnd((N,), torch.float32, 3), rnd((M, N), T, 4)
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, out_scale=1.0, act=act)
+    o_h = torch.full((M, N), float("nan"), dtype=T, device="cuda")
+    hip.gemm(a.cuda(), w.cuda(), o_h, bias=bias.cuda(), residual=res.cuda(), **kw)
+    o_e = torch.zeros(M, N, dtype=T)
+    emu.gemm(a, w, o_e, bias=bias, residual=res, **kw)
+    close(o_h, o_e, f"gemm act={act} {dt} {M}x{N}x{K}", RTOL[dt])
+    with pytest.raises(Exception, match="LINEAR"):
+        hip.gemm(a.cuda(), w.cuda(), o_h, M=M, N=N - N % 32, K=K, lda=K, ldw=K, ldo=N, epilogue=1, act=act)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_softmax_rows_causal(hip, emu, dt):
+    T = DT[dt]
+    heads, n, ld = 3, 77, 80
+    x = rnd((heads * n, ld), T, 11, 3.0)
+    xh = x.clone().cuda()
+    hip.softmax_rows(xh, rows=heads * n, cols=n, ld=ld, causal_rows=n)
+    xe = x.clone()
+    emu.softmax_rows(xe, rows=heads * n, cols=n, ld=ld, causal_rows=n)
+    close(xh[:, :n], xe[:, :n], f"causal softmax {dt}", RTOL[dt])
+    assert float(xh[0, 1:n].float().abs().sum()) == 0.0 and abs(float(xh[0, 0]) - 1.0) < 1e-6      # first query sees only itself
+    assert torch.equal(xh[:, n:].cpu(), x[:, n:])                                                    # padding columns untouched
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_embed_tokens_and_patchify(hip, emu, dt):
+    T = DT[dt]
+    vocab, seq, C, B = 1000, 77, 768, 2
+    table, pos = rnd((vocab, C), torch.float32, 1), rnd((seq, C), torch.float32, 2)
+    ids = torch.randint(0, vocab, (B, seq), generator=torch.Generator().manual_seed(3))
+    ids[0, 0], ids[1, -1] = 0, vocab - 1
+    o_h = torch.empty(B * seq, C, dtype=T, device="cuda")
+    hip.embed_tokens(ids.cuda(), table.cuda(), pos.cuda(), o_h, rows=B * seq, seq=seq, C_=C)
+    o_e = torch.empty(B * seq, C, dtype=T)
+    emu.embed_tokens(ids, table, pos, o_e, rows=B * seq, seq=seq, C_=C)
+    assert torch.equal(o_h.cpu(), o_e)                              # one rounding of an f32 sum: bit-exact
+    img = rnd((B, 3, 28, 42), torch.float32, 5)
+    P, ld = 14, 592
+    p_h = torch.full((B * 2 * 3, ld), float("nan"), dtype=T, device="cuda")
+    hip.patchify(img.cuda(), p_h, B=B, Cin=3, H=28, W=42, P=P, ld=ld)
+    p_e = torch.empty(B * 2 * 3, ld, dtype=T)
+    emu.patchify(img, p_e, B=B, Cin=3, H=28, W=42, P=P, ld=ld)
+    assert torch.equal(p_h.cpu(), p_e)
+    # unfold + GEMM == the strided convolution it replaces
+    w = rnd((32, 3, P, P), torch.float32, 6)
+    ref = torch.nn.functional.conv2d(img, w, stride=P).permute(0, 2, 3, 1).reshape(-1, 32)
+    assert torch.allclose(p_e.float()[:, :588] @ w.reshape(32, -1).t(), ref, atol=2e-1 if dt == "bf16" else 1e-4)
+    with pytest.raises(Exception, match="patch size"):
+        hip.patchify(img.cuda(), p_h, B=B, Cin=3, H=28, W=42, P=16, ld=1024)
