@@ -1,5 +1,6 @@
-"""Drop-in `ip_adapter` package: the attention-processor API surface on the MI355X attention kernels.
-(MyIPAdapter / MyIPAdapterPlus, i.e. the CLIP-vision front-end, are the conditioning "next" row of
-SURVEY.md 8f and are not part of this package yet.)"""
+"""Drop-in `ip_adapter` package on the MI355X engine: the attention-processor API, the image-projection models and the
+MyIPAdapter / MyIPAdapterPlus front-ends (CLIP vision tower + projection as HIP op schedules)."""
 from .attention_processor import (AttnProcessor, AttnProcessor2_0, CNAttnProcessor, CNAttnProcessor2_0,  # noqa: F401
                                   IPAttnProcessor, IPAttnProcessor2_0)
+from .my_ip_adapter import ImageProjModel, MyIPAdapter, MyIPAdapterPlus  # noqa: F401
+from .resampler import Resampler  # noqa: F401

@@ -194,3 +194,52 @@ def test_sd_pipeline_surface(dropin, tmp_path):
         pipe("x", height=64, width=64, latents=torch.zeros(1, 4, 4, 4))
     with pytest.raises(NotImplementedError):
         StableDiffusionPipeline(vae, stubs.StubTextEncoder(64), stubs.FakeTokenizer(), unet, sch, safety_checker=object())
+
+
+# ---- conditioning front-end: ip_adapter.{Resampler, ImageProjModel, MyIPAdapter[Plus]}, CLIP fronts -------------
+def test_ip_adapter_modules_surface(dropin, golden_dir, tmp_path):
+    import ip_adapter
+    from ip_adapter.my_ip_adapter import ImageProjModel, MyIPAdapter, MyIPAdapterPlus
+    from ip_adapter.resampler import Resampler
+    from oracle import encoders as E
+    assert ip_adapter.Resampler is Resampler and ip_adapter.MyIPAdapterPlus is MyIPAdapterPlus
+    rc = E.TINY_RESAMPLER
+    res = Resampler(dim=rc.dim, depth=rc.depth, dim_head=rc.dim_head, heads=rc.heads, num_queries=rc.num_queries,
+                    embedding_dim=rc.embedding_dim, output_dim=rc.output_dim, ff_mult=rc.ff_mult)
+    # these shape tables were loaded with strict=True into the REAL reference classes by oracle/make_golden_encoders.py
+    assert {k: tuple(v.shape) for k, v in res.state_dict().items()} == dict(E.resampler_shapes(rc))
+    proj = ImageProjModel(cross_attention_dim=64, clip_embeddings_dim=64, clip_extra_context_tokens=4)
+    assert {k: tuple(v.shape) for k, v in proj.state_dict().items()} == dict(E.image_proj_shapes(64, 64, 4))
+    with pytest.raises(NotImplementedError):
+        Resampler(apply_pos_emb=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        proj(torch.zeros(1, 64))
+    assert list(inspect.signature(MyIPAdapter.__init__).parameters)[1:] == ["unet", "image_encoder_path", "ip_ckpt", "device", "num_tokens"]
+    for name in ("init_proj", "get_ip_adapter_state_dict", "load_ip_adapter", "get_image_clip_feat", "get_image_embeds"):
+        assert callable(getattr(MyIPAdapterPlus, name))
+
+
+def test_load_ip_adapter_state_surgery(dropin, tmp_path):
+    """checkpoint `ip_adapter` tensors are matched in order with the UNet's *_ip* parameters; image_proj goes to the projection"""
+    from animatediff.models.unet import UNet3DConditionModel
+    from followyourclick_amd.encoders import ClipVisionHip
+    from ip_adapter.my_ip_adapter import MyIPAdapter
+    from oracle import encoders as E
+    unet = UNet3DConditionModel(**dict(TINY, use_ip_cross_attention=True, num_tokens=4))
+    vis = ClipVisionHip(E.make_encoder_weights(E.clip_vision_shapes(E.TINY_VISION), 53), vars(E.TINY_VISION))
+    ip_keys = [k for k in unet.state_dict() if "_ip" in k]
+    assert len(ip_keys) == 32                                    # 16 cross-attention layers x (to_k_ip, to_v_ip)
+    ck = {"image_proj": E.make_encoder_weights(E.image_proj_shapes(64, 64, 4), 55),
+          "ip_adapter": {f"{i}.to_{'kv'[i % 2]}_ip.weight": torch.full_like(unet.state_dict()[k], float(i)) for i, k in enumerate(ip_keys)}}
+    path = str(tmp_path / "ip.bin")
+    torch.save(ck, path)
+    ad = MyIPAdapter(unet, vis, path, "cpu", num_tokens=4)
+    missing, unexpected = ad.load_ip_adapter()
+    assert not unexpected
+    sd = unet.state_dict()
+    assert all(float(sd[k].flatten()[0]) == float(i) for i, k in enumerate(ip_keys))
+    assert torch.equal(ad.image_proj_model.state_dict()["proj.weight"], ck["image_proj"]["proj.weight"])
+    # use_unet_image_proj_model=True: the projection weights travel inside the UNet state dict (scripts/inference.py:167-168)
+    unet.image_proj_model = ad.init_proj()
+    ad.load_ip_adapter(unet, use_unet_image_proj_model=True)
+    assert torch.equal(unet.state_dict()["image_proj_model.norm.bias"], ck["image_proj"]["norm.bias"])

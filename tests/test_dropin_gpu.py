@@ -186,3 +186,110 @@ def test_stable_diffusion_pipeline_call(dropin, golden_dir, dtype, tol_lat, tol_
     assert e < tol_img, e
     pil = pipe("a corgi on the beach", height=64, width=64, num_inference_steps=2, latents=g["latents"].clone()).images
     assert len(pil) == 1 and pil[0].size == (64, 64)
+
+
+# ---- conditioning front-end ---------------------------------------------------------------------------------------
+def _vision_model(dtype):
+    from followyourclick_amd.encoders import ClipVisionHip
+    from oracle import encoders as E
+    return ClipVisionHip(E.make_encoder_weights(E.clip_vision_shapes(E.TINY_VISION), 53), vars(E.TINY_VISION), compute_dtype=dtype)
+
+
+class _Unet64:
+    config = type("C", (), {"cross_attention_dim": 64})()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
+def test_my_ip_adapter_front_end(dropin, golden_dir, dtype, tol):
+    """MyIPAdapter.get_image_clip_feat / get_image_embeds == transformers CLIP vision + the reference's ImageProjModel"""
+    from ip_adapter.my_ip_adapter import MyIPAdapter, MyIPAdapterPlus
+    from oracle import encoders as E
+    gv, gi = _load(golden_dir, "enc_clip_vision.npz"), _load(golden_dir, "enc_ip_adapter.npz")
+    ad = MyIPAdapter(_Unet64(), _vision_model(dtype), None, "cuda", num_tokens=4)
+    ad.image_proj_model.compute_dtype = dtype
+    ad.image_proj_model.load_state_dict(E.make_encoder_weights(E.image_proj_shapes(64, 64, 4), int(gi["proj_seed"])))
+    cond, uncond = ad.get_image_clip_feat(gv["pixel_values"])
+    assert cond.shape == gv["image_embeds"].shape and float(uncond.abs().sum()) == 0.0
+    rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()
+    assert rel(cond, gv["image_embeds"]) < tol
+    tok, utok = ad.get_image_embeds(clip_image_embeds=gi["image_embeds"])
+    assert rel(tok, gi["proj_tokens"]) < tol and rel(utok, gi["proj_tokens_uncond"]) < tol
+    # Plus: penultimate hidden states of the image and of an all-zero image, then the Resampler (depth 4, 12 heads x 64)
+    plus = MyIPAdapterPlus(_Unet64(), _vision_model(dtype), None, "cuda", num_tokens=4)
+    c, u = plus.get_image_clip_feat(gv["pixel_values"])
+    assert rel(c, gv["penultimate"]) < tol
+    sd_v = E.make_encoder_weights(E.clip_vision_shapes(E.TINY_VISION), 53)
+    u_ref = E.clip_vision_forward(sd_v, E.TINY_VISION, torch.zeros_like(gv["pixel_values"]))[0][-2]
+    assert rel(u, u_ref) < tol
+    rcfg = E.ResamplerConfig(dim=64, depth=4, dim_head=64, heads=12, num_queries=4, embedding_dim=128, output_dim=64, ff_mult=4)
+    sd_r = E.make_encoder_weights(E.resampler_shapes(rcfg), 91)
+    plus.image_proj_model.compute_dtype = dtype
+    plus.image_proj_model.load_state_dict(sd_r)
+    toks = plus.image_proj_model(gv["penultimate"].cuda())
+    assert rel(toks, E.resampler_forward(sd_r, rcfg, gv["penultimate"])) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_clip_text_front_in_pipeline(dropin, golden_dir, dtype, tol):
+    """pipeline._encode_prompt with the HIP text encoder == transformers.CLIPTextModel on the same token ids"""
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import AutoencoderKL, DDIMScheduler
+    from followyourclick_amd.encoders import ClipTextHip
+    from oracle import encoders as E
+    g = _load(golden_dir, "enc_clip_text.npz")
+    sd = E.make_encoder_weights(E.clip_text_shapes(E.TINY_TEXT), int(g["weight_seed"]))
+    enc = ClipTextHip({"text_model." + k: v for k, v in sd.items()}, dict(vars(E.TINY_TEXT), eos_token_id=2), compute_dtype=dtype)
+    out = enc.cuda()(g["input_ids"].cuda(), attention_mask=None)
+    assert ((out[0].cpu() - g["last_hidden_state"]).norm() / g["last_hidden_state"].norm()).item() < tol
+    assert out.pooler_output.shape == (2, 64)
+    tok = stubs.FakeTokenizer()
+    pipe = AnimationPipeline(vae=AutoencoderKL(block_out_channels=(64, 128, 128, 128)), text_encoder=enc, tokenizer=tok, unet=None,
+                             scheduler=DDIMScheduler()).to("cuda")
+    emb = pipe._encode_prompt(["a corgi waving its tail"], "cuda", 1, True, ["blurry"])
+    ids = torch.cat([tok(["blurry"], max_length=77).input_ids, tok(["a corgi waving its tail"], max_length=77).input_ids])
+    ref = E.clip_text_forward(sd, E.TINY_TEXT, ids)
+    assert emb.shape == ref.shape and ((emb.cpu() - ref).norm() / ref.norm()).item() < tol
+    with pytest.raises(NotImplementedError):
+        enc(g["input_ids"].cuda(), attention_mask=torch.ones(2, 77))
+
+
+def test_pipeline_with_ip_adapter_end_to_end(dropin, golden_dir):
+    """cfg5-shaped run through the public API only: condition image -> CLIP vision tower -> ImageProjModel -> IP cross-attention
+    UNet -> DDIM loop, all on the engine, against the oracle fed with the same weights (f32 parity mode)."""
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import AutoencoderKL, DDIMScheduler
+    from ip_adapter.my_ip_adapter import MyIPAdapter
+    from oracle import encoders as E
+    gv, g = _load(golden_dir, "enc_clip_vision.npz"), _load(golden_dir, "pipeline_tiny.npz")
+    f32 = torch.float32
+    ocfg = Fn.tiny_unet_config(use_ip_cross_attention=True, ip_scale=0.7, ip_num_tokens=4)
+    sd = W.make_weights(W.unet_state_shapes(ocfg), 5)
+    unet = UNet3DConditionModel(**dict(TINY, use_ip_cross_attention=True, num_tokens=4, scale=0.7), compute_dtype=f32)
+    assert not any(unet.load_state_dict(sd, strict=False))
+    ad = MyIPAdapter(unet, _vision_model(f32), None, "cuda", num_tokens=4)
+    sd_p = E.make_encoder_weights(E.image_proj_shapes(64, 64, 4), 55)
+    ad.image_proj_model.compute_dtype = f32
+    ad.image_proj_model.load_state_dict(sd_p)
+    unet.image_proj_model = ad.image_proj_model                          # scripts/inference.py:167
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4, compute_dtype=f32)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+                          clip_sample=False, prediction_type="v_prediction", rescale_betas_zero_snr=True)
+    pipe = AnimationPipeline(vae=vae, text_encoder=stubs.StubTextEncoder(64), tokenizer=stubs.FakeTokenizer(), unet=unet,
+                             scheduler=sched, ip_adapter=ad).to("cuda")
+    image = gv["pixel_values"][:1]
+    traj = []
+    pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=3, guidance_scale=8.0,
+         negative_prompt="blurry", latents=g["latents"].clone(), first_image_latents=g["first_image_latents"].cuda(),
+         first_images_mask=g["first_images_mask"].cuda(), use_first_frame_mask_condition_concat=True, use_fps_condition=True,
+         fps_tensor=torch.tensor([2]), flow_control=torch.tensor([4]), use_ip_cross_attention=True, condition_images=image,
+         callback=lambda i, t, l: traj.append(l.clone().cpu()), callback_steps=1)
+    # oracle: same text states (the stub encoder is deterministic), image tokens from the restated CLIP tower + projection
+    emb = E.clip_vision_forward(E.make_encoder_weights(E.clip_vision_shapes(E.TINY_VISION), 53), E.TINY_VISION, image)[1]
+    ip_tokens = E.image_proj_forward(sd_p, torch.cat([torch.zeros_like(emb), emb]), 4, 64)
+    ref = []
+    Fn.denoise(sd, ocfg, Fn.DDIMConfig(), g["latents"], g["text_embeddings"], 3, 8.0, g["first_image_latents"], g["first_images_mask"],
+               fps=torch.tensor([2]), flow=torch.tensor([4]), ip_tokens=ip_tokens, callback=lambda i, t, l: ref.append(l.clone()))
+    traj, ref = torch.stack(traj), torch.stack(ref)
+    err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert err.max().item() < 1e-3, err
