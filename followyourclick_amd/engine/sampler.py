@@ -10,6 +10,7 @@ coefficients) is prepared once per clip.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -81,7 +82,12 @@ class DDIMSampler:
     def sample(self, latents: Tensor, text_embeddings: Tensor, num_steps: int, guidance_scale: float,
                first_image_latents: Optional[Tensor] = None, first_images_mask: Optional[Tensor] = None,
                fps: Optional[Sequence[float]] = None, flow: Optional[Sequence[float]] = None,
-               ip_tokens: Optional[Tensor] = None, callback: Optional[Callable] = None, callback_steps: int = 1) -> Tensor:
+               ip_tokens: Optional[Tensor] = None, callback: Optional[Callable] = None, callback_steps: int = 1,
+               use_graph: Optional[bool] = None) -> Tensor:
+        """use_graph: replay steps 1..n-1 from one captured hipGraph (None = the FYC_HIPGRAPH environment switch, default off).
+        Measured on MI355X it buys nothing: at cfg2 the loop is GPU-bound (56 ms of kernels per step) and even the 2-D
+        one-frame case (13.7 ms / step, ~700 small kernels) is bound by the kernels' own execution, not by launch overhead
+        (profiles/r01_front_end_rows.json).  Kept as an option for hosts with slow Python."""
         u = self.unet
         latents = latents.to(device=u.device, dtype=torch.float32).contiguous().clone()
         B, CL, F, H, W = latents.shape
@@ -91,8 +97,31 @@ class DDIMSampler:
             # mask for ALL frames = clamp(first_images_mask[:, :, 0:1]) (reference :632-635)
             mask = first_images_mask.to(u.device, torch.float32)[:, :, 0].reshape(B, 1, H * W).contiguous()
         st = self.prepare(text_embeddings, num_steps, B, guidance_scale, fps, flow, ip_tokens)
-        for i, t in enumerate(st["timesteps"].tolist()):
-            self.step(st, i, latents, first, mask)
+        ts = st["timesteps"].tolist()
+        if use_graph is None:
+            use_graph = os.environ.get("FYC_HIPGRAPH", "0") == "1"
+        if not (use_graph and latents.is_cuda and num_steps >= 3):
+            for i, t in enumerate(ts):
+                self.step(st, i, latents, first, mask)
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, latents)
+            return latents
+        # Step 0 runs eagerly (it is also the warm-up: lazily set kernel attributes, allocator pools); step 1 is captured
+        # reading its time-embedding row and DDIM coefficients from two fixed buffers, which are refreshed before every replay.
+        self.step(st, 0, latents, first, mask)
+        if callback is not None:
+            callback(0, ts[0], latents)
+        temb_cur, coef_cur = torch.empty_like(st["temb"][0]), torch.empty_like(st["coef"][0])
+        gst = dict(st, temb=temb_cur[None], coef=coef_cur[None])
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=u.device)
+        side.wait_stream(torch.cuda.current_stream(u.device))
+        with torch.cuda.graph(graph, stream=side):
+            self.step(gst, 0, latents, first, mask)
+        for i in range(1, num_steps):
+            temb_cur.copy_(st["temb"][i])
+            coef_cur.copy_(st["coef"][i])
+            graph.replay()
             if callback is not None and i % callback_steps == 0:
-                callback(i, t, latents)
+                callback(i, ts[i], latents)
         return latents
