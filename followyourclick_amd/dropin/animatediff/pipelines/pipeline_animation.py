@@ -4,7 +4,10 @@ Same constructor, attributes, `__call__` signature, error behaviour and output t
 (reference animatediff/pipelines/pipeline_animation.py:41-130, 400-445, 546-788), so
 `scripts/inference*.py` can drive it unchanged.  What differs is where the work happens:
 
-  * prompt encoding stays with the caller's tokenizer / text encoder (conditioning front-end);
+  * two conditioning modes: the FollowYourClick one (`use_first_frame_mask_condition_concat=True`: 9-channel input of latents,
+    click mask and first-frame latents, scripts/inference.py:374-395) and plain text-to-video on a 4-channel UNet (how
+    scripts/inference_org.py:265-289 / animate.py call it);
+  * prompt encoding stays with the caller's tokenizer / text encoder (or followyourclick_amd.encoders.ClipTextHip);
   * the DDIM loop does not go module-by-module through torch: per step it is ONE input-assembly kernel,
     the engine's UNet3D op schedule on the CFG pair, and ONE fused guidance + DDIM-update kernel; all
     text/IP K,V projections, time embeddings and scheduler coefficients are prepared once per clip;
@@ -173,9 +176,11 @@ class AnimationPipeline:
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"AnimationPipeline on the MI355X engine: {bad} not implemented (SURVEY.md 8 scope)")
-        if not use_first_frame_mask_condition_concat:
-            raise NotImplementedError("only use_first_frame_mask_condition_concat=True (the FollowYourClick path) is implemented")
-        if first_image_latents is None:
+        concat_model = bool(getattr(self.unet.engine_config, "use_first_frame_mask_condition_concat", False))
+        if use_first_frame_mask_condition_concat != concat_model:
+            raise ValueError(f"use_first_frame_mask_condition_concat={use_first_frame_mask_condition_concat} but the UNet was built "
+                             f"with use_first_frame_mask_condition_concat={concat_model} ({self.unet.engine_config.conv_in_channels} input channels)")
+        if use_first_frame_mask_condition_concat and first_image_latents is None:
             raise ValueError("first_image_latents is required with use_first_frame_mask_condition_concat")
 
         batch_size = 1

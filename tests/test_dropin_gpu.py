@@ -293,3 +293,29 @@ def test_pipeline_with_ip_adapter_end_to_end(dropin, golden_dir):
     traj, ref = torch.stack(traj), torch.stack(ref)
     err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
     assert err.max().item() < 1e-3, err
+
+
+@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1.5e-1, 1e-1)])
+def test_animation_pipeline_plain_text_to_video(dropin, golden_dir, dtype, tol_lat, tol_vid):
+    """the call scripts/inference_org.py makes: no concat conditioning, 4-channel UNet3D with motion modules"""
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import AutoencoderKL, DDIMScheduler
+    g = _load(golden_dir, "pipeline_tiny_t2v.npz")
+    kw = dict(TINY, use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+    unet = UNet3DConditionModel(**kw, compute_dtype=dtype)
+    ocfg = Fn.tiny_unet_config(use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+    assert not any(unet.load_state_dict(W.make_weights(W.unet_state_shapes(ocfg), int(g["unet_weight_seed"])), strict=False))
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4, compute_dtype=dtype)
+    vae.load_state_dict(W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["vae_weight_seed"])), strict=False)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1, clip_sample=False)
+    pipe = AnimationPipeline(vae=vae, text_encoder=stubs.StubTextEncoder(64), tokenizer=stubs.FakeTokenizer(), unet=unet, scheduler=sched).to("cuda")
+    traj = []
+    out = pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=4, guidance_scale=7.5,
+               negative_prompt="blurry", latents=g["latents"].clone(), callback=lambda i, t, l: traj.append(l.clone().cpu()), callback_steps=1)
+    traj = torch.stack(traj)
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < tol_lat, err
+    assert ((out.videos - g["videos"]).norm() / g["videos"].norm()).item() < tol_vid
+    with pytest.raises(ValueError, match="built"):
+        pipe("x", video_length=4, height=64, width=64, use_first_frame_mask_condition_concat=True, first_image_latents=torch.zeros(1, 4, 8, 8))

@@ -189,3 +189,17 @@ def test_sampler_plain_latents_matches_reference_sd_pipeline(golden_dir):
     vae = VAEDecoderEngine(pack_vae_decoder(sdv, vcfg, torch.float32, "cpu"), ops=EmuOps())
     img = vae.decode_video(lat)[:, :, 0].permute(0, 2, 3, 1)
     assert (img - g["images"]).abs().max().item() < 2e-3
+
+
+def test_sampler_plain_text_to_video_matches_reference_pipeline(golden_dir):
+    g = _load(golden_dir, "pipeline_tiny_t2v.npz")
+    ocfg = Fn.tiny_unet_config(use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+    sd = W.make_weights(W.unet_state_shapes(ocfg), int(g["unet_weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(use_fps_condition=False, use_first_frame_mask_condition_concat=False), torch.float32, "cpu"),
+                       ops=EmuOps())
+    traj = []
+    DDIMSampler(eng, DDIMConfig(prediction_type="epsilon", rescale_betas_zero_snr=False)).sample(
+        g["latents"], g["text_embeddings"], 4, 7.5, callback=lambda i, t, l: traj.append(l.clone()))
+    traj = torch.stack(traj)
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < 5e-4, err

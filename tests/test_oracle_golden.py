@@ -156,9 +156,23 @@ def test_sd2d_pipeline_trajectory(golden_dir):
     traj = []
     lat = Fn.denoise(sd, cfg, sched, g["latents"][:, :, None], g["text_embeddings"], 4, 8.0,
                      callback=lambda i, t, l: traj.append(l[:, :, 0].clone()))
-    traj = torch.stack(traj)
-    assert torch.allclose(traj, g["trajectory"], atol=5e-5, rtol=1e-4), (traj - g["trajectory"]).abs().max()
+    traj = torch.stack(traj)          # random weights + epsilon prediction: latents grow to |x| ~ 20, so compare relatively
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < 2e-5, err
     vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))
     sdv = W.make_weights(W.vae_decoder_state_shapes(vcfg), int(g["vae_weight_seed"]))
     img = (Fn.vae_decode(sdv, vcfg, lat[:, :, 0] / 0.18215) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
     assert torch.allclose(img, g["images"], atol=2e-5), (img - g["images"]).abs().max()
+
+
+def test_pipeline_trajectory_plain_text_to_video(golden_dir):
+    """AnimationPipeline without the concat conditioning (scripts/inference_org.py mode): 4-channel UNet3D, epsilon prediction"""
+    g = _load(golden_dir, "pipeline_tiny_t2v.npz")
+    cfg = Fn.tiny_unet_config(use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["unet_weight_seed"]))
+    sched = Fn.DDIMConfig(prediction_type="epsilon", rescale_betas_zero_snr=False)
+    traj = []
+    Fn.denoise(sd, cfg, sched, g["latents"], g["text_embeddings"], 4, 7.5, callback=lambda i, t, l: traj.append(l.clone()))
+    traj = torch.stack(traj)          # random weights + epsilon prediction: latents grow to |x| ~ 20, so compare relatively
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < 2e-5, err
