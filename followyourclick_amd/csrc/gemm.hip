@@ -1,6 +1,6 @@
 // Host entry of the GEMM family: argument validation, tile/ring selection, dispatch.
 // Kernel template: gemm_kernel.h; instantiations: gemm_bf16_plain.hip, gemm_bf16_conv.hip, gemm_f32.hip.
-#include "gemm_kernel.h"
+#include "gemm_staged.h"
 
 using fycg::GemmP;
 
@@ -113,6 +113,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, (p.N % 128 == 0) ? 1 : 2, st);
   int cfg = 1, ns = 2;
   choose(p, batch, a->tile, cfg, ns);
+  if (cfg >= 12 && p.act == FYC_ACT_NONE) return fycg::run_bf16_staged(p, batch, cfg, st);   // register-staged variants (gemm_staged.h)
   if (p.act != FYC_ACT_NONE) {
     FYC_REQUIRE(a->mode == FYC_GEMM_PLAIN, "fyc_gemm: act needs the PLAIN mode");
     return fycg::run_bf16_act(p, batch, cfg, st);

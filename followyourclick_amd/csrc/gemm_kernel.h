@@ -39,10 +39,26 @@ struct GemmP {
   float out_scale;
   int act;    // FYC_ACT_* (LINEAR epilogue)
   int tiles_m, tiles_n;
+  int strip;  // > 0: tiles are walked in column strips of this many tiles (row-major inside a strip), see tile_coords
   int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
 };
+
+// Linear tile index (after the XCD remap) -> tile coordinates.  The 32 CUs of an XCD work on ~32 consecutive indices at
+// any time.  With plain row-major order (n fastest) and many column tiles that window is 1-2 tile rows x 16-32 columns:
+// per K slab the XCD's L2 then has to hold 2 A panels + 16-32 weight panels.  Walking column strips of `strip` tiles makes
+// the window 8 rows x 4 columns: (8*BM + 4*BN) instead of (BM + 32*BN) rows per slab, i.e. up to 3x less L2 fill traffic
+// for the wide FF1 layers (N = 2560 / 5120 / 10240).
+__device__ __forceinline__ void tile_coords(const GemmP& p, int t, int& tile_m, int& tile_n) {
+  if (p.strip <= 0) { tile_n = t % p.tiles_n; tile_m = t / p.tiles_n; return; }
+  const int per_strip = p.strip * p.tiles_m;
+  const int s = t / per_strip, r = t - s * per_strip;
+  const int n0 = s * p.strip;
+  const int w = min(p.strip, p.tiles_n - n0);        // the last strip may be narrower
+  tile_m = r / w;
+  tile_n = n0 + r - tile_m * w;
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -83,6 +99,186 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 template <int RB> __device__ __forceinline__ int swz_key(int row) {
   if (RB == 128) return row & 7;
   return (0x78 >> (((row >> 2) & 3) * 2)) & 3;   // {0, 2, 3, 1}
+}
+
+// ---- epilogue (shared by the DMA-ring kernel and the register-staged kernel): lane holds out[m][n0 .. n0+3] per (i, j).
+// `stg_stage`: an LDS region of STG_BYTES that no wave reads any more once all waves passed the barrier inside.
+template <typename T, int BM, int BN, int WGM, int WGN, int EPI, int STG_BYTES>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
+                                              long long bz, char* stg_stage, int wave, int lane) {
+  constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int g = lane >> 4, r16 = lane & 15;
+  // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
+  T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
+  const T* R = reinterpret_cast<const T*>(p.residual);
+  if (EPI != FYC_EPI_HEADS && sizeof(T) == 2 && p.wide) {
+    // Wide epilogue (bf16 linear / GEGLU): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
+    // 32-B row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
+    // (profiles/r01_gemm_epilogue_ablation.txt).  Each wave therefore transposes its f32 results through a
+    // private slice of the LDS stage that was consumed last and issues 16-B/lane accesses covering >=128-B
+    // contiguous row segments.  Single rounding: the residual is added in f32 after staging.
+    constexpr bool GLU = (EPI == FYC_EPI_GEGLU);
+    constexpr int OT = GLU ? WTN / 2 : WTN;            // 16-column output tiles per wave
+    constexpr int JG = (OT + 1) / 2;                   // output tiles per pass
+    constexpr int PITCH = JG * 64 + 16;                // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
+    static_assert(WGM * WGN * 16 * PITCH <= STG_BYTES, "staging must fit in one ring stage");
+    __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
+    char* stg = stg_stage + wave * (16 * PITCH);
+    const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
+    const int o_w0 = GLU ? (n_w0 >> 1) : n_w0;         // first output column of this wave
+    const int n_out = GLU ? (p.N >> 1) : p.N;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
+      const float* rb = (!GLU && p.rowbias && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j0 = h * JG;
+        const int nj = (OT - j0 < JG) ? (OT - j0) : JG;
+        if (nj <= 0) continue;
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) {
+          const int jo = j0 + jj;
+          if (jo >= OT) continue;
+          f32x4 v;
+          if (GLU) {
+            const int np = n_w0 + (2 * jo) * 16 + g * 4;   // packed value column; its gate is 16 further
+            f32x4 hv = acc[i][2 * jo], gv = acc[i][2 * jo + 1];
+            if (np < p.N && p.bias) {
+              const f32x4 bh = *reinterpret_cast<const f32x4*>(p.bias + np), bg = *reinterpret_cast<const f32x4*>(p.bias + np + 16);
+              hv[0] += bh[0]; hv[1] += bh[1]; hv[2] += bh[2]; hv[3] += bh[3];
+              gv[0] += bg[0]; gv[1] += bg[1]; gv[2] += bg[2]; gv[3] += bg[3];
+            }
+            v[0] = hv[0] * gelu_erf_f(gv[0]); v[1] = hv[1] * gelu_erf_f(gv[1]);
+            v[2] = hv[2] * gelu_erf_f(gv[2]); v[3] = hv[3] * gelu_erf_f(gv[3]);
+          } else {
+            const int n = n_w0 + jo * 16 + g * 4;
+            v = acc[i][jo];
+            if (n < p.N) {
+              if (p.bias) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+              }
+              if (rb) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(rb + n);
+                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+              }
+            }
+            if (EPI == EPI_LINEAR_ACT) { v[0] = activate(v[0], p.act); v[1] = activate(v[1], p.act); v[2] = activate(v[2], p.act); v[3] = activate(v[3], p.act); }
+          }
+          *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int cpr = nj * 2;                         // 8-element chunks per staged row
+        for (int c = lane; c < 16 * cpr; c += 64) {
+          const int row = c / cpr, ch = c - row * cpr;
+          const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
+          const int n = o_w0 + j0 * 16 + ch * 8;
+          if (m < p.M && n < n_out) {
+            float v[8];
+            *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
+            *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
+            if (!GLU) {
+              if (R) {
+                float rr[8];
+                load8<T>(R + (long long)m * p.ldr + n, rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rr[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+            }
+            store8<T>(O + (long long)m * p.ldo + n, v);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
+    if (m >= p.M) continue;
+    if (EPI == FYC_EPI_GEGLU) {
+      // packed columns: [32b, 32b+16) = value channels 16b.., [32b+16, 32b+32) = their gates
+#pragma unroll
+      for (int j = 0; j + 1 < WTN; j += 2) {
+        const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;  // value column (packed index)
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float h = acc[i][j][r], gt = acc[i][j + 1][r];
+          if (p.bias) { h += p.bias[n + r]; gt += p.bias[n + 16 + r]; }
+          v[r] = h * gelu_erf_f(gt);
+        }
+        const int oc = (n >> 5) * 16 + (n & 15);
+        ElemIO<T>::st4(O + (long long)m * p.ldo + oc, v);
+      }
+    } else {
+      const float* rb = p.rowbias ? p.rowbias + (long long)(m / p.rows_per_batch) * p.ldrb : nullptr;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        const bool full = (n + 3 < p.N);
+        if (p.bias) {
+          if (full) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += p.bias[n + r];
+          }
+        }
+        if (rb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (full || n + r < p.N) v[r] += rb[n + r];
+        }
+        if (EPI == FYC_EPI_LINEAR || EPI == EPI_LINEAR_ACT) {
+          if (EPI == EPI_LINEAR_ACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
+          }
+          if (R) {
+            if (full) {
+              float rr[4];
+              ElemIO<T>::ld4(R + (long long)m * p.ldr + n, rr);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            } else {
+              for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += ElemIO<T>::ld(R + (long long)m * p.ldr + n + r);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
+          if (full) {
+            ElemIO<T>::st4(O + (long long)m * p.ldo + n, v);
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) ElemIO<T>::st(O + (long long)m * p.ldo + n + r, v[r]);
+          }
+        } else {  // FYC_EPI_HEADS: split columns into segments (q|k|v) and heads
+          const int seg = n / p.seg_cols, c = n - seg * p.seg_cols;
+          const int h = c / p.head_dim, di = c - h * p.head_dim;
+          const int b = m / p.tokens, tok = m - b * p.tokens;
+          T* S = reinterpret_cast<T*>(p.seg_out[seg]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
+          if (!p.seg_transposed[seg]) {
+            ElemIO<T>::st4(S + ((long long)(b * p.heads + h) * p.tokens + tok) * p.head_dim + di, v);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              ElemIO<T>::st(S + ((long long)(b * p.heads + h) * p.head_dim + di + r) * p.seg_ld[seg] + tok, v[r]);
+          }
+        }
+      }
+    }
+  }
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128>
@@ -143,7 +339,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   }
   auto setup_issue = [&](int tile) {
     const int t = remap(tile);
-    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(p, t, tile_m, tile_n);
     tap = 0; c0 = 0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -278,179 +475,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     }
     const int t = remap(tile);
-    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(p, t, tile_m, tile_n);
 
-  // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
-  T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
-  const T* R = reinterpret_cast<const T*>(p.residual);
-  if (EPI != FYC_EPI_HEADS && sizeof(T) == 2 && p.wide) {
-    // Wide epilogue (bf16 linear / GEGLU): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
-    // 32-B row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
-    // (profiles/r01_gemm_epilogue_ablation.txt).  Each wave therefore transposes its f32 results through a
-    // private slice of the LDS stage that was consumed last and issues 16-B/lane accesses covering >=128-B
-    // contiguous row segments.  Single rounding: the residual is added in f32 after staging.
-    constexpr bool GLU = (EPI == FYC_EPI_GEGLU);
-    constexpr int OT = GLU ? WTN / 2 : WTN;            // 16-column output tiles per wave
-    constexpr int JG = (OT + 1) / 2;                   // output tiles per pass
-    constexpr int PITCH = JG * 64 + 16;                // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
-    static_assert(WGM * WGN * 16 * PITCH <= STAGE, "staging must fit in one ring stage");
-    __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
-    const int last = (st_c == 0) ? NS - 1 : st_c - 1;
-    char* stg = smem + last * STAGE + wave * (16 * PITCH);
-    const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
-    const int o_w0 = GLU ? (n_w0 >> 1) : n_w0;         // first output column of this wave
-    const int n_out = GLU ? (p.N >> 1) : p.N;
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) {
-      const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
-      const float* rb = (!GLU && p.rowbias && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int j0 = h * JG;
-        const int nj = (OT - j0 < JG) ? (OT - j0) : JG;
-        if (nj <= 0) continue;
-#pragma unroll
-        for (int jj = 0; jj < JG; ++jj) {
-          const int jo = j0 + jj;
-          if (jo >= OT) continue;
-          f32x4 v;
-          if (GLU) {
-            const int np = n_w0 + (2 * jo) * 16 + g * 4;   // packed value column; its gate is 16 further
-            f32x4 hv = acc[i][2 * jo], gv = acc[i][2 * jo + 1];
-            if (np < p.N && p.bias) {
-              const f32x4 bh = *reinterpret_cast<const f32x4*>(p.bias + np), bg = *reinterpret_cast<const f32x4*>(p.bias + np + 16);
-              hv[0] += bh[0]; hv[1] += bh[1]; hv[2] += bh[2]; hv[3] += bh[3];
-              gv[0] += bg[0]; gv[1] += bg[1]; gv[2] += bg[2]; gv[3] += bg[3];
-            }
-            v[0] = hv[0] * gelu_erf_f(gv[0]); v[1] = hv[1] * gelu_erf_f(gv[1]);
-            v[2] = hv[2] * gelu_erf_f(gv[2]); v[3] = hv[3] * gelu_erf_f(gv[3]);
-          } else {
-            const int n = n_w0 + jo * 16 + g * 4;
-            v = acc[i][jo];
-            if (n < p.N) {
-              if (p.bias) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-              }
-              if (rb) {
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(rb + n);
-                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-              }
-            }
-            if (EPI == EPI_LINEAR_ACT) { v[0] = activate(v[0], p.act); v[1] = activate(v[1], p.act); v[2] = activate(v[2], p.act); v[3] = activate(v[3], p.act); }
-          }
-          *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int cpr = nj * 2;                         // 8-element chunks per staged row
-        for (int c = lane; c < 16 * cpr; c += 64) {
-          const int row = c / cpr, ch = c - row * cpr;
-          const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
-          const int n = o_w0 + j0 * 16 + ch * 8;
-          if (m < p.M && n < n_out) {
-            float v[8];
-            *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
-            *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
-            if (!GLU) {
-              if (R) {
-                float rr[8];
-                load8<T>(R + (long long)m * p.ldr + n, rr);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rr[e];
-              }
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-            }
-            store8<T>(O + (long long)m * p.ldo + n, v);
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    }
-    continue;  // next tile of the stream
-  }
-#pragma unroll
-  for (int i = 0; i < WTM; ++i) {
-    const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
-    if (m >= p.M) continue;
-    if (EPI == FYC_EPI_GEGLU) {
-      // packed columns: [32b, 32b+16) = value channels 16b.., [32b+16, 32b+32) = their gates
-#pragma unroll
-      for (int j = 0; j + 1 < WTN; j += 2) {
-        const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;  // value column (packed index)
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float h = acc[i][j][r], gt = acc[i][j + 1][r];
-          if (p.bias) { h += p.bias[n + r]; gt += p.bias[n + 16 + r]; }
-          v[r] = h * gelu_erf_f(gt);
-        }
-        const int oc = (n >> 5) * 16 + (n & 15);
-        ElemIO<T>::st4(O + (long long)m * p.ldo + oc, v);
-      }
-    } else {
-      const float* rb = p.rowbias ? p.rowbias + (long long)(m / p.rows_per_batch) * p.ldrb : nullptr;
-#pragma unroll
-      for (int j = 0; j < WTN; ++j) {
-        const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        const bool full = (n + 3 < p.N);
-        if (p.bias) {
-          if (full) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-          } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += p.bias[n + r];
-          }
-        }
-        if (rb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (full || n + r < p.N) v[r] += rb[n + r];
-        }
-        if (EPI == FYC_EPI_LINEAR || EPI == EPI_LINEAR_ACT) {
-          if (EPI == EPI_LINEAR_ACT) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
-          }
-          if (R) {
-            if (full) {
-              float rr[4];
-              ElemIO<T>::ld4(R + (long long)m * p.ldr + n, rr);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += rr[r];
-            } else {
-              for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += ElemIO<T>::ld(R + (long long)m * p.ldr + n + r);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
-          if (full) {
-            ElemIO<T>::st4(O + (long long)m * p.ldo + n, v);
-          } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) ElemIO<T>::st(O + (long long)m * p.ldo + n + r, v[r]);
-          }
-        } else {  // FYC_EPI_HEADS: split columns into segments (q|k|v) and heads
-          const int seg = n / p.seg_cols, c = n - seg * p.seg_cols;
-          const int h = c / p.head_dim, di = c - h * p.head_dim;
-          const int b = m / p.tokens, tok = m - b * p.tokens;
-          T* S = reinterpret_cast<T*>(p.seg_out[seg]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= p.out_scale;
-          if (!p.seg_transposed[seg]) {
-            ElemIO<T>::st4(S + ((long long)(b * p.heads + h) * p.tokens + tok) * p.head_dim + di, v);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              ElemIO<T>::st(S + ((long long)(b * p.heads + h) * p.head_dim + di + r) * p.seg_ld[seg] + tok, v[r]);
-          }
-        }
-      }
-    }
-  }
+    gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
   }  // tile stream
 }
 
@@ -467,6 +495,7 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   GemmP q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
+  q.strip = (q.tiles_n > 4 && g_fyc_tuning[4] >= 0) ? (g_fyc_tuning[4] > 0 ? g_fyc_tuning[4] : (q.tiles_n >= 16 ? 8 : 4)) : 0;   // measured: profiles/r01_gemm_strip_order.txt
   // persistent grid: as many blocks as stay resident (LDS-limited), each walks a strided tile list
   static int n_cu = 0;
   if (n_cu == 0) {

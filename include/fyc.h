@@ -39,7 +39,9 @@ int fyc_init(const void* zero_page);
 /* fills caps[0..7]: CU count, LDS bytes/CU, wave size, gfx arch number (950), clock kHz, L2 bytes, 0, 0 */
 int fyc_device_caps(int64_t* caps);
 /* tuning knobs for A/B measurements (0 = automatic): key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
- * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant */
+ * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles,
+ * 12/14: register-staged 128x320 / 128x128), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
+ * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 6 = 1 disables the LDS-staged wide epilogue */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------

@@ -45,7 +45,7 @@ def close(hip_t, emu_t, tag, rtol):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 2), (1, 4), (2, 3), (2, 4), (3, 2), (3, 3), (4, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)])
+@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 2), (1, 4), (2, 3), (2, 4), (3, 2), (3, 3), (4, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (12, 2), (14, 2)])
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 128), (300, 320, 320), (154, 64, 768), (8, 256, 64), (1000, 960, 40), (513, 4, 576)])
 def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
@@ -71,7 +71,7 @@ def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
     close(o_h, o_e, f"gemm {dt} {M}x{N}x{K} tile/ring={tile_ring}", RTOL[dt])
 
 
-@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 3), (3, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)])
+@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 3), (3, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (12, 2), (14, 2)])
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("mode,stride,frames,H,W,Cin,Cout", [
     (1, 1, 3, 8, 8, 64, 64), (1, 1, 2, 16, 12, 128, 320), (1, 2, 2, 16, 16, 64, 128), (2, 1, 2, 6, 5, 64, 64),

@@ -17,11 +17,15 @@ SHAPES = [
     ("conv", 8192, 1280, 11520, 0, 1, (16, 16, 1280, 1, 0)), ("conv", 2048, 1280, 11520, 0, 1, (8, 8, 1280, 1, 0)),
     ("conv", 131072, 320, 5760, 0, 0, (64, 64, 640, 1, 0)), ("conv", 8192, 1280, 23040, 0, 0, (16, 16, 2560, 1, 0)),
 ]
-CFGS = [(1, 2), (2, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)]
+import os as _os
+STRIP = int(_os.environ.get("FYC_STRIP", "0"))   # tuning key 4: column-strip width of the tile order (-1 = row-major)
+CFGS = [(1, 2), (5, 2), (6, 2), (7, 2)]
 
 
 def main():
     h = ops.get()
+    h.ensure_init(torch.device("cuda:0"))
+    h.set_tuning(4, STRIP)
     dev = torch.device("cuda:0")
     h.ensure_init(dev)
     T = torch.bfloat16
