@@ -8,6 +8,8 @@ that lives under tests/ - never in the product path.)
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -59,6 +61,9 @@ class HipOps:
         self._zero = torch.zeros(4096, dtype=torch.uint8, device=device)
         L.check(self.lib.fyc_init(self._zero.data_ptr()), "fyc_init")
         self._inited_dev = device
+        for kv in filter(None, os.environ.get("FYC_TUNING", "").split(",")):   # A/B runs: FYC_TUNING="5=1,4=8" (fyc_set_tuning keys)
+            k, v = kv.split("=")
+            self.set_tuning(int(k), int(v))
 
     def device_caps(self):
         caps = (L.i64 * 8)()
