@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
                 ("batch", i32), ("mode", i32), ("epilogue", i32),
                 ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32), ("conv_pad", i32),
                 ("rows_per_batch", i32), ("seg_cols", i32), ("heads", i32), ("tokens", i32),
-                ("out_scale", f32), ("dtype", i32), ("tile", i32), ("act", i32)]
+                ("out_scale", f32), ("dtype", i32), ("tile", i32), ("act", i32), ("ln_stats", vp), ("ln_colsum", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -55,6 +55,10 @@ class GnApplyArgs(C.Structure):
 class LayerNormArgs(C.Structure):
     _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("pe", vp), ("y", vp),
                 ("rows", i32), ("C", i32), ("eps", f32), ("pe_div", i32), ("pe_rows", i32), ("dtype", i32)]
+
+
+class RowStatsArgs(C.Structure):
+    _fields_ = [("x", vp), ("stats", vp), ("rows", i32), ("C", i32), ("eps", f32), ("dtype", i32)]
 
 
 class SoftmaxArgs(C.Structure):
@@ -110,7 +114,7 @@ OPS = {
     "fyc_softmax_rows": SoftmaxArgs, "fyc_concat_channels": ConcatArgs, "fyc_silu_f32": SiluArgs,
     "fyc_cast_from_f32": CastArgs, "fyc_cast_to_f32": CastArgs, "fyc_unet_input": UnetInputArgs,
     "fyc_cfg_ddim_step": CfgDdimArgs, "fyc_nchw_to_nhwc": NchwInArgs, "fyc_nhwc_to_nchw": NhwcOutArgs,
-    "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs,
+    "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs, "fyc_row_stats": RowStatsArgs,
 }
 MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning"]
 

@@ -1,6 +1,6 @@
 // Host entry of the GEMM family: argument validation, tile/ring selection, dispatch.
 // Kernel template: gemm_kernel.h; instantiations: gemm_bf16_plain.hip, gemm_bf16_conv.hip, gemm_f32.hip.
-#include "gemm_staged.h"
+#include "gemm_kernel.h"
 
 using fycg::GemmP;
 
@@ -35,6 +35,8 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   FYC_REQUIRE(a->dtype == FYC_F32 || a->dtype == FYC_BF16, "fyc_gemm: bad dtype %d", a->dtype);
   const int es = a->dtype == FYC_BF16 ? 2 : 4, ch = 16 / es;
   FYC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "fyc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+  FYC_REQUIRE((a->ln_stats == nullptr) == (a->ln_colsum == nullptr) && (a->ln_stats == nullptr || (a->mode == FYC_GEMM_PLAIN && a->batch <= 1 && ((uintptr_t)a->ln_stats % 8) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0)),
+              "fyc_gemm: ln_stats / ln_colsum must come together (PLAIN mode, no batch, 8-/16-byte aligned)");
   FYC_REQUIRE(a->act >= FYC_ACT_NONE && a->act <= FYC_ACT_QUICK_GELU && (a->act == FYC_ACT_NONE || a->epilogue == FYC_EPI_LINEAR),
               "fyc_gemm: act=%d needs the LINEAR epilogue", a->act);
   FYC_REQUIRE(a->K % ch == 0, "fyc_gemm: K=%d must be a multiple of %d", a->K, ch);
@@ -53,6 +55,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.ldrb = a->ldrb > 0 ? a->ldrb : a->N;
   p.out_scale = a->out_scale;
   p.act = a->act;
+  p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum;
   p.zero = (const char*)g_fyc_zero_page;
   const int batch = a->batch > 0 ? a->batch : 1;
   if (a->mode == FYC_GEMM_PLAIN) {
@@ -109,11 +112,15 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
             ((uintptr_t)a->out % 16) == 0 && (a->residual == nullptr || (a->ldr % 8 == 0 && ((uintptr_t)a->residual % 16) == 0)) &&
             (a->bias == nullptr || ((uintptr_t)a->bias % 16) == 0) &&
             (a->rowbias == nullptr || (p.ldrb % 4 == 0 && ((uintptr_t)a->rowbias % 16) == 0)) && g_fyc_tuning[6] == 0) ? 1 : 0;
+  // bias / colsum / rowbias rows may be fetched as 16-byte vectors and staged through LDS (always true for the engine's buffers)
+  p.colc = (a->dtype == FYC_BF16 && a->epilogue != FYC_EPI_GEGLU && a->N % 4 == 0 && ((uintptr_t)a->bias % 16) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0 &&
+            (a->rowbias == nullptr || (p.ldrb % 4 == 0 && ((uintptr_t)a->rowbias % 16) == 0))) ? 1 : 0;
+  if (p.wide) p.colc = 1;
+  p.rb_tile = 0;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, (p.N % 128 == 0) ? 1 : 2, st);
   int cfg = 1, ns = 2;
   choose(p, batch, a->tile, cfg, ns);
-  if (cfg >= 12 && p.act == FYC_ACT_NONE) return fycg::run_bf16_staged(p, batch, cfg, st);   // register-staged variants (gemm_staged.h)
   if (p.act != FYC_ACT_NONE) {
     FYC_REQUIRE(a->mode == FYC_GEMM_PLAIN, "fyc_gemm: act needs the PLAIN mode");
     return fycg::run_bf16_act(p, batch, cfg, st);

@@ -38,9 +38,12 @@ struct GemmP {
   int rows_per_batch, seg_cols, heads, tokens, head_dim;
   float out_scale;
   int act;    // FYC_ACT_* (LINEAR epilogue)
+  const float* ln_stats; const float* ln_colsum;   // folded LayerNorm (see fyc.h): acc := rstd*(acc - mean*colsum[n])
   int tiles_m, tiles_n;
   int strip;  // > 0: tiles are walked in column strips of this many tiles (row-major inside a strip), see tile_coords
   int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
+  int colc;   // bias / colsum / tile-uniform rowbias may be fetched 16 B at a time and staged through LDS once per tile
+  int rb_tile; // rowbias row is the same for every row of a tile (rows_per_batch % BM == 0): folded into the staged bias
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
 };
@@ -101,12 +104,35 @@ template <int RB> __device__ __forceinline__ int swz_key(int row) {
   return (0x78 >> (((row >> 2) & 3) * 2)) & 3;   // {0, 2, 3, 1}
 }
 
-// ---- epilogue (shared by the DMA-ring kernel and the register-staged kernel): lane holds out[m][n0 .. n0+3] per (i, j).
+// Column constants of one output tile, staged through LDS once per tile: colc[0..BN) = bias (+ the rowbias row when it is the
+// same for the whole tile), colc[BN..2BN) = LayerNorm column sums.  Every global load in the epilogue is followed by an
+// s_waitcnt that also drains the next tile's K-tile DMA (loads return in order) and, with one block per CU, nothing hides
+// that latency - so the constants are fetched by BN/4 lanes in one go instead of once per (row block, column tile) by all.
+template <int BN, bool LN>
+__device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc, int tile_m_row0, int tile_n, int tid) {
+  const int t4 = tid * 4;
+  if (t4 < BN) {
+    const int n = tile_n * BN + t4;
+    const bool ok = n < p.N;
+    f32x4 b = (ok && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ok && p.rb_tile) {
+      const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.rowbias + (long long)(tile_m_row0 / p.rows_per_batch) * p.ldrb + n);
+      b[0] += r4[0]; b[1] += r4[1]; b[2] += r4[2]; b[3] += r4[3];
+    }
+    *reinterpret_cast<f32x4*>(colc + t4) = b;
+    *reinterpret_cast<f32x4*>(colc + BN + t4) = (LN && ok && p.ln_stats) ? *reinterpret_cast<const f32x4*>(p.ln_colsum + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j).
 // `stg_stage`: an LDS region of STG_BYTES that no wave reads any more once all waves passed the barrier inside.
-template <typename T, int BM, int BN, int WGM, int WGN, int EPI, int STG_BYTES>
+template <typename T, int BM, int BN, int WGM, int WGN, int EPI, int STG_BYTES, int MODE = FYC_GEMM_PLAIN>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
                                               long long bz, char* stg_stage, int wave, int lane) {
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+  constexpr bool LN = (MODE == FYC_GEMM_PLAIN);   // the folded LayerNorm only exists for plain GEMMs: keep it out of the conv kernels
   const int wm = wave / WGN, wn = wave % WGN;
   const int g = lane >> 4, r16 = lane & 15;
   // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
@@ -122,55 +148,71 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     constexpr int OT = GLU ? WTN / 2 : WTN;            // 16-column output tiles per wave
     constexpr int JG = (OT + 1) / 2;                   // output tiles per pass
     constexpr int PITCH = JG * 64 + 16;                // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
-    static_assert(WGM * WGN * 16 * PITCH <= STG_BYTES, "staging must fit in one ring stage");
+    static_assert(WGM * WGN * 16 * PITCH + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
     char* stg = stg_stage + wave * (16 * PITCH);
     const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
     const int o_w0 = GLU ? (n_w0 >> 1) : n_w0;         // first output column of this wave
     const int n_out = GLU ? (p.N >> 1) : p.N;
+    float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * 16 * PITCH);   // [2][BN], see stage_col_constants
+    stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+    float ln_mu[WTM], ln_rs[WTM];
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
-      const float* rb = (!GLU && p.rowbias && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
+      ln_mu[i] = 0.f; ln_rs[i] = 1.f;
+      if (LN && p.ln_stats && m_lane < p.M) { const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2ll * m_lane); ln_mu[i] = ms.x; ln_rs[i] = ms.y; }
+    }
+    const int nl_w0 = wn * WTN * 16;                   // this wave's first column inside the tile
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int j0 = h * JG;
-        const int nj = (OT - j0 < JG) ? (OT - j0) : JG;
-        if (nj <= 0) continue;
+    for (int h = 0; h < 2; ++h) {
+      const int j0 = h * JG;
+      const int nj = (OT - j0 < JG) ? (OT - j0) : JG;
+      if (nj <= 0) continue;
+      const int cpr = nj * 2;                           // 8-element chunks per staged row
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
+        const float* rb = (!GLU && p.rowbias && !p.rb_tile && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) {
           const int jo = j0 + jj;
           if (jo >= OT) continue;
           f32x4 v;
           if (GLU) {
-            const int np = n_w0 + (2 * jo) * 16 + g * 4;   // packed value column; its gate is 16 further
             f32x4 hv = acc[i][2 * jo], gv = acc[i][2 * jo + 1];
-            if (np < p.N && p.bias) {
-              const f32x4 bh = *reinterpret_cast<const f32x4*>(p.bias + np), bg = *reinterpret_cast<const f32x4*>(p.bias + np + 16);
-              hv[0] += bh[0]; hv[1] += bh[1]; hv[2] += bh[2]; hv[3] += bh[3];
-              gv[0] += bg[0]; gv[1] += bg[1]; gv[2] += bg[2]; gv[3] += bg[3];
+            const int nl = nl_w0 + (2 * jo) * 16 + g * 4;  // packed value column inside the tile; its gate is 16 further
+            if (LN && p.ln_stats) {
+              const f32x4 sh = *reinterpret_cast<const f32x4*>(colc + BN + nl), sg = *reinterpret_cast<const f32x4*>(colc + BN + nl + 16);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { hv[r] = ln_rs[i] * (hv[r] - ln_mu[i] * sh[r]); gv[r] = ln_rs[i] * (gv[r] - ln_mu[i] * sg[r]); }
             }
+            const f32x4 bh = *reinterpret_cast<const f32x4*>(colc + nl), bg = *reinterpret_cast<const f32x4*>(colc + nl + 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { hv[r] += bh[r]; gv[r] += bg[r]; }
             v[0] = hv[0] * gelu_erf_f(gv[0]); v[1] = hv[1] * gelu_erf_f(gv[1]);
             v[2] = hv[2] * gelu_erf_f(gv[2]); v[3] = hv[3] * gelu_erf_f(gv[3]);
           } else {
             const int n = n_w0 + jo * 16 + g * 4;
             v = acc[i][jo];
-            if (n < p.N) {
-              if (p.bias) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-              }
-              if (rb) {
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(rb + n);
-                v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-              }
+            const int nl = nl_w0 + jo * 16 + g * 4;
+            if (LN && p.ln_stats) {
+              const f32x4 s4 = *reinterpret_cast<const f32x4*>(colc + BN + nl);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = ln_rs[i] * (v[r] - ln_mu[i] * s4[r]);
+            }
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(colc + nl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += b4[r];
+            if (rb && n < p.N) {
+              const f32x4 r4 = *reinterpret_cast<const f32x4*>(rb + n);
+              v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
             }
             if (EPI == EPI_LINEAR_ACT) { v[0] = activate(v[0], p.act); v[1] = activate(v[1], p.act); v[2] = activate(v[2], p.act); v[3] = activate(v[3], p.act); }
           }
           *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int cpr = nj * 2;                         // 8-element chunks per staged row
         for (int c = lane; c < 16 * cpr; c += 64) {
           const int row = c / cpr, ch = c - row * cpr;
           const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
@@ -197,10 +239,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     }
     return;
   }
+  float* colc = reinterpret_cast<float*>(stg_stage);
+  if (p.colc) {
+    __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
+    stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+  }
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
     const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
     if (m >= p.M) continue;
+    float ln_mu = 0.f, ln_rs = 1.f;
+    if (LN && p.ln_stats) { const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2ll * m); ln_mu = ms.x; ln_rs = ms.y; }
     if (EPI == FYC_EPI_GEGLU) {
       // packed columns: [32b, 32b+16) = value channels 16b.., [32b+16, 32b+32) = their gates
 #pragma unroll
@@ -211,6 +260,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float h = acc[i][j][r], gt = acc[i][j + 1][r];
+          if (LN && p.ln_stats) { h = ln_rs * (h - ln_mu * p.ln_colsum[n + r]); gt = ln_rs * (gt - ln_mu * p.ln_colsum[n + 16 + r]); }
           if (p.bias) { h += p.bias[n + r]; gt += p.bias[n + 16 + r]; }
           v[r] = h * gelu_erf_f(gt);
         }
@@ -218,7 +268,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
         ElemIO<T>::st4(O + (long long)m * p.ldo + oc, v);
       }
     } else {
-      const float* rb = p.rowbias ? p.rowbias + (long long)(m / p.rows_per_batch) * p.ldrb : nullptr;
+      const float* rb = (p.rowbias && !(p.colc && p.rb_tile)) ? p.rowbias + (long long)(m / p.rows_per_batch) * p.ldrb : nullptr;
 #pragma unroll
       for (int j = 0; j < WTN; ++j) {
         const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
@@ -227,7 +277,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
         const bool full = (n + 3 < p.N);
-        if (p.bias) {
+        if (p.colc) {                                    // staged constants (N % 4 == 0 here): colsum, then bias (+ tile rowbias)
+          const int nl = (wn * WTN + j) * 16 + g * 4;
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(colc + BN + nl), b4 = *reinterpret_cast<const f32x4*>(colc + nl);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (LN && p.ln_stats ? ln_rs * (v[r] - ln_mu * s4[r]) : v[r]) + b4[r];
+        } else if (LN && p.ln_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (full || n + r < p.N) v[r] = ln_rs * (v[r] - ln_mu * p.ln_colsum[n + r]);
+        }
+        if (p.bias && !p.colc) {
           if (full) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
             v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
@@ -478,7 +537,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     int tile_m, tile_n;
     tile_coords(p, t, tile_m, tile_n);
 
-    gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
+    gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
   }  // tile stream
 }
 
@@ -495,6 +554,7 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   GemmP q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
+  q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
   q.strip = (q.tiles_n > 4 && g_fyc_tuning[4] >= 0) ? (g_fyc_tuning[4] > 0 ? g_fyc_tuning[4] : (q.tiles_n >= 16 ? 8 : 4)) : 0;   // measured: profiles/r01_gemm_strip_order.txt
   // persistent grid: as many blocks as stay resident (LDS-limited), each walks a strided tile list
   static int n_cu = 0;

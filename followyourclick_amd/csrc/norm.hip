@@ -116,7 +116,7 @@ template <typename T, int MAXCH>
 __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ pe,
                                                         T* __restrict__ y, int rows, int C, float eps, int pe_div,
-                                                        int pe_rows) {
+                                                        int pe_rows, float* __restrict__ stats = nullptr) {
   const int p = threadIdx.x & 15;
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool live = row < rows;
@@ -149,6 +149,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
   for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
   if (!live) return;
   const float rstd = rsqrtf(q / (float)C + eps);
+  if (stats) {                                   // statistics-only mode (LayerNorm folded into the consuming GEMM)
+    if (p == 0) *reinterpret_cast<float2*>(stats + 2ll * row) = make_float2(mean, rstd);
+    return;
+  }
   const float* per = pe ? pe + (long long)((row / pe_div) % pe_rows) * C : nullptr;
   T* yr = y + (long long)row * C;
 #pragma unroll
@@ -259,6 +263,23 @@ extern "C" int fyc_layernorm(const fyc_layernorm_args* a, void* stream) {
   } else FYC_FAIL(-2, "fyc_layernorm: bad dtype");
 #undef FYC_LN
   FYC_CHECK_LAUNCH("fyc_layernorm");
+  return 0;
+}
+
+extern "C" int fyc_row_stats(const fyc_row_stats_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->stats, "fyc_row_stats: null pointer");
+  FYC_REQUIRE(a->rows > 0 && a->C % 8 == 0 && a->C >= 8 && a->C <= 2048, "fyc_row_stats: rows=%d C=%d (C must be a multiple of 8 in [8, 2048])", a->rows, a->C);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((a->rows + 15) / 16);
+#define FYC_RS(T, MAXC8) hipLaunchKernelGGL((layernorm_kernel<T, MAXC8>), grid, dim3(256), 0, st, (const T*)a->x, nullptr, nullptr, nullptr, (T*)nullptr, a->rows, a->C, a->eps, 1, 1, a->stats)
+  const int need = (a->C / 8 + 15) / 16;
+  if (a->dtype == FYC_BF16) {
+    if (need <= 3) FYC_RS(bf16_t, 3); else if (need <= 5) FYC_RS(bf16_t, 5); else if (need <= 10) FYC_RS(bf16_t, 10); else FYC_RS(bf16_t, 16);
+  } else if (a->dtype == FYC_F32) {
+    if (need <= 3) FYC_RS(float, 3); else if (need <= 5) FYC_RS(float, 5); else if (need <= 10) FYC_RS(float, 10); else FYC_RS(float, 16);
+  } else FYC_FAIL(-2, "fyc_row_stats: bad dtype");
+#undef FYC_RS
+  FYC_CHECK_LAUNCH("fyc_row_stats");
   return 0;
 }
 

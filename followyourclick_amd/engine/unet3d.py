@@ -147,6 +147,22 @@ class UNet3DEngine(EngineBase):
                 o.gemm(S, vt[kb], dst, M=n_q, N=d, K=ldS, lda=ldS, ldw=ldvt, ldo=C, batch=H, stride_a=n_q * ldS, stride_w=d * ldvt,
                        stride_o=d)
 
+    def row_stats(self, x: Tensor, rows: int, C: int, eps: float = 1e-5) -> Tensor:
+        """{mean, rstd} per token row: the statistics half of a LayerNorm whose affine half lives in the next GEMM"""
+        st = torch.empty(rows, 2, dtype=torch.float32, device=self.device)
+        self.ops.row_stats(x, st, rows=rows, C_=C, eps=eps)
+        return st
+
+    def _pe_rowbias(self, a: Packed, B: int, F: int) -> Tensor:
+        """pe_f W_qkv^T for token rows ordered [(b f)][pixel]: one row per (b, f)"""
+        key = (B, F)
+        cache = a.setdefault("_pe_rb", {})
+        if key not in cache:
+            if F > a.pe_w.shape[0]:
+                raise ValueError(f"video_length {F} exceeds the positional table ({a.pe_w.shape[0]})")
+            cache[key] = a.pe_w[:F].repeat(B, 1).contiguous()
+        return cache[key]
+
     def _axpy(self, x: Tensor, y: Tensor, rows: int, C: int, alpha: float) -> None:
         """y = y + alpha * x via the GEMM epilogue (parity mode only): (x @ (alpha*I)) + y."""
         key = ("axpy", C, alpha)
@@ -172,8 +188,14 @@ class UNet3DEngine(EngineBase):
     def feed_forward_out(self, ff: Packed, ln, tok: Tensor, residual: Tensor, rows: int, C: int) -> Tensor:
         """LN -> GEGLU FF -> (+tok) -> output projection (+residual) with FF2 and the projection merged into one GEMM
         over [tok | h] (see weights._ff): returns residual + Wp (tok + W2 h + b2) + bp."""
-        n = self.layer_norm(tok, ln, rows, C)
-        hmid = self.lin(n, ff.w1, rows, bias=ff.b1, geglu=True)
+        if ff.cs1 is not None:      # LayerNorm folded into FF1: one statistics pass instead of a normalise-and-write pass
+            N1 = ff.w1.shape[0]
+            hmid = self.new(rows, N1 // 2)
+            self.ops.gemm(tok, ff.w1, hmid, M=rows, N=N1, K=C, lda=C, ldw=C, ldo=N1 // 2, bias=ff.b1, epilogue=L.EPI_GEGLU,
+                          ln_stats=self.row_stats(tok, rows, C), ln_colsum=ff.cs1)
+        else:
+            n = self.layer_norm(tok, ln, rows, C)
+            hmid = self.lin(n, ff.w1, rows, bias=ff.b1, geglu=True)
         out = self.new(rows, C)
         K = ff.po_w.shape[1]
         self.ops.gemm(tok, ff.po_w, out, M=rows, N=C, K=K, lda=C, ldw=K, ldo=C, bias=ff.po_b, residual=residual, ldr=C,
@@ -188,19 +210,29 @@ class UNet3DEngine(EngineBase):
         h = self.group_norm(x, t.norm_g, t.norm_b, rows, C, N, 1e-6, False)
         tok = self.lin(h, t.pin_w, rows, bias=t.pin_b)
         # --- attn1: spatial self-attention
-        n1 = self.layer_norm(tok, t.ln1, rows, C)
         ld = ((N + 7) // 8) * 8
         q, k, vt = self.new(BF, H, N, d), self.new(BF, H, N, d), (self.zeros(BF, H, d, ld) if ld != N else self.new(BF, H, d, ld))
-        o.gemm(n1, t.qkv_w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS,
-               heads=dict(seg_cols=C, heads=H, tokens=N, outs=[q, k, vt], transposed=[0, 0, 1], ld=[0, 0, ld]))
+        hd = dict(seg_cols=C, heads=H, tokens=N, outs=[q, k, vt], transposed=[0, 0, 1], ld=[0, 0, ld])
+        if t.qkv_f is not None:     # LayerNorm (norm1) folded into the fused QKV projection
+            w, b, cs = t.qkv_f
+            o.gemm(tok, w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, bias=b, epilogue=L.EPI_HEADS, heads=hd,
+                   ln_stats=self.row_stats(tok, rows, C), ln_colsum=cs)
+        else:
+            n1 = self.layer_norm(tok, t.ln1, rows, C)
+            o.gemm(n1, t.qkv_w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS, heads=hd)
         att = self.new(rows, C)
         self._attend(q, k, vt, att, batch=BF, n_q=N, n_k=N, d=d, ldvt=ld, C=C, kv_div=1)
         tok = self.lin(att, t.o1_w, rows, bias=t.o1_b, residual=tok)
         # --- attn2: cross-attention on the cached text (and IP) K/V
-        n2 = self.layer_norm(tok, t.ln2, rows, C)
         q2 = self.new(BF, H, N, d)
-        o.gemm(n2, t.q2_w, None, M=rows, N=C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS,
-               heads=dict(seg_cols=C, heads=H, tokens=N, outs=[q2], transposed=[0], ld=[0]))
+        hd2 = dict(seg_cols=C, heads=H, tokens=N, outs=[q2], transposed=[0], ld=[0])
+        if t.q2_f is not None:
+            w, b, cs = t.q2_f
+            o.gemm(tok, w, None, M=rows, N=C, K=C, lda=C, ldw=C, bias=b, epilogue=L.EPI_HEADS, heads=hd2,
+                   ln_stats=self.row_stats(tok, rows, C), ln_colsum=cs)
+        else:
+            n2 = self.layer_norm(tok, t.ln2, rows, C)
+            o.gemm(n2, t.q2_w, None, M=rows, N=C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS, heads=hd2)
         cache = self.ctx_cache[t.idx]
         kt, vtt, ldt = cache["text"]
         att2 = self.new(rows, C)
@@ -221,8 +253,15 @@ class UNet3DEngine(EngineBase):
         tok = self.lin(h, m.pin_w, rows, bias=m.pin_b)
         for bi, blk in enumerate(m.blocks):
             for a in blk.attns:
-                n = self.layer_norm(tok, a.ln, rows, C, pe=a.pe, pe_div=N, pe_rows=g["F"])
-                qkv = self.lin(n, a.qkv_w, rows)
+                if a.qkv_f is not None:     # LayerNorm folded into the QKV projection, positional table as a per-frame row bias
+                    w, b, cs = a.qkv_f
+                    qkv = self.new(rows, 3 * C)
+                    rb = self._pe_rowbias(a, g["B"], g["F"]) if a.pe_w is not None else None
+                    o.gemm(tok, w, qkv, M=rows, N=3 * C, K=C, lda=C, ldw=C, ldo=3 * C, bias=b, rowbias=rb, rows_per_batch=N,
+                           ln_stats=self.row_stats(tok, rows, C), ln_colsum=cs)
+                else:
+                    n = self.layer_norm(tok, a.ln, rows, C, pe=a.pe, pe_div=N, pe_rows=g["F"])
+                    qkv = self.lin(n, a.qkv_w, rows)
                 att = self.new(rows, C)
                 o.temporal_attention(qkv, att, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5)
                 tok = self.lin(att, a.o_w, rows, bias=a.o_b, residual=tok)

@@ -12,6 +12,8 @@ Packed layouts (activation dtype unless noted):
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 import torch
@@ -67,6 +69,23 @@ def f32(t: Tensor, device) -> Tensor:
     return t.detach().float().contiguous().to(device)
 
 
+def fold_layernorm(w: Tensor, b: Optional[Tensor], gamma: Tensor, beta: Tensor, dtype, device, geglu: bool = False):
+    """LayerNorm folded into the Linear that consumes it (fyc_gemm ln_stats / ln_colsum):
+        LN(x) W^T + b = rstd * (x (W*gamma)^T - mean * colsum) + (W beta + b)
+    Returns (packed W*gamma, f32 bias W beta + b, f32 colsum).  colsum is taken from the ROUNDED packed weights so that the
+    mean term cancels against exactly what the MFMAs accumulate."""
+    w = w.reshape(w.shape[0], -1).double()
+    wf = (w * gamma.double()[None, :]).float()
+    bias = (w @ beta.double() + (b.double() if b is not None else 0.0)).float()
+    if geglu:
+        wp, bp = pack_geglu(wf, bias, dtype, device)
+    else:
+        wp, bp = pack_linear(wf, dtype, device), f32(bias, device)
+    return wp, bp, wp.float().sum(dim=1).contiguous()
+
+LN_FOLD = os.environ.get("FYC_LN_FOLD", "1") != "0"   # A/B switch: 0 keeps the separate LayerNorm kernel
+
+
 class Packed(dict):
     """dict with attribute access; leaves are device tensors."""
     __getattr__ = dict.__getitem__
@@ -85,7 +104,7 @@ def _resnet(sd: Dict[str, Tensor], p: str, dtype, device, temb: bool = True) -> 
     return r
 
 
-def _ff(sd, p, dtype, device, proj_out_w: Tensor, proj_out_b: Tensor) -> Packed:
+def _ff(sd, p, dtype, device, proj_out_w: Tensor, proj_out_b: Tensor, ln: Optional[str] = None) -> Packed:
     """GEGLU feed-forward followed by the block's output projection.
 
     The reference computes tok' = tok + W2 h + b2 (FeedForward, diffusers/models/attention.py:772-775) and then
@@ -93,12 +112,17 @@ def _ff(sd, p, dtype, device, proj_out_w: Tensor, proj_out_b: Tensor) -> Packed:
     motion_module.py:199-203); tok' is used nowhere else.  Both are linear, so they are merged at load time into ONE
     GEMM over the K-concatenated operand [tok | h]:  out = x + (bp + Wp b2) + [Wp | Wp W2] [tok ; h]
     (products in f32, then cast) - one launch and one full pass over the activations less per block."""
-    w1, b1 = pack_geglu(sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"], dtype, device)
+    cs1 = None
+    if ln is not None and LN_FOLD:      # the LayerNorm in front of the FF (norm3 / ff_norm) is folded into FF1
+        w1, b1, cs1 = fold_layernorm(sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"], sd[ln + ".weight"], sd[ln + ".bias"],
+                                     dtype, device, geglu=True)
+    else:
+        w1, b1 = pack_geglu(sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"], dtype, device)
     w2, b2 = sd[p + ".net.2.weight"].double(), sd[p + ".net.2.bias"].double()
     wp, bp = proj_out_w.reshape(proj_out_w.shape[0], -1).double(), proj_out_b.double()
     merged_w = torch.cat([wp, wp @ w2], dim=1).float()
     merged_b = (bp + wp @ b2).float()
-    return Packed(w1=w1, b1=b1, po_w=pack_linear(merged_w, dtype, device), po_b=f32(merged_b, device))
+    return Packed(w1=w1, b1=b1, cs1=cs1, po_w=pack_linear(merged_w, dtype, device), po_b=f32(merged_b, device))
 
 
 def _ln(sd, p, device):
@@ -118,7 +142,13 @@ def _transformer(sd, p: str, cfg: UNet3DConfig, dtype, device) -> Packed:
         q2_w=pack_linear(sd[a2 + ".to_q.weight"], dtype, device),
         kv2_w=pack_linear(torch.cat([sd[a2 + ".to_k.weight"], sd[a2 + ".to_v.weight"]], 0), dtype, device),
         o2_w=pack_linear(sd[a2 + ".to_out.0.weight"], dtype, device), o2_b=f32(sd[a2 + ".to_out.0.bias"], device),
-        ff=_ff(sd, t + ".ff", dtype, device, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]), kvip_w=None)
+        ff=_ff(sd, t + ".ff", dtype, device, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"], ln=t + ".norm3"), kvip_w=None,
+        qkv_f=None, q2_f=None)
+    if LN_FOLD:   # norm1 -> fused QKV, norm2 -> to_q of the cross-attention
+        qkv = torch.cat([sd[a1 + ".to_q.weight"], sd[a1 + ".to_k.weight"], sd[a1 + ".to_v.weight"]], 0)
+        d["qkv_f"] = fold_layernorm(qkv, None, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], dtype, device)
+        d["q2_f"] = fold_layernorm(sd[a2 + ".to_q.weight"], None, sd[t + ".norm2.weight"], sd[t + ".norm2.bias"], dtype, device)
+        d["qkv_w"] = d["q2_w"] = None
     if cfg.use_ip_cross_attention:
         d["kvip_w"] = pack_linear(torch.cat([sd[a2 + ".to_k_ip.weight"], sd[a2 + ".to_v_ip.weight"]], 0), dtype, device)
     return d
@@ -138,15 +168,22 @@ def _motion(sd, p: str, cfg: UNet3DConfig, dtype, device) -> Packed:
                 # analytic table (== the persistent `pos_encoder.pe` buffer, reference motion_module.py:286-304);
                 # regenerated so that clips longer than a checkpoint's max_len still work
                 pe = sinusoidal_pe(C, max(cfg.temporal_position_encoding_max_len, 32)).to(device)
-            attns.append(Packed(
-                ln=_ln(sd, f"{t}.norms.{a}", device), pe=pe,
-                qkv_w=pack_linear(torch.cat([sd[ab + ".to_q.weight"], sd[ab + ".to_k.weight"], sd[ab + ".to_v.weight"]], 0), dtype, device),
-                o_w=pack_linear(sd[ab + ".to_out.0.weight"], dtype, device), o_b=f32(sd[ab + ".to_out.0.bias"], device)))
+            qkv = torch.cat([sd[ab + ".to_q.weight"], sd[ab + ".to_k.weight"], sd[ab + ".to_v.weight"]], 0)
+            att = Packed(ln=_ln(sd, f"{t}.norms.{a}", device), pe=pe, qkv_w=None, qkv_f=None, pe_w=None,
+                         o_w=pack_linear(sd[ab + ".to_out.0.weight"], dtype, device), o_b=f32(sd[ab + ".to_out.0.bias"], device))
+            if LN_FOLD:
+                # (LN(x) + pe_f) W^T = LN(x) W^T + pe_f W^T: the positional table becomes a per-frame row bias of the QKV GEMM
+                att["qkv_f"] = fold_layernorm(qkv, None, sd[f"{t}.norms.{a}.weight"], sd[f"{t}.norms.{a}.bias"], dtype, device)
+                if pe is not None:
+                    att["pe_w"] = (pe.double().cpu() @ qkv.double().t()).float().contiguous().to(device)
+            else:
+                att["qkv_w"] = pack_linear(qkv, dtype, device)
+            attns.append(att)
         last = b == cfg.motion_num_transformer_block - 1
         if last:   # the module's proj_out is merged into the last block's FF (see _ff)
-            ff = _ff(sd, t + ".ff", dtype, device, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+            ff = _ff(sd, t + ".ff", dtype, device, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"], ln=t + ".ff_norm")
         else:      # inner blocks keep a plain FF2 + residual: identity "projection"
-            ff = _ff(sd, t + ".ff", dtype, device, torch.eye(C), torch.zeros(C))
+            ff = _ff(sd, t + ".ff", dtype, device, torch.eye(C), torch.zeros(C), ln=t + ".ff_norm")
         blocks.append(Packed(attns=attns, ff_ln=_ln(sd, t + ".ff_norm", device), ff=ff))
     return Packed(C=C, norm_g=f32(sd[p + ".norm.weight"], device), norm_b=f32(sd[p + ".norm.bias"], device),
                   pin_w=pack_linear(sd[p + ".proj_in.weight"], dtype, device), pin_b=f32(sd[p + ".proj_in.bias"], device),

@@ -86,7 +86,8 @@ class HipOps:
              residual: Optional[Tensor] = None, ldr: int = 0, ldrb: int = 0, out_scale: float = 1.0, epilogue: int = L.EPI_LINEAR,
              mode: int = L.GEMM_PLAIN, conv: Optional[dict] = None, batch: int = 1, stride_a: int = 0,
              stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None, tile: int = 0,
-             a2: Optional[Tensor] = None, k_split: int = 0, lda2: int = 0, act: int = L.ACT_NONE) -> None:
+             a2: Optional[Tensor] = None, k_split: int = 0, lda2: int = 0, act: int = L.ACT_NONE,
+             ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None) -> None:
         self.ensure_init(a.device)
         g = L.GemmArgs()
         g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
@@ -95,6 +96,7 @@ class HipOps:
         g.stride_a, g.stride_w, g.stride_o, g.batch = stride_a, stride_w, stride_o, batch
         g.mode, g.epilogue, g.rows_per_batch, g.out_scale, g.dtype = mode, epilogue, rows_per_batch, out_scale, _dt(a)
         g.tile, g.act = tile, act
+        g.ln_stats, g.ln_colsum = _f32(ln_stats, "ln_stats"), _f32(ln_colsum, "ln_colsum")
         g.a2, g.k_split, g.lda2 = _p(a2), k_split, lda2
         if a.dtype != w.dtype:
             raise TypeError(f"gemm: activation {a.dtype} vs weight {w.dtype}")
@@ -148,6 +150,11 @@ class HipOps:
         a.x, a.gamma, a.beta, a.pe, a.y = _p(x), _f32(gamma, "gamma"), _f32(beta, "beta"), _f32(pe, "pe"), _p(y)
         a.rows, a.C, a.eps, a.pe_div, a.pe_rows, a.dtype = rows, C_, eps, pe_div, pe_rows, _dt(x)
         self._call("fyc_layernorm", a)
+
+    def row_stats(self, x: Tensor, stats: Tensor, *, rows: int, C_: int, eps: float = 1e-5) -> None:
+        a = L.RowStatsArgs()
+        a.x, a.stats, a.rows, a.C, a.eps, a.dtype = _p(x), _f32(stats, "stats"), rows, C_, eps, _dt(x)
+        self._call("fyc_row_stats", a)
 
     def softmax_rows(self, x: Tensor, *, rows: int, cols: int, ld: int, causal_rows: int = 0) -> None:
         a = L.SoftmaxArgs()

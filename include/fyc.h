@@ -39,8 +39,7 @@ int fyc_init(const void* zero_page);
 /* fills caps[0..7]: CU count, LDS bytes/CU, wave size, gfx arch number (950), clock kHz, L2 bytes, 0, 0 */
 int fyc_device_caps(int64_t* caps);
 /* tuning knobs for A/B measurements (0 = automatic): key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
- * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles,
- * 12/14: register-staged 128x320 / 128x128), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
+ * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
  * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 6 = 1 disables the LDS-staged wide epilogue */
 int fyc_set_tuning(int key, int value);
 
@@ -87,6 +86,11 @@ typedef struct {
   int32_t dtype;
   int32_t tile;          /* 0 = automatic; else tile config id | ring depth << 8 (see fyc_set_tuning) */
   int32_t act;           /* LINEAR epilogue only: FYC_ACT_* applied to (acc + bias + rowbias) before residual / out_scale */
+  /* LayerNorm folded into the GEMM that consumes it (all epilogues):  LN(x) W^T = rstd (x (gamma*W)^T - mean * colsum) + beta W^T.
+   * `a` is the UN-normalised input, `w` = W scaled by gamma along K, `bias` already contains beta W^T, ln_colsum[n] = sum_k w[n][k],
+   * ln_stats[m] = {mean, rstd} of row m (fyc_row_stats).  acc := rstd[m] * (acc - mean[m] * ln_colsum[n]) before bias.  NULL = off. */
+  const float* ln_stats;
+  const float* ln_colsum;
 } fyc_gemm_args;
 int fyc_gemm(const fyc_gemm_args* a, void* stream);
 
@@ -157,6 +161,11 @@ typedef struct {
   int32_t dtype;
 } fyc_layernorm_args;
 int fyc_layernorm(const fyc_layernorm_args* a, void* stream);
+
+/* per-row LayerNorm statistics for the folded form above: stats[r] = {mean, 1/sqrt(var + eps)} over the C channels of row r
+ * (nn.LayerNorm's biased variance; reference attention.py:383,412,418, motion_module.py:261,267) */
+typedef struct { const void* x; float* stats; int32_t rows, C; float eps; int32_t dtype; } fyc_row_stats_args;
+int fyc_row_stats(const fyc_row_stats_args* a, void* stream);
 
 /* row softmax (in place, f32 math): x [rows][ld], first `cols` columns (materialised attention).
  * causal_rows = n > 0: row r belongs to query (r % n) and only columns <= r % n take part, the rest become 0

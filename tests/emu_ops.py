@@ -40,7 +40,7 @@ class EmuOps:
     # ------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
              ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
-             heads=None, tile=0, a2=None, k_split=0, lda2=0, act=0):
+             heads=None, tile=0, a2=None, k_split=0, lda2=0, act=0, ln_stats=None, ln_colsum=None):
         acc_t = self.acc
         af, wf = _flat(a), _flat(w)
         for z in range(batch):
@@ -69,6 +69,9 @@ class EmuOps:
                     y = F.conv2d(x, w4, None, stride=stride, padding=1)
                 assert y.shape[2] == Hout and y.shape[3] == Wout, (y.shape, Hout, Wout)
                 acc = y.permute(0, 2, 3, 1).reshape(M, N)
+            if ln_stats is not None:      # folded LayerNorm: rstd * (x W'^T - mean * colsum)
+                st = ln_stats.reshape(-1, 2)[:M].to(acc_t)
+                acc = st[:, 1:2] * (acc - st[:, 0:1] * ln_colsum.to(acc_t)[None, :N])
             if bias is not None:
                 acc = acc + bias.to(acc_t)[None, :N]
             if rowbias is not None:
@@ -163,6 +166,12 @@ class EmuOps:
             idx = (torch.arange(rows) // pe_div) % pe_rows
             yv = yv + pe.reshape(-1, C_)[idx].float()
         _flat(y)[: rows * C_].reshape(rows, C_).copy_(yv.to(y.dtype))
+
+    def row_stats(self, x, stats, *, rows, C_, eps=1e-5):
+        xs = _flat(x)[: rows * C_].reshape(rows, C_).float()
+        mean = xs.mean(dim=1)
+        var = ((xs - mean[:, None]) ** 2).mean(dim=1)
+        stats.reshape(-1, 2)[:rows].copy_(torch.stack([mean, torch.rsqrt(var + eps)], dim=1))
 
     def softmax_rows(self, x, *, rows, cols, ld, causal_rows=0):
         v = _strided(_flat(x), (rows, cols), (ld, 1), 0)

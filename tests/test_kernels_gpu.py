@@ -45,7 +45,7 @@ def close(hip_t, emu_t, tag, rtol):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 2), (1, 4), (2, 3), (2, 4), (3, 2), (3, 3), (4, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (12, 2), (14, 2)])
+@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 2), (1, 4), (2, 3), (2, 4), (3, 2), (3, 3), (4, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)])
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 128), (300, 320, 320), (154, 64, 768), (8, 256, 64), (1000, 960, 40), (513, 4, 576)])
 def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
@@ -71,7 +71,7 @@ def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
     close(o_h, o_e, f"gemm {dt} {M}x{N}x{K} tile/ring={tile_ring}", RTOL[dt])
 
 
-@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 3), (3, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (12, 2), (14, 2)])
+@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 3), (3, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)])
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("mode,stride,frames,H,W,Cin,Cout", [
     (1, 1, 3, 8, 8, 64, 64), (1, 1, 2, 16, 12, 128, 320), (1, 2, 2, 16, 16, 64, 128), (2, 1, 2, 6, 5, 64, 64),
@@ -407,3 +407,67 @@ def test_embed_tokens_and_patchify(hip, emu, dt):
     assert torch.allclose(p_e.float()[:, :588] @ w.reshape(32, -1).t(), ref, atol=2e-1 if dt == "bf16" else 1e-4)
     with pytest.raises(Exception, match="patch size"):
         hip.patchify(img.cuda(), p_h, B=B, Cin=3, H=28, W=42, P=16, ld=1024)
+
+
+# ---- LayerNorm folded into the consuming GEMM ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("rows,C", [(300, 320), (64, 64), (1000, 1280), (33, 640)])
+def test_row_stats(hip, emu, dt, rows, C):
+    T = DT[dt]
+    x = (rnd((rows, C), torch.float32, 3) * 2 + 0.7).to(T)
+    st_h = torch.full((rows, 2), float("nan"), device="cuda")
+    hip.row_stats(x.cuda(), st_h, rows=rows, C_=C, eps=1e-5)
+    st_e = torch.zeros(rows, 2)
+    emu.row_stats(x, st_e, rows=rows, C_=C, eps=1e-5)
+    close(st_h, st_e, f"row_stats {dt} {rows}x{C}", 2e-5)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("epi", ["linear", "linear_narrow", "geglu", "heads"])
+@pytest.mark.parametrize("M,C", [(300, 320), (4096, 640), (77, 64)])
+def test_gemm_layernorm_fold(hip, emu, dt, epi, M, C):
+    """rstd*(x W'^T - mean*colsum) + bias in every epilogue == LayerNorm(x) followed by the plain GEMM (checked against the op spec,
+    and the spec against torch's layer_norm)"""
+    T = DT[dt]
+    N = {"linear": 3 * C, "linear_narrow": C + 4, "geglu": 8 * C, "heads": 3 * C}[epi]
+    x = (rnd((M, C), torch.float32, 1) * 1.5 + 0.3).to(T)
+    gamma, beta = 1 + 0.2 * rnd((C,), torch.float32, 2), 0.1 * rnd((C,), torch.float32, 3)
+    w, b = rnd((N, C), torch.float32, 4, 1 / math.sqrt(C)), rnd((N,), torch.float32, 5)
+    wf = (w * gamma[None, :]).to(T)
+    bias = w @ beta + b
+    cs = wf.float().sum(dim=1)
+    st = torch.zeros(M, 2)
+    emu.row_stats(x, st, rows=M, C_=C)
+    kw = dict(M=M, N=N, K=C, lda=C, ldw=C, bias=bias)
+    if epi in ("linear", "linear_narrow"):
+        kw.update(ldo=N)
+        o_h, o_e = torch.full((M, N), float("nan"), dtype=T, device="cuda"), torch.zeros(M, N, dtype=T)
+    elif epi == "geglu":
+        kw.update(ldo=N // 2, epilogue=1)
+        o_h, o_e = torch.full((M, N // 2), float("nan"), dtype=T, device="cuda"), torch.zeros(M, N // 2, dtype=T)
+    else:
+        heads, tokens = 8, M
+        d, ld = C // heads, (M + 7) // 8 * 8
+        mk = lambda dev: [torch.zeros(1, heads, tokens, d, dtype=T, device=dev), torch.zeros(1, heads, tokens, d, dtype=T, device=dev),
+                          torch.zeros(1, heads, d, ld, dtype=T, device=dev)]
+        oh, oe = mk("cuda"), mk("cpu")
+        kw.update(epilogue=2)
+    cu = lambda t: t.cuda()
+    if epi == "heads":
+        hd = lambda outs: dict(seg_cols=C, heads=8, tokens=M, outs=outs, transposed=[0, 0, 1], ld=[0, 0, ld])
+        hip.gemm(cu(x), cu(wf), None, **dict(kw, bias=cu(bias)), heads=hd(oh), ln_stats=cu(st), ln_colsum=cu(cs))
+        emu.gemm(x, wf, None, **kw, heads=hd(oe), ln_stats=st, ln_colsum=cs)
+        for i in range(3):
+            close(oh[i], oe[i], f"ln-fold heads {dt} seg {i}", RTOL[dt])
+        ref = torch.nn.functional.layer_norm(x.float(), (C,), gamma, beta) @ w.t() + b            # what the fold stands for
+        got = oe[0].float().permute(0, 2, 1, 3).reshape(M, C)
+        assert ((got - ref[:, :C]).norm() / ref[:, :C].norm()).item() < (2e-2 if dt == "bf16" else 1e-5)
+        return
+    hip.gemm(cu(x), cu(wf), o_h, **dict(kw, bias=cu(bias)), ln_stats=cu(st), ln_colsum=cu(cs))
+    emu.gemm(x, wf, o_e, **kw, ln_stats=st, ln_colsum=cs)
+    close(o_h, o_e, f"ln-fold {epi} {dt} {M}x{N}x{C}", RTOL[dt])
+    if epi != "geglu":
+        ref = torch.nn.functional.layer_norm(x.float(), (C,), gamma, beta) @ w.t() + b
+        assert ((o_e.float() - ref).norm() / ref.norm()).item() < (2e-2 if dt == "bf16" else 1e-5)
+    with pytest.raises(Exception, match="come together"):
+        hip.gemm(cu(x), cu(wf), o_h, **dict(kw, bias=cu(bias)), ln_stats=cu(st))
