@@ -11,7 +11,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // LDS ring, not the MFMA rate, bounds this kernel, so the widest tile that still fills the chip wins.
   ns = 2;
   if (p.N % 320 == 0) {
-    if (p.M >= 16384) cfg = 5;
+    if (p.M >= 16384) cfg = (p.N == 320 && p.K <= 320 && p.mode == FYC_GEMM_PLAIN) ? 6 : 5;   // one column tile, 5 K tiles: epilogue-bound, two row tiles per 256 rows overlap better
     else if (p.M >= 4096) cfg = (p.N >= 5120) ? 5 : 6;
     else cfg = 2;
   } else if (p.N % 256 == 0 && p.M >= 16384) {

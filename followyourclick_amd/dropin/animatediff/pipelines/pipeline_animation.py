@@ -171,8 +171,7 @@ class AnimationPipeline:
         self.check_inputs(prompt, height, width, callback_steps)
         unsupported = dict(use_first_frame_condition=use_first_frame_condition, use_first_frame_condition_concat=use_first_frame_condition_concat,
                            video_scale=video_scale and video_scale > 0, use_camera_motion_condition=use_camera_motion_condition,
-                           use_text_encoder_2=use_text_encoder_2, partial_mask=use_first_frame_mask_condition_concat_image_partial_mask is not None,
-                           eta=eta != 0.0)
+                           use_text_encoder_2=use_text_encoder_2, eta=eta != 0.0)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"AnimationPipeline on the MI355X engine: {bad} not implemented (SURVEY.md 8 scope)")
@@ -182,6 +181,10 @@ class AnimationPipeline:
                              f"with use_first_frame_mask_condition_concat={concat_model} ({self.unet.engine_config.conv_in_channels} input channels)")
         if use_first_frame_mask_condition_concat and first_image_latents is None:
             raise ValueError("first_image_latents is required with use_first_frame_mask_condition_concat")
+        if use_first_frame_mask_condition_concat_image_partial_mask is not None and first_image_latents is not None:
+            # the first-frame block is multiplied by the partial mask before the concat (reference :698-699); the block is
+            # constant over the loop, so the product is taken once here
+            first_image_latents = first_image_latents * torch.as_tensor(use_first_frame_mask_condition_concat_image_partial_mask).to(first_image_latents)
 
         batch_size = 1
         if latents is not None:

@@ -319,3 +319,25 @@ def test_animation_pipeline_plain_text_to_video(dropin, golden_dir, dtype, tol_l
     assert ((out.videos - g["videos"]).norm() / g["videos"].norm()).item() < tol_vid
     with pytest.raises(ValueError, match="built"):
         pipe("x", video_length=4, height=64, width=64, use_first_frame_mask_condition_concat=True, first_image_latents=torch.zeros(1, 4, 8, 8))
+
+
+def test_partial_mask_on_first_frame_block(dropin, golden_dir):
+    """use_first_frame_mask_condition_concat_image_partial_mask: the first-frame latents block is multiplied by the mask before the
+    concat (reference pipeline_animation.py:698-699) == handing in pre-multiplied first-frame latents"""
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import AutoencoderKL, DDIMScheduler
+    g = _load(golden_dir, "pipeline_tiny.npz")
+    unet = UNet3DConditionModel(**TINY, compute_dtype=torch.float32)
+    unet.load_state_dict(W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["unet_weight_seed"])), strict=False)
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4, compute_dtype=torch.float32)
+    pipe = AnimationPipeline(vae=vae, text_encoder=stubs.StubTextEncoder(64), tokenizer=stubs.FakeTokenizer(), unet=unet,
+                             scheduler=DDIMScheduler(steps_offset=1, clip_sample=False, prediction_type="v_prediction")).to("cuda")
+    pm = (torch.rand(1, 1, 8, 8, generator=torch.Generator().manual_seed(3)) > 0.5).float().cuda()
+    kw = dict(video_length=4, height=64, width=64, num_inference_steps=2, guidance_scale=8.0, latents=g["latents"].clone(),
+              first_images_mask=g["first_images_mask"].cuda(), use_first_frame_mask_condition_concat=True, output_type="tensor")
+    a = pipe("x", first_image_latents=g["first_image_latents"].cuda(), use_first_frame_mask_condition_concat_image_partial_mask=pm, **kw).videos
+    b = pipe("x", first_image_latents=g["first_image_latents"].cuda() * pm, **kw).videos
+    c = pipe("x", first_image_latents=g["first_image_latents"].cuda(), **kw).videos
+    # run-to-run differences come from the summation order of the GroupNorm atomics only
+    assert (a - b).abs().max().item() < 2e-3 and (a - c).abs().max().item() > 2e-2

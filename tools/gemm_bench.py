@@ -19,7 +19,7 @@ SHAPES = [
 ]
 import os as _os
 STRIP = int(_os.environ.get("FYC_STRIP", "0"))   # tuning key 4: column-strip width of the tile order (-1 = row-major)
-CFGS = [(1, 2), (5, 2), (6, 2), (7, 2)]
+CFGS = [(1, 2), (2, 2), (3, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)]
 
 
 def main():
