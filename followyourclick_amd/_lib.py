@@ -86,7 +86,7 @@ class UnetInputArgs(C.Structure):
 class CfgDdimArgs(C.Structure):
     _fields_ = [("pred", vp), ("latents", vp), ("coef", vp),
                 ("B", i32), ("F", i32), ("HW", i32), ("c_latent", i32), ("ld", i32), ("cfg", i32), ("guidance", f32),
-                ("pred_type", i32), ("clip_sample", i32), ("dtype", i32)]
+                ("pred_type", i32), ("clip_sample", i32), ("dtype", i32), ("pred_single", vp), ("video_scale", f32)]
 
 
 class NchwInArgs(C.Structure):

@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256) unet_input_kernel(const float* __restrict
 template <typename T>
 __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ pred, float* __restrict__ lat,
                                                        const float* __restrict__ coef, int B, int F, int HW, int CL, int ld,
-                                                       int cfg, float guidance, int pred_type, int clip) {
+                                                       int cfg, float guidance, int pred_type, int clip,
+                                                       const T* __restrict__ single, float video_scale) {
   const float sa = coef[0], sb = coef[1], sap = coef[2], sbp = coef[3];
   const long long total = (long long)B * F * HW;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -83,7 +84,11 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ pre
     const T* pc = pred + ((long long)B * F * HW + i) * ld;         // cond half
     for (int c = 0; c < CL; ++c) {
       float v = ElemIO<T>::ld(pu + c);
-      if (cfg) v = v + guidance * (ElemIO<T>::ld(pc + c) - v);
+      if (cfg) {
+        const float u = v, cnd = ElemIO<T>::ld(pc + c);
+        if (single) { const float s1 = ElemIO<T>::ld(single + i * ld + c); v = s1 + video_scale * (u - s1) + guidance * (cnd - u); }
+        else v = u + guidance * (cnd - u);
+      }
       float* lp = lat + (((long long)b * CL + c) * F + f) * HW + p;
       const float x = *lp;
       float x0, eps;
@@ -238,11 +243,12 @@ extern "C" int fyc_cfg_ddim_step(const fyc_cfg_ddim_args* a, void* stream) {
   FYC_REQUIRE(a && a->pred && a->latents && a->coef, "fyc_cfg_ddim_step: null pointer");
   FYC_REQUIRE(a->B > 0 && a->F > 0 && a->HW > 0 && a->c_latent > 0 && a->ld >= a->c_latent, "fyc_cfg_ddim_step: bad dims");
   FYC_REQUIRE(a->pred_type >= 0 && a->pred_type <= 2, "fyc_cfg_ddim_step: pred_type %d", a->pred_type);
+  FYC_REQUIRE(a->pred_single == nullptr || a->cfg, "fyc_cfg_ddim_step: pred_single needs classifier-free guidance (cfg = 1)");
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)a->B * a->F * a->HW;
   FYC_DT(a,
-         hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample),
-         hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample));
+         hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const bf16_t*)a->pred_single, a->video_scale),
+         hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const float*)a->pred_single, a->video_scale));
   FYC_CHECK_LAUNCH("fyc_cfg_ddim_step");
   return 0;
 }

@@ -170,7 +170,7 @@ class AnimationPipeline:
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
         unsupported = dict(use_first_frame_condition=use_first_frame_condition, use_first_frame_condition_concat=use_first_frame_condition_concat,
-                           video_scale=video_scale and video_scale > 0, use_camera_motion_condition=use_camera_motion_condition,
+                           use_camera_motion_condition=use_camera_motion_condition,
                            use_text_encoder_2=use_text_encoder_2, eta=eta != 0.0)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -234,7 +234,8 @@ class AnimationPipeline:
         latents_out = sampler.sample(latents, text_embeddings, num_inference_steps, guidance_scale,
                                      first_image_latents=first_image_latents, first_images_mask=mask_final,
                                      fps=as_list(fps_tensor) if use_fps_condition else None,
-                                     flow=as_list(flow_control) if use_fps_condition else None, ip_tokens=ip_tokens, callback=cb)
+                                     flow=as_list(flow_control) if use_fps_condition else None, ip_tokens=ip_tokens, callback=cb,
+                                     video_scale=float(video_scale or 0.0))
         if hasattr(bar, "close"):
             bar.close()
 

@@ -32,7 +32,7 @@ class DDIMSampler:
     @torch.no_grad()
     def prepare(self, text_embeddings: Tensor, num_steps: int, batch: int, guidance_scale: float,
                 fps: Optional[Sequence[float]] = None, flow: Optional[Sequence[float]] = None,
-                ip_tokens: Optional[Tensor] = None) -> dict:
+                ip_tokens: Optional[Tensor] = None, video_scale: float = 0.0, frames: int = 0) -> dict:
         """text_embeddings: (cfg*batch, 77, D) with the unconditional half first (reference :397)."""
         u = self.unet
         cfg_on = guidance_scale > 1.0
@@ -49,11 +49,22 @@ class DDIMSampler:
                 v = v * batch
             return v * 2 if cfg_on else v
 
+        extra = {}
+        if video_scale > 0 and cfg_on:
+            # `video_scale` (reference :738-760): every frame is also denoised on its own, as a one-frame clip.  The reference
+            # builds that call's text batch as cat([text_embeddings] * f).chunk(2)[0], i.e. single-frame clip j gets
+            # text_embeddings[j mod 2B] - for B = 1 the frames alternate between the negative and the positive prompt - and
+            # passes no fps / flow conditioning; both are reproduced as they are.
+            nf = batch * frames
+            idx = torch.arange(nf) % (2 * batch)
+            u.prepare_context(text_embeddings[idx], None)
+            _, temb_s = u.prepare_time_embeddings(ts.tolist(), None, None, nf)
+            extra = dict(ctx_single=u.ctx_cache, temb_single=temb_s.reshape(num_steps, nf, -1), video_scale=float(video_scale))
         u.prepare_context(text_embeddings, ip_tokens)
         emb, temb = u.prepare_time_embeddings(ts.tolist(), dup(fps), dup(flow), beff)
         coef = self.tables.coefficient_table(num_steps).to(u.device)
         return dict(timesteps=ts, temb=temb.reshape(num_steps, beff, -1), coef=coef, cfg=cfg_on, beff=beff,
-                    guidance=float(guidance_scale), steps=num_steps, batch=batch)
+                    guidance=float(guidance_scale), steps=num_steps, batch=batch, ctx_main=u.ctx_cache, **extra)
 
     @torch.no_grad()
     def step(self, st: dict, i: int, latents: Tensor, first_image_latents: Optional[Tensor], mask: Optional[Tensor]) -> None:
@@ -75,15 +86,21 @@ class DDIMSampler:
             for d in range(dupn):
                 o.nchw_to_nhwc(frames, x[d * n:(d + 1) * n], N=B * F, C_=CL, HW=H * W, c_pad=cp, scale=1.0)
         pred = u.forward(x, st["temb"][i], dupn * B, F, H, W)
+        single = None
+        if "ctx_single" in st:      # per-frame unconditional pass: the first (unconditional) half of x as B*F one-frame clips
+            u.ctx_cache = st["ctx_single"]
+            single = u.forward(x[: B * F * H * W], st["temb_single"][i], B * F, 1, H, W)
+            u.ctx_cache = st["ctx_main"]
         o.cfg_ddim_step(pred, latents, st["coef"][i], B=B, F=F, HW=H * W, c_latent=CL, ld=pred.shape[1], cfg=st["cfg"],
-                        guidance=st["guidance"], pred_type=self.tables.pred_type, clip_sample=self.clip_sample)
+                        guidance=st["guidance"], pred_type=self.tables.pred_type, clip_sample=self.clip_sample,
+                        pred_single=single, video_scale=st.get("video_scale", 0.0))
 
     @torch.no_grad()
     def sample(self, latents: Tensor, text_embeddings: Tensor, num_steps: int, guidance_scale: float,
                first_image_latents: Optional[Tensor] = None, first_images_mask: Optional[Tensor] = None,
                fps: Optional[Sequence[float]] = None, flow: Optional[Sequence[float]] = None,
                ip_tokens: Optional[Tensor] = None, callback: Optional[Callable] = None, callback_steps: int = 1,
-               use_graph: Optional[bool] = None) -> Tensor:
+               use_graph: Optional[bool] = None, video_scale: float = 0.0) -> Tensor:
         """use_graph: replay steps 1..n-1 from one captured hipGraph (None = the FYC_HIPGRAPH environment switch, default off).
         Measured on MI355X it buys nothing: at cfg2 the loop is GPU-bound (56 ms of kernels per step) and even the 2-D
         one-frame case (13.7 ms / step, ~700 small kernels) is bound by the kernels' own execution, not by launch overhead
@@ -96,7 +113,7 @@ class DDIMSampler:
         if first_images_mask is not None:
             # mask for ALL frames = clamp(first_images_mask[:, :, 0:1]) (reference :632-635)
             mask = first_images_mask.to(u.device, torch.float32)[:, :, 0].reshape(B, 1, H * W).contiguous()
-        st = self.prepare(text_embeddings, num_steps, B, guidance_scale, fps, flow, ip_tokens)
+        st = self.prepare(text_embeddings, num_steps, B, guidance_scale, fps, flow, ip_tokens, video_scale=video_scale, frames=F)
         ts = st["timesteps"].tolist()
         if use_graph is None:
             use_graph = os.environ.get("FYC_HIPGRAPH", "0") == "1"

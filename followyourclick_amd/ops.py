@@ -206,8 +206,12 @@ class HipOps:
         self._call("fyc_unet_input", a)
 
     def cfg_ddim_step(self, pred: Tensor, latents: Tensor, coef: Tensor, *, B: int, F: int, HW: int, c_latent: int,
-                      ld: int, cfg: bool, guidance: float, pred_type: int, clip_sample: bool) -> None:
+                      ld: int, cfg: bool, guidance: float, pred_type: int, clip_sample: bool,
+                      pred_single: Optional[Tensor] = None, video_scale: float = 0.0) -> None:
         a = L.CfgDdimArgs()
+        if pred_single is not None and pred_single.dtype != pred.dtype:
+            raise TypeError("cfg_ddim_step: pred_single dtype differs from pred")
+        a.pred_single, a.video_scale = _p(pred_single), video_scale
         a.pred, a.latents, a.coef = _p(pred), _f32(latents, "latents"), _f32(coef, "coef")
         a.B, a.F, a.HW, a.c_latent, a.ld, a.cfg, a.guidance = B, F, HW, c_latent, ld, int(cfg), guidance
         a.pred_type, a.clip_sample, a.dtype = pred_type, int(clip_sample), _dt(pred)

@@ -208,6 +208,9 @@ typedef struct {
   int32_t B, F, HW, c_latent, ld, cfg; float guidance;
   int32_t pred_type, clip_sample;
   int32_t dtype;
+  /* optional third prediction (pipeline_animation.py:738-760, `video_scale > 0`): per-frame ("single frame") unconditional
+   * prediction [B*F][HW][ld];  v = single + video_scale * (uncond - single) + guidance * (cond - uncond).  NULL = plain CFG. */
+  const void* pred_single; float video_scale;
 } fyc_cfg_ddim_args;
 int fyc_cfg_ddim_step(const fyc_cfg_ddim_args* a, void* stream);
 

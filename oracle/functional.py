@@ -458,7 +458,7 @@ def denoise(sd: SD, cfg: UNetConfig, sched: DDIMConfig, latents: Tensor, text_em
             guidance_scale: float, first_image_latents: Optional[Tensor] = None,
             first_images_mask: Optional[Tensor] = None, fps: Optional[Tensor] = None,
             flow: Optional[Tensor] = None, ip_tokens: Optional[Tensor] = None,
-            callback=None) -> Tensor:
+            callback=None, video_scale: float = 0.0) -> Tensor:
     """The DDIM loop of AnimationPipeline.__call__ with use_first_frame_mask_condition_concat
     and classifier-free guidance: text_embeddings is cat[uncond, cond] (2B,77,D)
     (pipeline_animation.py:397, 690-773)."""
@@ -473,9 +473,21 @@ def denoise(sd: SD, cfg: UNetConfig, sched: DDIMConfig, latents: Tensor, text_em
             x = torch.cat([x] * 2)
         dup = (lambda v: torch.cat([v] * 2) if (cfg_on and v is not None) else v)
         pred = unet3d_forward(sd, cfg, x, torch.tensor(t), text_embeddings, dup(fps), dup(flow), ip_tokens)
+        single = None
+        if video_scale > 0:
+            # per-frame prediction (pipeline_animation.py:738-752): frames as one-frame clips; the text batch is
+            # cat([text_embeddings] * f).chunk(2)[0] exactly as the reference builds it; no fps / flow conditioning
+            b2, c_, f_, h_, w_ = x.shape
+            xs = x.permute(0, 2, 1, 3, 4).reshape(b2 * f_, c_, h_, w_).unsqueeze(2).chunk(2, dim=0)[0]
+            ts_ = torch.cat([text_embeddings] * f_, dim=0).chunk(2, dim=0)[0]
+            ps = unet3d_forward(sd, cfg, xs, torch.tensor(t), ts_)
+            single = ps.squeeze(2).reshape(b2 // 2, f_, -1, h_, w_).permute(0, 2, 1, 3, 4)
         if cfg_on:
             u, c = pred.chunk(2)
-            pred = u + guidance_scale * (c - u)
+            if single is not None:
+                pred = single + video_scale * (u - single) + guidance_scale * (c - u)
+            else:
+                pred = u + guidance_scale * (c - u)
         latents = ddim_step(sched, abar, num_steps, pred, t, latents)
         if callback is not None:
             callback(i, t, latents)

@@ -40,9 +40,13 @@ def main():
                negative_prompt="blurry", latents=lat.clone(), callback=lambda i, t, l: traj.append(l.clone()), callback_steps=1)
     with torch.no_grad():
         text_emb = pipe._encode_prompt(["a corgi waving its tail"], "cpu", 1, True, ["blurry"])
+    # video_scale > 0: extra per-frame unconditional UNet pass and three-way guidance (scripts/inference_org.py --video_scale)
+    traj_vs = []
+    pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=3, guidance_scale=7.5,
+         negative_prompt="blurry", latents=lat.clone(), video_scale=0.7, callback=lambda i, t, l: traj_vs.append(l.clone()), callback_steps=1)
     np.savez_compressed(os.path.join(OUT, "pipeline_tiny_t2v.npz"), latents=lat.numpy(), text_embeddings=text_emb.numpy(),
                         trajectory=torch.stack(traj).numpy(), videos=out.videos.numpy(), unet_weight_seed=np.int64(8),
-                        vae_weight_seed=np.int64(3))
+                        vae_weight_seed=np.int64(3), trajectory_video_scale=torch.stack(traj_vs).numpy(), video_scale=np.float32(0.7))
     print("pipeline_tiny_t2v.npz", os.path.getsize(os.path.join(OUT, "pipeline_tiny_t2v.npz")))
 
 

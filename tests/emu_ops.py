@@ -222,10 +222,14 @@ class EmuOps:
         out = torch.cat([out] * cfg_dup, dim=0)
         _flat(x)[: out.numel()].reshape(out.shape).copy_(out.to(x.dtype))
 
-    def cfg_ddim_step(self, pred, latents, coef, *, B, F, HW, c_latent, ld, cfg, guidance, pred_type, clip_sample):
+    def cfg_ddim_step(self, pred, latents, coef, *, B, F, HW, c_latent, ld, cfg, guidance, pred_type, clip_sample,
+                      pred_single=None, video_scale=0.0):
         n = (2 if cfg else 1) * B * F * HW
         p = _flat(pred)[: n * ld].reshape(-1, B, F, HW, ld)[..., :c_latent].float()
         v = p[0] + guidance * (p[1] - p[0]) if cfg else p[0]
+        if pred_single is not None:
+            s1 = _flat(pred_single)[: B * F * HW * ld].reshape(B, F, HW, ld)[..., :c_latent].float()
+            v = s1 + video_scale * (p[0] - s1) + guidance * (p[1] - p[0])
         v = v.permute(0, 3, 1, 2)                                  # B C F HW
         x = latents.reshape(B, c_latent, F, HW)
         sa, sb, sap, sbp = [float(c) for c in coef.reshape(-1)[:4]]

@@ -319,6 +319,13 @@ def test_animation_pipeline_plain_text_to_video(dropin, golden_dir, dtype, tol_l
     assert ((out.videos - g["videos"]).norm() / g["videos"].norm()).item() < tol_vid
     with pytest.raises(ValueError, match="built"):
         pipe("x", video_length=4, height=64, width=64, use_first_frame_mask_condition_concat=True, first_image_latents=torch.zeros(1, 4, 8, 8))
+    # --video_scale of scripts/inference_org.py: per-frame unconditional pass + three-way guidance
+    traj = []
+    pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=3, guidance_scale=7.5, negative_prompt="blurry",
+         latents=g["latents"].clone(), video_scale=float(g["video_scale"]), callback=lambda i, t, l: traj.append(l.clone().cpu()), callback_steps=1)
+    traj, ref = torch.stack(traj), g["trajectory_video_scale"]
+    err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert err.max().item() < tol_lat, err
 
 
 def test_partial_mask_on_first_frame_block(dropin, golden_dir):

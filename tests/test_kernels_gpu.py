@@ -471,3 +471,21 @@ def test_gemm_layernorm_fold(hip, emu, dt, epi, M, C):
         assert ((o_e.float() - ref).norm() / ref.norm()).item() < (2e-2 if dt == "bf16" else 1e-5)
     with pytest.raises(Exception, match="come together"):
         hip.gemm(cu(x), cu(wf), o_h, **dict(kw, bias=cu(bias)), ln_stats=cu(st))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_ddim_three_way_guidance(hip, emu, dt):
+    """single + video_scale*(uncond - single) + guidance*(cond - uncond) (reference pipeline_animation.py:754-760)"""
+    T = DT[dt]
+    B, F, HW, CL, ld = 2, 3, 20, 4, 8
+    pred, single = rnd((2 * B * F * HW, ld), T, 1), rnd((B * F * HW, ld), T, 2)
+    lat = rnd((B, CL, F, HW), torch.float32, 3)
+    coef = torch.tensor([0.8, 0.6, 0.9, 0.43589])
+    kw = dict(B=B, F=F, HW=HW, c_latent=CL, ld=ld, cfg=True, guidance=7.5, pred_type=0, clip_sample=False, video_scale=0.7)
+    l_h = lat.clone().cuda()
+    hip.cfg_ddim_step(pred.cuda(), l_h, coef.cuda(), pred_single=single.cuda(), **kw)
+    l_e = lat.clone()
+    emu.cfg_ddim_step(pred, l_e, coef, pred_single=single, **kw)
+    close(l_h, l_e, f"three-way guidance {dt}", 1e-5)
+    with pytest.raises(Exception, match="needs classifier-free"):
+        hip.cfg_ddim_step(pred.cuda(), l_h, coef.cuda(), pred_single=single.cuda(), **dict(kw, cfg=False))

@@ -176,3 +176,18 @@ def test_pipeline_trajectory_plain_text_to_video(golden_dir):
     traj = torch.stack(traj)          # random weights + epsilon prediction: latents grow to |x| ~ 20, so compare relatively
     err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
     assert err.max().item() < 2e-5, err
+
+
+def test_pipeline_trajectory_video_scale(golden_dir):
+    """video_scale > 0 (scripts/inference_org.py --video_scale): extra per-frame pass with the reference's text-batch construction"""
+    g = _load(golden_dir, "pipeline_tiny_t2v.npz")
+    cfg = Fn.tiny_unet_config(use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["unet_weight_seed"]))
+    sched = Fn.DDIMConfig(prediction_type="epsilon", rescale_betas_zero_snr=False)
+    traj = []
+    Fn.denoise(sd, cfg, sched, g["latents"], g["text_embeddings"], 3, 7.5, callback=lambda i, t, l: traj.append(l.clone()),
+               video_scale=float(g["video_scale"]))
+    traj = torch.stack(traj)
+    ref = g["trajectory_video_scale"]
+    err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert err.max().item() < 2e-5, err
