@@ -4,10 +4,10 @@ sys.path.insert(0, "/root/repo")
 from followyourclick_amd.engine import UNet3DConfig
 from followyourclick_amd.engine.unet3d import UNet3DEngine
 from followyourclick_amd.engine.weights import pack_unet
-from oracle import functional as Fn, weights as W
+from followyourclick_amd.engine.schema import random_state_dict, unet_schema
 t0 = time.time()
 cfg = UNet3DConfig()
-sd = W.make_weights(W.unet_state_shapes(Fn.UNetConfig()), 0)
+sd = random_state_dict(unet_schema(cfg), seed=0)
 print("weights", time.time() - t0)
 eng = UNet3DEngine(pack_unet(sd, cfg, torch.bfloat16, "cuda:0"))
 print("packed", time.time() - t0)
