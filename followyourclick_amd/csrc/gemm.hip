@@ -116,6 +116,12 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.colc = (a->dtype == FYC_BF16 && a->epilogue != FYC_EPI_GEGLU && a->N % 4 == 0 && ((uintptr_t)a->bias % 16) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0 &&
             (a->rowbias == nullptr || (p.ldrb % 4 == 0 && ((uintptr_t)a->rowbias % 16) == 0))) ? 1 : 0;
   if (p.wide) p.colc = 1;
+  if (a->dtype == FYC_BF16 && a->epilogue == FYC_EPI_HEADS && p.colc && g_fyc_tuning[6] == 0 && g_fyc_tuning[7] == 0 && p.head_dim % 8 == 0 && a->tokens % 16 == 0 && a->N % 8 == 0) {
+    bool ok = true;                                   // wide head-split epilogue: 16-byte runs into every segment
+    for (int s = 0; s < a->N / a->seg_cols; ++s)
+      ok = ok && ((uintptr_t)a->seg_out[s] % 16) == 0 && (!a->seg_transposed[s] || p.seg_ld[s] % 8 == 0);
+    p.wide = ok ? 1 : 0;
+  }
   p.rb_tile = 0;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, (p.N % 128 == 0) ? 1 : 2, st);

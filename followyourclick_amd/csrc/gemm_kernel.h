@@ -138,6 +138,80 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
   // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
   const T* R = reinterpret_cast<const T*>(p.residual);
+  if (EPI == FYC_EPI_HEADS && sizeof(T) == 2 && p.wide) {
+    // Wide head-split epilogue.  The plain path stores what a lane holds - 4 consecutive channels (8 B) for q / k and four
+    // single bf16 values a whole row pitch apart for the transposed V^T.  Here each wave stages its f32 tile through LDS
+    // (as the linear epilogue does) and then writes q / k as 16-byte runs along the head dimension and V^T as 16-byte runs
+    // along the TOKEN axis (8 consecutive tokens of one V^T row).  Host guarantees: head_dim % 8 == 0, tokens % 16 == 0,
+    // transposed row pitches % 8 == 0, 16-byte aligned segment bases.
+    constexpr int JG = (WTN + 1) / 2;
+    constexpr int PITCH = JG * 64 + 16;
+    static_assert(WGM * WGN * 16 * PITCH + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
+    __builtin_amdgcn_s_barrier();
+    char* stg = stg_stage + wave * (16 * PITCH);
+    float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * 16 * PITCH);
+    stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+    const int n_w0 = tile_n * BN + wn * WTN * 16, nl_w0 = wn * WTN * 16;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      const int m0 = tile_m * BM + (wm * WTM + i) * 16;            // first of the 16 token rows of this block (same batch element)
+      float ln_mu = 0.f, ln_rs = 1.f;
+      if (LN && p.ln_stats && m0 + r16 < p.M) { const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2ll * (m0 + r16)); ln_mu = ms.x; ln_rs = ms.y; }
+      const int b = m0 / p.tokens, tok0 = m0 - b * p.tokens;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j0 = h * JG;
+        const int nj = (WTN - j0 < JG) ? (WTN - j0) : JG;
+        if (nj <= 0) continue;
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) {
+          const int jo = j0 + jj;
+          if (jo >= WTN) continue;
+          const int nl = nl_w0 + jo * 16 + g * 4;
+          f32x4 v = acc[i][jo];
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(colc + BN + nl), b4 = *reinterpret_cast<const f32x4*>(colc + nl);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ((LN && p.ln_stats ? ln_rs * (v[r] - ln_mu * s4[r]) : v[r]) + b4[r]) * p.out_scale;
+          *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n0 = n_w0 + j0 * 16;                               // first GEMM column of this pass
+        if (m0 < p.M) {
+          // (1) q / k style segments: 8 consecutive head-dim elements of one token
+          const int cpr = nj * 2;
+          for (int c = lane; c < 16 * cpr; c += 64) {
+            const int row = c / cpr, ch = c - row * cpr;
+            const int n = n0 + ch * 8;
+            if (n >= p.N) continue;
+            const int seg = n / p.seg_cols, cs = n - seg * p.seg_cols;
+            if (p.seg_transposed[seg]) continue;
+            const int hh = cs / p.head_dim, di = cs - hh * p.head_dim;
+            float v8[8];
+            *reinterpret_cast<f32x4*>(v8) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
+            *reinterpret_cast<f32x4*>(v8 + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
+            T* S = reinterpret_cast<T*>(p.seg_out[seg]);
+            store8<T>(S + ((long long)(b * p.heads + hh) * p.tokens + tok0 + row) * p.head_dim + di, v8);
+          }
+          // (2) transposed segments (V^T [b*H][d][ld]): 8 consecutive tokens of one head-dim row
+          for (int u = lane; u < nj * 32; u += 64) {
+            const int col = u >> 1, half = u & 1;
+            const int n = n0 + col;
+            if (n >= p.N) continue;
+            const int seg = n / p.seg_cols, cs = n - seg * p.seg_cols;
+            if (!p.seg_transposed[seg]) continue;
+            const int hh = cs / p.head_dim, di = cs - hh * p.head_dim;
+            float v8[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v8[r] = *reinterpret_cast<const float*>(stg + (half * 8 + r) * PITCH + col * 4);
+            T* S = reinterpret_cast<T*>(p.seg_out[seg]);
+            store8<T>(S + ((long long)(b * p.heads + hh) * p.head_dim + di) * p.seg_ld[seg] + tok0 + half * 8, v8);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    return;
+  }
   if (EPI != FYC_EPI_HEADS && sizeof(T) == 2 && p.wide) {
     // Wide epilogue (bf16 linear / GEGLU): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
     // 32-B row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
