@@ -169,7 +169,7 @@ class AnimationPipeline:
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
-        unsupported = dict(use_first_frame_condition=use_first_frame_condition, use_first_frame_condition_concat=use_first_frame_condition_concat,
+        unsupported = dict(use_first_frame_condition_concat=use_first_frame_condition_concat,
                            use_camera_motion_condition=use_camera_motion_condition,
                            use_text_encoder_2=use_text_encoder_2, eta=eta != 0.0)
         bad = [k for k, v in unsupported.items() if v]
@@ -179,8 +179,10 @@ class AnimationPipeline:
         if use_first_frame_mask_condition_concat != concat_model:
             raise ValueError(f"use_first_frame_mask_condition_concat={use_first_frame_mask_condition_concat} but the UNet was built "
                              f"with use_first_frame_mask_condition_concat={concat_model} ({self.unet.engine_config.conv_in_channels} input channels)")
-        if use_first_frame_mask_condition_concat and first_image_latents is None:
-            raise ValueError("first_image_latents is required with use_first_frame_mask_condition_concat")
+        if (use_first_frame_mask_condition_concat or use_first_frame_condition) and first_image_latents is None:
+            raise ValueError("first_image_latents is required with use_first_frame_mask_condition_concat / use_first_frame_condition")
+        if use_first_frame_condition and use_first_frame_mask_condition_concat:
+            raise ValueError("use_first_frame_condition and use_first_frame_mask_condition_concat are alternatives (reference :691-693)")
         if use_first_frame_mask_condition_concat_image_partial_mask is not None and first_image_latents is not None:
             # the first-frame block is multiplied by the partial mask before the concat (reference :698-699); the block is
             # constant over the loop, so the product is taken once here
@@ -235,7 +237,7 @@ class AnimationPipeline:
                                      first_image_latents=first_image_latents, first_images_mask=mask_final,
                                      fps=as_list(fps_tensor) if use_fps_condition else None,
                                      flow=as_list(flow_control) if use_fps_condition else None, ip_tokens=ip_tokens, callback=cb,
-                                     video_scale=float(video_scale or 0.0))
+                                     video_scale=float(video_scale or 0.0), first_frame_condition=bool(use_first_frame_condition))
         if hasattr(bar, "close"):
             bar.close()
 

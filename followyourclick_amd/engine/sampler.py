@@ -32,7 +32,8 @@ class DDIMSampler:
     @torch.no_grad()
     def prepare(self, text_embeddings: Tensor, num_steps: int, batch: int, guidance_scale: float,
                 fps: Optional[Sequence[float]] = None, flow: Optional[Sequence[float]] = None,
-                ip_tokens: Optional[Tensor] = None, video_scale: float = 0.0, frames: int = 0) -> dict:
+                ip_tokens: Optional[Tensor] = None, video_scale: float = 0.0, frames: int = 0,
+                first_frame_condition: bool = False) -> dict:
         """text_embeddings: (cfg*batch, 77, D) with the unconditional half first (reference :397)."""
         u = self.unet
         cfg_on = guidance_scale > 1.0
@@ -60,6 +61,14 @@ class DDIMSampler:
             u.prepare_context(text_embeddings[idx], None)
             _, temb_s = u.prepare_time_embeddings(ts.tolist(), None, None, nf)
             extra = dict(ctx_single=u.ctx_cache, temb_single=temb_s.reshape(num_steps, nf, -1), video_scale=float(video_scale))
+        if first_frame_condition:
+            # `use_first_frame_condition` (reference :691-692; unet.py:523-524): frame 0 of the latents is pinned to the clean
+            # first-frame latents and every ResNet gives that frame the embedding of timestep 0
+            if fps is not None:
+                raise ValueError("use_first_frame_condition cannot be combined with fps conditioning (the reference's embeddings "
+                                 "have mismatching batch sizes there)")
+            _, temb0 = u.prepare_time_embeddings([0], None, None, 1)
+            extra["temb_first"] = temb0
         u.prepare_context(text_embeddings, ip_tokens)
         emb, temb = u.prepare_time_embeddings(ts.tolist(), dup(fps), dup(flow), beff)
         coef = self.tables.coefficient_table(num_steps).to(u.device)
@@ -74,6 +83,8 @@ class DDIMSampler:
         cp = pad_channels(u.cfg.conv_in_channels)
         dupn = 2 if st["cfg"] else 1
         x = u.new(dupn * B * F * H * W, cp)
+        if "temb_first" in st:
+            latents[:, :, 0] = first_image_latents.reshape(B, CL, H, W)
         if u.cfg.use_first_frame_mask_condition_concat:
             o.unet_input(latents, mask, first_image_latents, x, B=B, F=F, HW=H * W, c_latent=CL, c_pad=cp, cfg_dup=dupn,
                          mask_frames=1)
@@ -85,7 +96,7 @@ class DDIMSampler:
             frames = latents.permute(0, 2, 1, 3, 4).reshape(B * F, CL, H * W).contiguous()
             for d in range(dupn):
                 o.nchw_to_nhwc(frames, x[d * n:(d + 1) * n], N=B * F, C_=CL, HW=H * W, c_pad=cp, scale=1.0)
-        pred = u.forward(x, st["temb"][i], dupn * B, F, H, W)
+        pred = u.forward(x, st["temb"][i], dupn * B, F, H, W, temb_first=st.get("temb_first"))
         single = None
         if "ctx_single" in st:      # per-frame unconditional pass: the first (unconditional) half of x as B*F one-frame clips
             u.ctx_cache = st["ctx_single"]
@@ -100,7 +111,7 @@ class DDIMSampler:
                first_image_latents: Optional[Tensor] = None, first_images_mask: Optional[Tensor] = None,
                fps: Optional[Sequence[float]] = None, flow: Optional[Sequence[float]] = None,
                ip_tokens: Optional[Tensor] = None, callback: Optional[Callable] = None, callback_steps: int = 1,
-               use_graph: Optional[bool] = None, video_scale: float = 0.0) -> Tensor:
+               use_graph: Optional[bool] = None, video_scale: float = 0.0, first_frame_condition: bool = False) -> Tensor:
         """use_graph: replay steps 1..n-1 from one captured hipGraph (None = the FYC_HIPGRAPH environment switch, default off).
         Measured on MI355X it buys nothing: at cfg2 the loop is GPU-bound (56 ms of kernels per step) and even the 2-D
         one-frame case (13.7 ms / step, ~700 small kernels) is bound by the kernels' own execution, not by launch overhead
@@ -113,7 +124,8 @@ class DDIMSampler:
         if first_images_mask is not None:
             # mask for ALL frames = clamp(first_images_mask[:, :, 0:1]) (reference :632-635)
             mask = first_images_mask.to(u.device, torch.float32)[:, :, 0].reshape(B, 1, H * W).contiguous()
-        st = self.prepare(text_embeddings, num_steps, B, guidance_scale, fps, flow, ip_tokens, video_scale=video_scale, frames=F)
+        st = self.prepare(text_embeddings, num_steps, B, guidance_scale, fps, flow, ip_tokens, video_scale=video_scale, frames=F,
+                          first_frame_condition=first_frame_condition)
         ts = st["timesteps"].tolist()
         if use_graph is None:
             use_graph = os.environ.get("FYC_HIPGRAPH", "0") == "1"

@@ -180,7 +180,9 @@ class UNet3DEngine(EngineBase):
         cin_p = r.c1_w.shape[1] // 9
         h = self.group_norm(x, r.n1_g, r.n1_b, rows, cin_p, rpb, self.cfg.norm_eps, True)
         tb = temb[:, r.temb_off:]  # view: row pitch stays temb_total (ldrb)
-        h = self.conv(h, r.c1_w, r.c1_b, frames, g["H"], g["W"], rowbias=tb, rpb=rpb, ldrb=temb.shape[1])
+        # time-embedding row per clip, or per (clip, frame) when frame 0 carries the timestep-0 embedding (use_first_frame_condition)
+        h = self.conv(h, r.c1_w, r.c1_b, frames, g["H"], g["W"], rowbias=tb, rpb=g["H"] * g["W"] if g.get("temb_per_frame") else rpb,
+                      ldrb=temb.shape[1])
         h = self.group_norm(h, r.n2_g, r.n2_b, rows, r.cout, rpb, self.cfg.norm_eps, True)
         sc = self.lin(x, r.sc_w, rows, bias=r.sc_b) if r.sc_w is not None else x
         return self.conv(h, r.c2_w, r.c2_b, frames, g["H"], g["W"], residual=sc)
@@ -270,12 +272,18 @@ class UNet3DEngine(EngineBase):
         return tok
 
     # ---- forward -------------------------------------------------------------------------------
-    def forward(self, x: Tensor, temb: Tensor, B: int, F: int, H: int, W: int) -> Tensor:
+    def forward(self, x: Tensor, temb: Tensor, B: int, F: int, H: int, W: int, temb_first: Optional[Tensor] = None) -> Tensor:
         """x: channels-last model input [B*F*H*W][pad64(conv_in_channels)] (B already includes the CFG
-        duplicate); temb: [B, temb_total] f32 rows of the current step.  Returns [B*F*H*W][out_channels]."""
+        duplicate); temb: [B, temb_total] f32 rows of the current step.  Returns [B*F*H*W][out_channels].
+        temb_first ([1, temb_total], optional): time-embedding row of timestep 0 that every ResNet adds to FRAME 0 instead of
+        the clip's own row (reference `use_first_frame_condition`, unet.py:523-524, resnet.py:310-317)."""
         assert self.ctx_cache is not None, "call prepare_context() first"
         cfg, P, o = self.cfg, self.P, self.ops
         g = dict(B=B, F=F, H=H, W=W, rows=B * F * H * W)
+        if temb_first is not None:
+            temb = temb.repeat_interleave(F, dim=0)            # one row per (clip, frame)
+            temb[0::F] = temb_first
+            g["temb_per_frame"] = True
         frames = B * F
         x = self.conv(x, P.conv_in_w, P.conv_in_b, frames, H, W)
         if cfg.use_first_frame_condition_concat:

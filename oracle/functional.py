@@ -164,7 +164,13 @@ def resnet_block3d(sd: SD, p: str, x: Tensor, emb: Tensor, groups: int, eps: flo
     h = F.silu(group_norm_cross_frame(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], groups, eps))
     h = conv_frames(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"])
     temb = _lin(sd, p + ".time_emb_proj", F.silu(emb))
-    h = h + temb[:, :, None, None, None]
+    if temb.shape[0] == h.shape[0] + 1:
+        # use_first_frame_condition (resnet.py:310-317): the extra last row is the embedding of timestep 0 and goes to frame 0,
+        # frames 1.. get the row of their own batch element
+        h = h + temb[:-1, :, None, None, None]
+        h[:, :, 0] = h[:, :, 0] - temb[:-1, :, None, None] + temb[-1:, :, None, None]
+    else:
+        h = h + temb[:, :, None, None, None]
     h = F.silu(group_norm_cross_frame(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], groups, eps))
     h = conv_frames(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"])
     if (p + ".conv_shortcut.weight") in sd:
@@ -306,7 +312,8 @@ def _has_motion(cfg: UNetConfig, res: int) -> bool:
 
 def unet3d_forward(sd: SD, cfg: UNetConfig, sample: Tensor, timestep: Tensor, ctx: Tensor,
                    fps: Optional[Tensor] = None, flow: Optional[Tensor] = None,
-                   ip_tokens: Optional[Tensor] = None, taps: Optional[dict] = None) -> Tensor:
+                   ip_tokens: Optional[Tensor] = None, taps: Optional[dict] = None,
+                   use_first_frame_condition: bool = False) -> Tensor:
     """UNet3DConditionModel.forward (unet.py:422-672).
 
     sample: (B, conv_in_channels, F, h, w); timestep: scalar/(B,) int; ctx: (B, 77, D);
@@ -315,6 +322,8 @@ def unet3d_forward(sd: SD, cfg: UNetConfig, sample: Tensor, timestep: Tensor, ct
     ``taps``: optional dict that receives intermediate activations by name."""
     B = sample.shape[0]
     t = timestep.reshape(-1).expand(B) if timestep.dim() <= 1 else timestep
+    if use_first_frame_condition:      # unet.py:523-524: one extra embedding row for timestep 0 (the clean first frame)
+        t = torch.cat([t, torch.zeros(1, dtype=t.dtype)])
     emb = unet_time_embedding(sd, cfg, t, fps, flow, sample.dtype)
     if cfg.use_ip_cross_attention:
         ctx = torch.cat([ctx, ip_tokens], dim=1)
@@ -458,21 +467,26 @@ def denoise(sd: SD, cfg: UNetConfig, sched: DDIMConfig, latents: Tensor, text_em
             guidance_scale: float, first_image_latents: Optional[Tensor] = None,
             first_images_mask: Optional[Tensor] = None, fps: Optional[Tensor] = None,
             flow: Optional[Tensor] = None, ip_tokens: Optional[Tensor] = None,
-            callback=None, video_scale: float = 0.0) -> Tensor:
+            callback=None, video_scale: float = 0.0, use_first_frame_condition: bool = False) -> Tensor:
     """The DDIM loop of AnimationPipeline.__call__ with use_first_frame_mask_condition_concat
     and classifier-free guidance: text_embeddings is cat[uncond, cond] (2B,77,D)
     (pipeline_animation.py:397, 690-773)."""
     abar = ddim_alphas_cumprod(sched)
     cfg_on = guidance_scale > 1.0
     for i, t in enumerate(ddim_timesteps(sched, num_steps).tolist()):
-        if cfg.use_first_frame_mask_condition_concat:
+        if use_first_frame_condition:      # pipeline_animation.py:691-692: frame 0 is pinned to the clean first-frame latents
+            latents = latents.clone()
+            latents[:, :, 0] = first_image_latents
+            x = latents
+        elif cfg.use_first_frame_mask_condition_concat:
             x = build_model_input(latents, first_image_latents, first_images_mask)
         else:
             x = latents
         if cfg_on:
             x = torch.cat([x] * 2)
         dup = (lambda v: torch.cat([v] * 2) if (cfg_on and v is not None) else v)
-        pred = unet3d_forward(sd, cfg, x, torch.tensor(t), text_embeddings, dup(fps), dup(flow), ip_tokens)
+        pred = unet3d_forward(sd, cfg, x, torch.tensor(t), text_embeddings, dup(fps), dup(flow), ip_tokens,
+                              use_first_frame_condition=use_first_frame_condition)
         single = None
         if video_scale > 0:
             # per-frame prediction (pipeline_animation.py:738-752): frames as one-frame clips; the text batch is

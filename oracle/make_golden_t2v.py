@@ -44,7 +44,14 @@ def main():
     traj_vs = []
     pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=3, guidance_scale=7.5,
          negative_prompt="blurry", latents=lat.clone(), video_scale=0.7, callback=lambda i, t, l: traj_vs.append(l.clone()), callback_steps=1)
+    # use_first_frame_condition: frame 0 pinned to the clean first-frame latents, timestep-0 embedding for that frame
+    first = 0.18215 * torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(62))
+    traj_ff = []
+    pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=3, guidance_scale=7.5,
+         negative_prompt="blurry", latents=lat.clone(), use_first_frame_condition=True, first_image_latents=first,
+         callback=lambda i, t, l: traj_ff.append(l.clone()), callback_steps=1)
     np.savez_compressed(os.path.join(OUT, "pipeline_tiny_t2v.npz"), latents=lat.numpy(), text_embeddings=text_emb.numpy(),
+                        first_image_latents=first.numpy(), trajectory_first_frame=torch.stack(traj_ff).numpy(),
                         trajectory=torch.stack(traj).numpy(), videos=out.videos.numpy(), unet_weight_seed=np.int64(8),
                         vae_weight_seed=np.int64(3), trajectory_video_scale=torch.stack(traj_vs).numpy(), video_scale=np.float32(0.7))
     print("pipeline_tiny_t2v.npz", os.path.getsize(os.path.join(OUT, "pipeline_tiny_t2v.npz")))

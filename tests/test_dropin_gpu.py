@@ -326,6 +326,14 @@ def test_animation_pipeline_plain_text_to_video(dropin, golden_dir, dtype, tol_l
     traj, ref = torch.stack(traj), g["trajectory_video_scale"]
     err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
     assert err.max().item() < tol_lat, err
+    # use_first_frame_condition: frame 0 pinned to the first-frame latents, timestep-0 embedding on that frame
+    traj = []
+    pipe("a corgi waving its tail", video_length=4, height=64, width=64, num_inference_steps=3, guidance_scale=7.5, negative_prompt="blurry",
+         latents=g["latents"].clone(), use_first_frame_condition=True, first_image_latents=g["first_image_latents"].cuda(),
+         callback=lambda i, t, l: traj.append(l.clone().cpu()), callback_steps=1)
+    traj, ref = torch.stack(traj), g["trajectory_first_frame"]
+    err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert err.max().item() < tol_lat, err
 
 
 def test_partial_mask_on_first_frame_block(dropin, golden_dir):

@@ -218,3 +218,18 @@ def test_sampler_video_scale_matches_reference_pipeline(golden_dir):
     ref = g["trajectory_video_scale"]
     err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
     assert err.max().item() < 5e-4, err
+
+
+def test_sampler_first_frame_condition_matches_reference_pipeline(golden_dir):
+    g = _load(golden_dir, "pipeline_tiny_t2v.npz")
+    ocfg = Fn.tiny_unet_config(use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+    sd = W.make_weights(W.unet_state_shapes(ocfg), int(g["unet_weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(use_fps_condition=False, use_first_frame_mask_condition_concat=False), torch.float32, "cpu"),
+                       ops=EmuOps())
+    traj = []
+    DDIMSampler(eng, DDIMConfig(prediction_type="epsilon", rescale_betas_zero_snr=False)).sample(
+        g["latents"], g["text_embeddings"], 3, 7.5, first_image_latents=g["first_image_latents"],
+        callback=lambda i, t, l: traj.append(l.clone()), first_frame_condition=True)
+    traj, ref = torch.stack(traj), g["trajectory_first_frame"]
+    err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert err.max().item() < 5e-4, err

@@ -191,3 +191,17 @@ def test_pipeline_trajectory_video_scale(golden_dir):
     ref = g["trajectory_video_scale"]
     err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
     assert err.max().item() < 2e-5, err
+
+
+def test_pipeline_trajectory_first_frame_condition(golden_dir):
+    """use_first_frame_condition: frame 0 pinned to the first-frame latents, ResNets give frame 0 the timestep-0 embedding"""
+    g = _load(golden_dir, "pipeline_tiny_t2v.npz")
+    cfg = Fn.tiny_unet_config(use_fps_condition=False, use_first_frame_mask_condition_concat=False)
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["unet_weight_seed"]))
+    sched = Fn.DDIMConfig(prediction_type="epsilon", rescale_betas_zero_snr=False)
+    traj = []
+    Fn.denoise(sd, cfg, sched, g["latents"], g["text_embeddings"], 3, 7.5, first_image_latents=g["first_image_latents"],
+               callback=lambda i, t, l: traj.append(l.clone()), use_first_frame_condition=True)
+    traj, ref = torch.stack(traj), g["trajectory_first_frame"]
+    err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert err.max().item() < 2e-5, err
