@@ -8,7 +8,7 @@ collective of a run; clips are then independent DDIM trajectories
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist

@@ -15,7 +15,6 @@ Same constructor, attributes, `__call__` signature, error behaviour and output t
 """
 from __future__ import annotations
 
-import inspect
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
 

@@ -12,7 +12,6 @@ Differences, on purpose:
 """
 from __future__ import annotations
 
-import re
 from typing import Dict, Optional
 
 import torch

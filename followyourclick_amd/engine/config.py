@@ -1,7 +1,7 @@
 """Hyper-parameters of the hot path, named after the reference constructor arguments they mirror."""
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Tuple
 
 

@@ -17,7 +17,7 @@ LayerNorm -> fc1 GEMM with the activation in its epilogue -> fc2 GEMM (+bias +re
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 

@@ -25,7 +25,7 @@ from .. import _lib as L
 from .. import ops as ops_mod
 from .base import EngineBase
 from .config import UNet3DConfig
-from .weights import Packed, pad_channels
+from .weights import Packed
 
 Tensor = torch.Tensor
 

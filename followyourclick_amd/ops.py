@@ -11,7 +11,7 @@ from __future__ import annotations
 import os
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import Optional
 
 import torch
 

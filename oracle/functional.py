@@ -22,7 +22,7 @@ Citations are ``file:line`` relative to ``/root/reference``.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch

@@ -16,7 +16,6 @@ Weights are NOT stored: they are re-derived from seeds by oracle/weights.py::mak
 """
 import json
 import os
-import sys
 
 import numpy as np
 import torch

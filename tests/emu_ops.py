@@ -7,7 +7,6 @@ Two uses:
   * `-m gpu` tests use it as the per-op specification the HIP kernels are compared with.
 It mirrors the buffer layouts of include/fyc.h exactly (flat buffers + leading dimensions).
 """
-import math
 
 import torch
 import torch.nn.functional as F

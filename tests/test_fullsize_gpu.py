@@ -10,8 +10,7 @@ not need a full-size CPU reference (the oracle takes ~100 s per forward there):
 import pytest
 import torch
 
-from followyourclick_amd.engine import DDIMConfig, UNet3DConfig
-from followyourclick_amd.engine.sampler import DDIMSampler
+from followyourclick_amd.engine import UNet3DConfig
 from followyourclick_amd.engine.schema import random_state_dict, unet_schema
 from followyourclick_amd.engine.unet3d import UNet3DEngine
 from followyourclick_amd.engine.weights import pack_unet

@@ -2,7 +2,6 @@
 CLIP ViT-L/14 text encoder, CLIP ViT-H/14 vision tower, ImageProjModel / Resampler, VAE encode of the first frame,
 2-D Stable Diffusion first-image synthesis (50 DDIM steps @512x512 + decode).  Prints one JSON object."""
 import json
-import sys
 import time
 
 import torch

@@ -1,6 +1,6 @@
 """Calibration only (not product): what do the vendor libraries (hipBLASLt via torch.matmul, MIOpen via F.conv2d)
 reach on the engine's GEMM / conv shapes?  Gives an attainable-rate yardstick next to tools/gemm_bench.py."""
-import torch, time
+import torch
 import torch.nn.functional as F
 
 def timeit(fn, n=20):
