@@ -247,3 +247,32 @@ def test_load_ip_adapter_state_surgery(dropin, tmp_path):
     unet.image_proj_model = ad.init_proj()
     ad.load_ip_adapter(unet, use_unet_image_proj_model=True)
     assert torch.equal(unet.state_dict()["image_proj_model.norm.bias"], ck["image_proj"]["norm.bias"])
+
+
+def test_load_ip_adapter_plus_state_surgery(dropin, tmp_path):
+    """MyIPAdapterPlus: the Resampler weights come from the checkpoint's `image_proj` entry, either into the adapter's own projection
+    or into a fresh `unet.image_proj_model` (reference my_ip_adapter.py:252-262)"""
+    from animatediff.models.unet import UNet3DConditionModel
+    from followyourclick_amd.encoders import ClipVisionHip
+    from ip_adapter.my_ip_adapter import MyIPAdapterPlus
+    from ip_adapter.resampler import Resampler
+    from oracle import encoders as E
+    unet = UNet3DConditionModel(**dict(TINY, use_ip_cross_attention=True, num_tokens=4))
+    vis = ClipVisionHip(E.make_encoder_weights(E.clip_vision_shapes(E.TINY_VISION), 53), vars(E.TINY_VISION))
+    ad = MyIPAdapterPlus(unet, vis, None, "cpu", num_tokens=4)
+    assert isinstance(ad.image_proj_model, Resampler)
+    rcfg = E.ResamplerConfig(dim=64, depth=4, dim_head=64, heads=12, num_queries=4, embedding_dim=E.TINY_VISION.hidden_size, output_dim=64)
+    proj_sd = E.make_encoder_weights(E.resampler_shapes(rcfg), 91)
+    assert {k: tuple(v.shape) for k, v in ad.image_proj_model.state_dict().items()} == dict(E.resampler_shapes(rcfg))
+    ip_keys = [k for k in unet.state_dict() if "_ip" in k]
+    ck = {"image_proj": proj_sd, "ip_adapter": {f"{i}.w": torch.full_like(unet.state_dict()[k], float(i) + 0.5) for i, k in enumerate(ip_keys)}}
+    path = str(tmp_path / "ip_plus.bin")
+    torch.save(ck, path)
+    ad.ip_ckpt = path
+    ad.load_ip_adapter()
+    assert torch.equal(ad.image_proj_model.state_dict()["layers.3.1.3.weight"], proj_sd["layers.3.1.3.weight"])
+    assert all(float(unet.state_dict()[k].flatten()[0]) == i + 0.5 for i, k in enumerate(ip_keys))
+    ad.load_ip_adapter(unet, use_unet_image_proj_model=True)
+    assert isinstance(unet.image_proj_model, Resampler)
+    assert torch.equal(unet.image_proj_model.state_dict()["latents"], proj_sd["latents"])
+    assert "image_proj_model.latents" in unet.state_dict()        # travels with the UNet's state dict, as in the reference
