@@ -115,12 +115,24 @@ class AnimationPipeline:
             raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
 
     def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator, latents=None,
-                        init_latents=None, use_interpolate_noise=True, k: int = 64):
-        """reference :448-537 (init_image / residual-noise branches are dead code there and omitted)"""
+                        init_latents=None, init_image=None, use_residual_noise=False, base_lambda=0.9, k=64, use_interpolate_noise=True,
+                        use_add_noise=False, first_images_mask=None):
+        """reference :448-537, pinned by tests/golden/prepare_latents.npz.  `init_image` (dead there: it needs PIL/transforms names
+        the reference never imports, :464) is rejected; `use_add_noise` is unused by the reference as well."""
         shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
                              f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if init_image is not None and init_latents is None:
+            raise NotImplementedError("prepare_latents(init_image=...): pass init_latents (the reference's image branch cannot run, :464)")
+
+        def blend(lat):       # first image blended into every frame with a decaying weight (:501-508, :526-532)
+            lat = lat.clone()
+            for i in range(video_length):
+                a = (video_length - float(i)) / video_length / k
+                lat[:, :, i] = init_latents.to(lat) * a + lat[:, :, i] * (1 - a)
+            return lat
+
         if latents is None:
             if isinstance(generator, list):
                 latents = torch.cat([torch.randn(shape, generator=g, device=g.device if hasattr(g, "device") else device, dtype=dtype)
@@ -130,15 +142,20 @@ class AnimationPipeline:
                 latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
                 if use_interpolate_noise:
                     latents = latents[:, :, :1].repeat(1, 1, video_length, 1, 1)
+                if init_latents is not None:
+                    if first_images_mask is None:     # the reference indexes the mask in this branch (:505) although it never uses it
+                        raise TypeError("'NoneType' object is not subscriptable")
+                    latents = blend(latents)
+                if use_residual_noise:                # :509-513
+                    base = latents[:, :, 0].unsqueeze(2).repeat(1, 1, video_length, 1, 1)
+                    latents = base_lambda ** 0.5 * base + (1 - base_lambda) ** 0.5 * latents
+                    latents[:, :, 0] = base[:, :, 0]
         else:
             if latents.shape != shape:
                 raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
             latents = latents.to(device)
-        if init_latents is not None:
-            latents = latents.clone()
-            for i in range(video_length):       # blend the first image into every frame with a decaying weight (:501-508, :526-532)
-                a = (video_length - float(i)) / video_length / k
-                latents[:, :, i] = init_latents.to(latents) * a + latents[:, :, i] * (1 - a)
+            if init_latents is not None:
+                latents = blend(latents)
         return latents * self.scheduler.init_noise_sigma
 
     def decode_latents(self, latents):
@@ -207,7 +224,8 @@ class AnimationPipeline:
         latents = self.prepare_latents(batch_size * num_videos_per_prompt, self.unet.in_channels, video_length, height, width,
                                        text_embeddings.dtype, device, generator, latents,
                                        init_latents=first_image_latents if use_first_image_as_init_latents else None,
-                                       use_interpolate_noise=use_interpolate_noise)
+                                       use_interpolate_noise=use_interpolate_noise,
+                                       first_images_mask=mask_final if use_first_image_as_init_latents else None)   # :636-668
 
         ip_tokens = None
         if use_ip_cross_attention:

@@ -1,0 +1,194 @@
+"""Golden vectors at SD-1.5 WIDTHS (320/640/1280/1280, ctx 768, 8 heads => d = 40/80/160) and at the
+production precision, by executing the REAL reference (container only; TEST INFRASTRUCTURE).
+
+    python -m oracle.make_golden_full small      # F=4, 16x16 latent, one forward            (~1 min)
+    python -m oracle.make_golden_full vae        # AutoencoderKL.decode, (128,256,512,512), 16x16 latent
+    python -m oracle.make_golden_full p2         # AnimationPipeline.prepare_latents (init-latents blend / interpolate noise)
+    python -m oracle.make_golden_full cfg1       # BASELINE configs[0]: 8 frames 256x256, 5 DDIM steps, full pipeline
+    python -m oracle.make_golden_full cfg2       # BASELINE configs[1]: 16 frames 512x512, 25 DDIM steps (~1.5 h on 8 cores)
+
+Every UNet golden exists twice: `*_f32` = the reference as the CPU runs it (fp32), `*_bf16` = the same
+reference code under the CUDA-autocast cast policy with bfloat16 (oracle/autocast_emul.py), i.e. the
+precision the engine's production mode computes in.  `drift` = rel-L2(bf16 reference, f32 reference) is
+stored next to them: it is the yardstick for the engine's own bf16-vs-f32 distance.
+Weights/inputs are re-derived from seeds (oracle/weights.py); only outputs are stored.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import functional as Fn
+from . import refshim, stubs
+from . import weights as W
+from .autocast_emul import CudaAutocastOnCpu
+from .make_golden import MM_KW, OUT, ref_unet, ref_vae
+
+SKW = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+           clip_sample=False, prediction_type="v_prediction", rescale_betas_zero_snr=True)
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+def log(*a):
+    print(time.strftime("%H:%M:%S"), *a, flush=True)
+
+
+def full_unet(max_len=24):
+    cfg = Fn.UNetConfig(temporal_position_encoding_max_len=max_len) if max_len != 24 else Fn.UNetConfig()
+    t0 = time.time()
+    unet = ref_unet(cfg).eval()
+    sd = W.make_weights(W.unet_state_shapes(cfg), seed=0)
+    unet.load_state_dict(sd, strict=True)
+    for m in unet.modules():                       # score-tensor valve on the 16 spatial attn1 only: bit-identical math
+        if m.__class__.__name__ == "BasicTransformerBlock" and hasattr(m, "attn1"):
+            m.attn1._slice_size = 8
+    log(f"reference UNet3D built + seeded in {time.time() - t0:.0f}s")
+    return cfg, unet
+
+
+def small():
+    cfg, unet = full_unet()
+    inp = W.seeded_inputs(cfg, 1, 4, 16, 16, seed=31)
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    kw = dict(use_fps_condition=True, fps_tensor=fps, flow_control=flow)
+    with torch.no_grad():
+        y32 = unet(x9, torch.tensor(961), inp["text"], **kw).sample
+        with CudaAutocastOnCpu(torch.bfloat16):
+            y16 = unet(x9, torch.tensor(961), inp["text"], **kw).sample.float()
+    d = rel(y16, y32)
+    log(f"small: drift bf16-autocast vs f32 = {d:.3e}")
+    np.savez_compressed(os.path.join(OUT, "unet_full_small_fwd.npz"), out_f32=y32.numpy(), out_bf16=y16.numpy(), drift=np.float64(d),
+                        timestep=np.int64(961), fps=fps.numpy(), flow=flow.numpy(), weight_seed=np.int64(0), input_seed=np.int64(31),
+                        frames=np.int64(4), h=np.int64(16), w=np.int64(16))
+
+
+def vae():
+    vcfg = Fn.VAEConfig()
+    v = ref_vae(vcfg).eval()
+    sdv = W.make_weights(W.vae_decoder_state_shapes(vcfg), seed=3)
+    v.load_state_dict(sdv, strict=False)
+    z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        img = v.decode(z).sample
+        with CudaAutocastOnCpu(torch.bfloat16):
+            img16 = v.decode(z).sample.float()
+    log(f"vae: max|bf16-f32| = {(img16 - img).abs().max():.3e}")
+    np.savez_compressed(os.path.join(OUT, "vae_full.npz"), z=z.numpy(), out=img.numpy(), out_bf16=img16.numpy(), weight_seed=np.int64(3))
+
+
+def _pipeline(unet, cfg, vae_mod=None):
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers.schedulers.scheduling_ddim import DDIMScheduler
+    if vae_mod is None:
+        vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))
+        vae_mod = ref_vae(vcfg).eval()
+        vae_mod.load_state_dict(W.make_weights(W.vae_decoder_state_shapes(vcfg), seed=3), strict=False)
+    tok, txt = stubs.FakeTokenizer(), stubs.StubTextEncoder(cfg.cross_attention_dim)
+    return AnimationPipeline(vae=vae_mod, text_encoder=txt, tokenizer=tok, unet=unet, scheduler=DDIMScheduler(**SKW))
+
+
+def p2():
+    """prepare_latents (reference pipeline_animation.py:448-536): generated noise with / without use_interpolate_noise, the
+    init_latents blend in both branches (:501-508, :526-532), use_residual_noise (:509-513); the generator is seeded so the
+    host restatement must draw the same noise."""
+    cfg = Fn.tiny_unet_config()
+    unet = ref_unet(cfg).eval()
+    pipe = _pipeline(unet, cfg)
+    d = {}
+    first = 0.18215 * torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(41))
+    mask = (torch.rand(1, 1, 6, 8, 8, generator=torch.Generator().manual_seed(42)) > 0.5).float()
+    given = torch.randn(1, 4, 6, 8, 8, generator=torch.Generator().manual_seed(43))
+    cases = (("gen_interp", dict()),
+             ("gen_plain", dict(use_interpolate_noise=False)),
+             ("gen_init", dict(use_interpolate_noise=False, init_latents=first, first_images_mask=mask)),
+             ("gen_init_interp", dict(init_latents=first, first_images_mask=mask)),
+             ("gen_init_nomask", dict(init_latents=first)),
+             ("gen_residual", dict(use_interpolate_noise=False, use_residual_noise=True, base_lambda=0.9)),
+             ("given_init", dict(latents=given.clone(), init_latents=first, k=30)),
+             ("given_plain", dict(latents=given.clone())),
+             ("given_badshape", dict(latents=given[:, :, :5].clone())))
+    import contextlib
+    import io
+    for name, kw in cases:
+        g = torch.Generator().manual_seed(77)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                lat = pipe.prepare_latents(1, 4, 6, 64, 64, torch.float32, torch.device("cpu"), g, **kw)
+            d[name] = lat.numpy()
+            log("p2", name, tuple(lat.shape), float(lat.std()))
+        except Exception as e:       # recorded: the host restatement must raise as well
+            d[name + "_error"] = np.array(type(e).__name__)
+            log("p2", name, "raises", repr(e)[:120])
+    d["first_image_latents"], d["first_images_mask"], d["given"] = first.numpy(), mask.numpy(), given.numpy()
+    np.savez_compressed(os.path.join(OUT, "prepare_latents.npz"), **d)
+
+
+def _run_pipeline(pipe, inp, frames, size, steps, keep):
+    traj = {}
+
+    def cb(i, t, l):
+        log(f"  step {i} t={int(t)}")
+        if i in keep:
+            traj[i] = l.clone().float()
+
+    out = pipe("a corgi waving its tail", video_length=frames, height=size, width=size, num_inference_steps=steps, guidance_scale=8.0,
+               negative_prompt="blurry", latents=inp["latents"].clone(), first_image_latents=inp["first_image_latents"],
+               first_images_mask=inp["first_images_mask"], use_first_frame_mask_condition_concat=True,
+               use_fps_condition=True, fps_tensor=torch.tensor([2]), flow_control=torch.tensor([4]),
+               callback=cb, callback_steps=1, output_type="latent")
+    return traj, out
+
+
+def _trajectory(tag, frames, lat, steps, keep, seed):
+    cfg, unet = full_unet()
+    pipe = _pipeline(unet, cfg)
+    pipe.decode_latents = lambda latents: np.zeros((1, 3, frames, 8, 8), dtype=np.float32)   # VAE decode is pinned by vae_full / pipeline_tiny
+    inp = W.seeded_inputs(cfg, 1, frames, lat, lat, seed=seed)
+    with torch.no_grad():
+        text_emb = pipe._encode_prompt(["a corgi waving its tail"], "cpu", 1, True, ["blurry"])
+    res = {}
+    for mode in ("bf16", "f32"):
+        t0 = time.time()
+        log(f"{tag} {mode}: {steps} steps")
+        if mode == "bf16":
+            with CudaAutocastOnCpu(torch.bfloat16):
+                traj, _ = _run_pipeline(pipe, inp, frames, lat * 8, steps, keep)
+        else:
+            traj, _ = _run_pipeline(pipe, inp, frames, lat * 8, steps, keep)
+        res[mode] = traj
+        log(f"{tag} {mode}: {time.time() - t0:.0f}s")
+        # partial save after each mode so a long run leaves something behind
+        d = dict(text_embeddings=text_emb.numpy(), steps=np.int64(steps), frames=np.int64(frames), lat=np.int64(lat),
+                 weight_seed=np.int64(0), input_seed=np.int64(seed), keep=np.array(sorted(keep)))
+        for m, tr in res.items():
+            for i, l in tr.items():
+                d[f"step{i}_{m}"] = l.numpy()
+        if "f32" in res:
+            for i in sorted(keep):
+                d[f"drift{i}"] = np.float64(rel(res["bf16"][i], res["f32"][i]))
+                log(f"{tag}: drift bf16-autocast vs f32 after step {i}: {d[f'drift{i}']:.3e}")
+        np.savez_compressed(os.path.join(OUT, f"{tag}_trajectory.npz"), **d)
+
+
+def cfg1():
+    _trajectory("cfg1", 8, 32, 5, {0, 1, 2, 3, 4}, seed=51)
+
+
+def cfg2():
+    _trajectory("cfg2", 16, 64, 25, {0, 4, 24}, seed=52)
+
+
+if __name__ == "__main__":
+    refshim.install()
+    torch.manual_seed(0)
+    for part in sys.argv[1:]:
+        log("==", part)
+        dict(small=small, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2)[part]()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -4,6 +4,7 @@ import inspect
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -276,3 +277,34 @@ def test_load_ip_adapter_plus_state_surgery(dropin, tmp_path):
     assert isinstance(unet.image_proj_model, Resampler)
     assert torch.equal(unet.image_proj_model.state_dict()["latents"], proj_sd["latents"])
     assert "image_proj_model.latents" in unet.state_dict()        # travels with the UNet's state dict, as in the reference
+
+
+def test_prepare_latents_vs_reference_golden(dropin, golden_dir):
+    """AnimationPipeline.prepare_latents against the real reference's outputs (oracle/make_golden_full.py p2; reference
+    pipeline_animation.py:448-536): seeded noise, use_interpolate_noise repeat, the init_latents blend in both branches,
+    use_residual_noise, and the two error paths."""
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import AutoencoderKL, DDIMScheduler
+    from oracle import stubs
+    g = dict(np.load(os.path.join(golden_dir, "prepare_latents.npz")))
+    vae = AutoencoderKL(block_out_channels=(64, 128, 128, 128), layers_per_block=2, latent_channels=4)
+    pipe = AnimationPipeline(vae=vae, text_encoder=stubs.StubTextEncoder(64), tokenizer=stubs.FakeTokenizer(),
+                             unet=UNet3DConditionModel(**TINY), scheduler=DDIMScheduler())
+    first, mask, given = (torch.from_numpy(g[k]) for k in ("first_image_latents", "first_images_mask", "given"))
+    cases = dict(gen_interp=dict(), gen_plain=dict(use_interpolate_noise=False),
+                 gen_init=dict(use_interpolate_noise=False, init_latents=first, first_images_mask=mask),
+                 gen_init_interp=dict(init_latents=first, first_images_mask=mask),
+                 gen_init_nomask=dict(init_latents=first),
+                 gen_residual=dict(use_interpolate_noise=False, use_residual_noise=True, base_lambda=0.9),
+                 given_init=dict(latents=given.clone(), init_latents=first, k=30), given_plain=dict(latents=given.clone()),
+                 given_badshape=dict(latents=given[:, :, :5].clone()))
+    errors = dict(TypeError=TypeError, ValueError=ValueError)
+    for name, kw in cases.items():
+        gen = torch.Generator().manual_seed(77)
+        if name + "_error" in g:
+            with pytest.raises(errors[str(g[name + "_error"])]):
+                pipe.prepare_latents(1, 4, 6, 64, 64, torch.float32, torch.device("cpu"), gen, **kw)
+            continue
+        out = pipe.prepare_latents(1, 4, 6, 64, 64, torch.float32, torch.device("cpu"), gen, **kw)
+        assert torch.equal(out, torch.from_numpy(g[name])), name
