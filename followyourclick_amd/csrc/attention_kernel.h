@@ -1,0 +1,365 @@
+// Flash-style attention for gfx950: bf16 MFMA QK^T / PV with wave-level online softmax (kernel template).
+//
+// Layouts (written by the GEMM "HEADS" epilogue): q,k [B*H][N][d] ; vt [B*H][d][ldvt] (V transposed,
+// keys contiguous) ; o token-major [B*N][ldo] (channel = h*d + i) for the to_out GEMM.
+//
+// Work split: workgroup = 4 wave64 = 64*QT queries of one (batch, head); each wave owns QT tiles of 16 queries for the
+// whole key loop.  K and V^T tiles of 64 keys go global->LDS by DMA (global_load_lds, 16 B/lane) into a 3-deep ring:
+// the wait that retires tile j is counted (vmcnt(LOADS): tile j+1 stays in flight), the barrier is the raw s_barrier
+// (cdna_hip_programming.md "Pipelining across barriers") and tile j+2 is issued right behind it.
+//
+// MFMA orientation (v_mfma_f32_16x16x32_bf16, D[row][col]: col = lane&15, row = 4*(lane>>4)+reg):
+//   S^T = K Q^T  : A = K rows (keys), B = Q rows (queries)  -> a lane holds, for ONE query (col), scores of 4 keys per
+//                  tile; two tiles with interleaved key rows give it 8 consecutive keys 8g..8g+7 of a 32-key block.
+//   O^T = V^T P^T: B = P^T is exactly those 8 scores (exponentiated, bf16) - no cross-lane traffic,
+//                  A = V^T rows (dv) x 8 consecutive keys = one 16-B LDS read.
+// The head dim is covered by d/32 full k-steps plus one 16-wide step (v_mfma_f32_16x16x16_bf16) when d%32 is 8 or 16:
+// d = 40 issues 32+16 instead of 64.
+//
+// Softmax on a VALU diet (the loop is VALU-bound before it is MFMA-bound at d = 40):
+//   * Q is pre-multiplied by scale*log2(e): a score needs no multiply;
+//   * the row sum l is a row of O^T: V^T gets a row of ones at index d, so the PV MFMAs accumulate sum_k p_k (of the
+//     bf16-rounded p that also multiply V) - no adds, and l is rescaled together with O^T;
+//   * when index d is a padding slot of the head dim (d % 16 == 8, e.g. 40), K gets a column of ones there and Q the
+//     value -m (running max, bf16): the QK^T MFMA delivers s - m directly, so p = exp2(s') with no subtract;
+//   * the running max is only moved when a score exceeds it by more than RESCALE_THR (p stays <= 2^THR), checked with
+//     a wave-uniform ballot: the O^T rescale runs in the first tiles only.
+#pragma once
+#include "fyc_common.h"
+
+namespace fyca {
+
+struct AttnP {
+  const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
+  int batch, heads, n_q, n_k, d, ldo, ldvt, kv_batch_div, o_accumulate;
+  float sl2e, o_scale;   // scale * log2(e)
+  int nqb;               // query blocks per (b,h)
+  const char* zero;
+};
+
+// 64 x bf16 1.0 (a V^T row of ones), then {1.0, 0 x 7} (the K column of ones): sources of the direct-to-LDS loads
+#define FYC_1 0x3F80
+static __device__ __attribute__((aligned(16))) const unsigned short fyc_ones[72] = {
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, 0, 0, 0, 0, 0, 0, 0};
+#undef FYC_1
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr float RESCALE_THR = 6.0f;   // log2 units: probabilities stay <= 64 between moves of the running max
+
+// max over the 4 lane quads that share a query column: xor 16 inside each 32-lane half (ds_swizzle bit mode, no LDS
+// traffic), then across the halves (v_permlane32_swap)
+__device__ __forceinline__ float quad_max(float mx) {
+  mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x401F)));
+  const unsigned u = __builtin_bit_cast(unsigned, mx);
+  auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+}
+
+// DP16: padded head dim / 16 (K-dim of QK^T).  DVT: 16-row blocks of O^T = d/16 + 1 (the extra row at index d is l).
+// DVT == DP16 <=> d % 16 == 8: index d is a free padding slot of the head dim, used for the in-MFMA max subtraction.
+template <int DP16, int DVT, int QT>
+__global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
+  constexpr int KS = DP16 / 2;           // full 32-wide k-steps
+  constexpr bool TAIL = (DP16 & 1) != 0; // plus one 16-wide k-step
+  constexpr bool MSUB = (DVT == DP16);
+  constexpr int DC = DP16 * 2;           // 16-B chunks per K row
+  constexpr bool KXOR = (DC == 8);       // 128-B rows: XOR swizzle; otherwise one pad chunk per row (odd pitch)
+  constexpr int PC = KXOR ? 8 : DC + 1;  // K row pitch in chunks
+  constexpr int KB = 64;                 // keys per LDS tile
+  constexpr int K_IT = (KB * PC + 255) / 256, K_BYTES = K_IT * 256 * 16;
+  constexpr int V_ROWS = DVT * 16, V_IT = (V_ROWS * 8 + 255) / 256, V_BYTES = V_IT * 256 * 16;
+  constexpr int STAGE = K_BYTES + V_BYTES, LOADS = K_IT + V_IT, NS = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+
+  // block -> (bh, query block); keep all query blocks of one (b,h) on one XCD (block b runs on XCD b%8)
+  const int BH = p.batch * p.heads;
+  int bh, qb;
+  if ((BH & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    bh = (j / p.nqb) * 8 + xcd;
+    qb = j % p.nqb;
+  } else {
+    bh = blockIdx.x / p.nqb;
+    qb = blockIdx.x % p.nqb;
+  }
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int kvb = (b / p.kv_batch_div) * p.heads + h;
+  const bf16_t* Q = p.q + (long long)bh * p.n_q * p.d;
+  const bf16_t* K = p.k + (long long)kvb * p.n_k * p.d;
+  const bf16_t* VT = p.vt + (long long)kvb * p.d * p.ldvt;
+  const char* zero = p.zero;
+  const int ntiles = (p.n_k + KB - 1) / KB;
+  const int dchunks = p.d >> 3;
+
+  auto issue = [&](int tile, int stage) {
+    char* sK = smem + stage * STAGE;
+    char* sV = sK + K_BYTES;
+    const int key0 = tile * KB;
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it) {
+      const int L = it * 256 + tid, row = L / PC, cc = L - row * PC;
+      const int c = KXOR ? (cc ^ (row & 7)) : cc;
+      const int key = key0 + row;
+      const bool live = row < KB && key < p.n_k;
+      const void* src = zero;
+      if (live && c < dchunks) src = K + (long long)key * p.d + c * 8;
+      else if (MSUB && live && c == dchunks) src = fyc_ones + 64;    // {1, 0 x 7}: the column that adds -m to every score
+      glds16(src, sK + (it * 256 + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) {
+      const int L = it * 256 + tid, row = L >> 3, cc = L & 7;
+      const int c = cc ^ (row & 7);
+      const int key = key0 + c * 8;
+      const void* src = zero;
+      if (row < p.d) { if (key < p.ldvt) src = VT + (long long)row * p.ldvt + key; }
+      else if (row == p.d) src = fyc_ones;                            // the row of ones that makes O^T[d] = sum_k p_k
+      glds16(src, sV + (it * 256 + wave * 64) * 16);
+    }
+  };
+  issue(0, 0);
+  if (ntiles > 1) issue(1, 1);
+
+  // ---- Q fragments (B operand), pre-scaled by scale*log2(e): lane (query = r16, quad g) holds Q[query][32ks + 8g .. +8]
+  //      and, for the 16-wide step, Q[query][32*KS + 4g .. +4]
+  const int qbase = qb * (64 * QT) + wave * (16 * QT);
+  bf16x8 qf[QT][KS > 0 ? KS : 1];
+  s16x4 qt4[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int query = qbase + qt * 16 + r16;
+    const bool qok = query < p.n_q;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int dd = 32 * ks + 8 * g;
+      float v[8];
+      load8<bf16_t>((qok && dd < p.d) ? Q + (long long)query * p.d + dd : reinterpret_cast<const bf16_t*>(zero), v);
+      u32x4 pk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(v[2 * i] * p.sl2e, v[2 * i + 1] * p.sl2e);
+      qf[qt][ks] = __builtin_bit_cast(bf16x8, pk);
+    }
+    if (TAIL) {
+      const int dd = 32 * KS + 4 * g;
+      float v[4];
+      ElemIO<bf16_t>::ld4((qok && dd < p.d) ? Q + (long long)query * p.d + dd : reinterpret_cast<const bf16_t*>(zero), v);
+      u32x2 pk = {pack_bf16x2(v[0] * p.sl2e, v[1] * p.sl2e), pack_bf16x2(v[2] * p.sl2e, v[3] * p.sl2e)};
+      qt4[qt] = __builtin_bit_cast(s16x4, pk);
+    }
+  }
+  // MSUB: the slot of head-dim index d inside this lane's fragments (element 0 of quad MG of the last k-step)
+  constexpr int MOFF = MSUB ? ((DP16 * 16 - 8) - (TAIL ? 32 * KS : 32 * (KS - 1))) : 0;   // d - first index of the last step
+  constexpr int MG = TAIL ? MOFF / 4 : MOFF / 8;
+  auto set_neg_max = [&](int qt, float m_bf16_exact) {       // writes -m into Q'[query][d]
+    const unsigned short bits = f32_to_bf16_bits(-m_bf16_exact);
+    if (g == MG) {
+      if (TAIL) qt4[qt][0] = (short)bits;
+      else {
+        u32x4 t = __builtin_bit_cast(u32x4, qf[qt][KS > 0 ? KS - 1 : 0]);
+        t[0] = (t[0] & 0xffff0000u) | bits;
+        qf[qt][KS > 0 ? KS - 1 : 0] = __builtin_bit_cast(bf16x8, t);
+      }
+    }
+  };
+
+  f32x4 o[QT][DVT];
+  float m_run[QT];        // running max in log2 units (MSUB: exactly representable in bf16, mirrored in Q')
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = 0.f;
+#pragma unroll
+    for (int dv = 0; dv < DVT; ++dv) o[qt][dv] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  bool started = false;   // the first key block always fixes the running max (scores may sit anywhere)
+
+  int st_c = 0, st_i = (ntiles > 1) ? 2 : 1;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (tile + 2 < ntiles) { issue(tile + 2, st_i); st_i = (st_i + 1 == NS) ? 0 : st_i + 1; }
+    const char* sK = smem + st_c * STAGE;
+    const char* sV = sK + K_BYTES;
+    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    const bool tail = (tile * KB + KB > p.n_k);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (tile * KB + kb * 32 >= p.n_k) break;  // whole 32-key block out of range (uniform)
+      // ---- S^T tiles: tile t row i <-> key kb*32 + 8*(i>>2) + 4t + (i&3)
+      f32x4 s[2][QT];
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int krow = kb * 32 + 8 * (r16 >> 2) + 4 * t + (r16 & 3);
+        const char* kr = sK + krow * (PC * 16);
+        bf16x8 kf[KS > 0 ? KS : 1];
+        s16x4 kt4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int chunk = 4 * ks + g;
+          kf[ks] = *reinterpret_cast<const bf16x8*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16);
+        }
+        if (TAIL) {
+          const int chunk = 4 * KS + (g >> 1);
+          kt4 = *reinterpret_cast<const s16x4*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16 + (g & 1) * 8);
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[qt][ks], a, 0, 0, 0);
+          if (TAIL) a = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt4, qt4[qt], a, 0, 0, 0);
+          s[t][qt] = a;
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      // ---- online softmax; lane holds keys kb*32 + 8g + 4t + r of query r16.  MSUB: s already is score - m_run.
+      float mx[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        if (tail) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (tile * KB + kb * 32 + 8 * g + 4 * t + r >= p.n_k) s[t][qt][r] = -INFINITY;
+        }
+        const float m0 = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), s[0][qt][2]);
+        const float m1 = fmaxf(fmaxf(s[0][qt][3], s[1][qt][0]), s[1][qt][1]);
+        mx[qt] = quad_max(fmaxf(fmaxf(m0, m1), fmaxf(s[1][qt][2], s[1][qt][3])));
+      }
+      bool move = !started;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) move = move || (MSUB ? mx[qt] > RESCALE_THR : mx[qt] > m_run[qt] + RESCALE_THR);
+      float shift[QT];     // what still has to be subtracted from the scores of THIS block
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) shift[qt] = MSUB ? 0.f : m_run[qt];
+      if (__builtin_amdgcn_ballot_w64(move) != 0) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const bool mv = !started || (MSUB ? mx[qt] > RESCALE_THR : mx[qt] > m_run[qt] + RESCALE_THR);
+          if (MSUB) {
+            // new max = bf16(m_run + mx) so that it fits Q' exactly; this block's scores are still relative to the old one
+            const float m_new = mv ? bf16_bits_to_f32(f32_to_bf16_bits(m_run[qt] + mx[qt])) : m_run[qt];
+            const float delta = m_new - m_run[qt];
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_run[qt] = m_new;
+            shift[qt] = delta;
+            set_neg_max(qt, m_new);
+#pragma unroll
+            for (int dv = 0; dv < DVT; ++dv) { o[qt][dv][0] *= alpha; o[qt][dv][1] *= alpha; o[qt][dv][2] *= alpha; o[qt][dv][3] *= alpha; }
+          } else {
+            const float m_new = mv ? mx[qt] : m_run[qt];
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            shift[qt] = m_new;
+#pragma unroll
+            for (int dv = 0; dv < DVT; ++dv) { o[qt][dv][0] *= alpha; o[qt][dv][1] *= alpha; o[qt][dv][2] *= alpha; o[qt][dv][3] *= alpha; }
+          }
+        }
+        started = true;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][qt][r] -= shift[qt];
+      } else if (!MSUB) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][qt][r] -= shift[qt];
+      }
+      bf16x8 pf[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        u32x4 pk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          pk[2 * t] = pack_bf16x2(__builtin_amdgcn_exp2f(s[t][qt][0]), __builtin_amdgcn_exp2f(s[t][qt][1]));
+          pk[2 * t + 1] = pack_bf16x2(__builtin_amdgcn_exp2f(s[t][qt][2]), __builtin_amdgcn_exp2f(s[t][qt][3]));
+        }
+        pf[qt] = __builtin_bit_cast(bf16x8, pk);
+      }
+      // ---- O^T += V^T P^T  (row d of V^T is all ones: O^T[d] accumulates the row sums)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv) {
+        const int vrow = dv * 16 + r16;
+        const int chunk = kb * 4 + g;
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + vrow * 128 + ((chunk ^ (vrow & 7)) * 16));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][dv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][dv], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // ---- epilogue: lane holds O[query r16][dv*16 + 4g + r]; l = O^T[d] sits in quad (d%16)/4, register 0 of the last block
+  const int lsrc = ((p.d & 15) >> 2) * 16 + r16;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l = __shfl(o[qt][DVT - 1][0], lsrc);
+    const float inv = 1.0f / l;
+    const int query = qbase + qt * 16 + r16;
+    if (query >= p.n_q) continue;
+    bf16_t* orow = p.o + ((long long)b * p.n_q + query) * p.ldo + h * p.d;
+#pragma unroll
+    for (int dv = 0; dv < DVT; ++dv) {
+      const int dd = dv * 16 + 4 * g;
+      if (dd >= p.d) continue;
+      float v[4] = {o[qt][dv][0] * inv, o[qt][dv][1] * inv, o[qt][dv][2] * inv, o[qt][dv][3] * inv};
+      if (p.o_accumulate) {
+        float prev[4];
+        ElemIO<bf16_t>::ld4(orow + dd, prev);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = prev[r] + p.o_scale * v[r];
+      }
+      ElemIO<bf16_t>::st4(orow + dd, v);
+    }
+  }
+}
+
+template <int DP16, int DVT, int QT>
+int launch_attn(const AttnP& p0, hipStream_t st) {
+  constexpr int DC = DP16 * 2;
+  constexpr int PC = (DC == 8) ? 8 : DC + 1;
+  constexpr int K_BYTES = ((64 * PC + 255) / 256) * 256 * 16;
+  constexpr int V_BYTES = ((DVT * 16 * 8 + 255) / 256) * 256 * 16;
+  constexpr int smem = 3 * (K_BYTES + V_BYTES);
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  auto kern = fyc_attn_kernel<DP16, DVT, QT>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);   // per call: cheap, and correct on every device
+  AttnP p = p0;
+  p.nqb = (p.n_q + 64 * QT - 1) / (64 * QT);
+  dim3 grid(p.batch * p.heads * p.nqb);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  FYC_CHECK_LAUNCH("fyc_attention");
+  return 0;
+}
+
+// one translation unit per group of head dims keeps the build parallel
+int run_small(const AttnP& p, bool qt4, hipStream_t st);    // d <= 48
+int run_medium(const AttnP& p, bool qt4, hipStream_t st);   // 48 < d <= 96
+int run_large(const AttnP& p, hipStream_t st);              // 96 < d <= 160
+
+// d -> (DP16, DVT) = (ceil(d/16), d/16 + 1), d a multiple of 8
+#define FYC_ATTN_CASE(D, QT) case D: return launch_attn<(D + 15) / 16, D / 16 + 1, QT>(p, st)
+
+}  // namespace fyca

@@ -24,10 +24,28 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   if (tile > 0) { cfg = tile & 0xff; if (tile >> 8) ns = tile >> 8; }
   if (g_fyc_tuning[1] > 0) cfg = g_fyc_tuning[1];
   if (g_fyc_tuning[2] > 0) ns = g_fyc_tuning[2];
-  if (cfg == 3 && ns > 3) ns = 3;
-  if (cfg >= 5) ns = 2;   // configs 5+ fix their own ring depth
+  if (cfg != 1 || ns != 3) ns = 2;   // only config 1 is also built 3-deep
+}
+// column-tile width of a tile config (gemm_kernel.h::dispatch_cfg)
+int tile_bn(int cfg) {
+  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: return 320; case 7: return 256; default: return 128; }
+}
+void pick(const fyc_gemm_args* a, int& cfg, int& ns) {
+  if (a->dtype == FYC_F32) { cfg = (a->N % 128 == 0) ? 1 : 2; ns = 2; return; }
+  GemmP q;
+  memset(&q, 0, sizeof(q));
+  q.M = a->M; q.N = a->N; q.K = a->K; q.mode = a->mode;
+  choose(q, a->batch > 0 ? a->batch : 1, a->tile, cfg, ns);
 }
 }  // namespace
+
+extern "C" int fyc_gemm_row_parts(const fyc_gemm_args* a) {
+  if (a == nullptr || a->N <= 0) return 0;
+  int cfg = 1, ns = 2;
+  pick(a, cfg, ns);
+  const int bn = tile_bn(cfg);
+  return (a->N + bn - 1) / bn;
+}
 
 extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   FYC_REQUIRE(a != nullptr, "fyc_gemm: null args");
@@ -56,6 +74,16 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.out_scale = a->out_scale;
   p.act = a->act;
   p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum;
+  p.ln_nparts = a->ln_nparts; p.ln_eps = a->ln_eps;
+  FYC_REQUIRE(a->ln_nparts >= 0 && (a->ln_nparts == 0 || (a->ln_stats != nullptr && a->a2 == nullptr)), "fyc_gemm: ln_nparts=%d needs ln_stats (and no a2)", a->ln_nparts);
+  p.chan_stats = a->chan_stats; p.cs_rows = a->cs_rows; p.row_parts = a->row_parts; p.row_nparts = a->row_nparts;
+  if (a->chan_stats != nullptr || a->row_parts != nullptr) {
+    FYC_REQUIRE(a->epilogue == FYC_EPI_LINEAR && (a->batch <= 1), "fyc_gemm: output statistics need the LINEAR epilogue without batch");
+    FYC_REQUIRE(a->chan_stats == nullptr || (a->cs_rows > 0 && a->cs_rows % 16 == 0 && (a->cs_rows == 64 || a->cs_rows >= 128) && a->M % a->cs_rows == 0 && ((uintptr_t)a->chan_stats % 8) == 0),
+                "fyc_gemm: chan_stats needs cs_rows (=%d) a multiple of 16 that is 64 or >= 128 and divides M=%d", a->cs_rows, a->M);
+    FYC_REQUIRE(a->row_parts == nullptr || (((uintptr_t)a->row_parts % 8) == 0 && a->row_nparts == fyc_gemm_row_parts(a)),
+                "fyc_gemm: row_parts needs row_nparts == fyc_gemm_row_parts() = %d (got %d)", fyc_gemm_row_parts(a), a->row_nparts);
+  }
   p.zero = (const char*)g_fyc_zero_page;
   const int batch = a->batch > 0 ? a->batch : 1;
   if (a->mode == FYC_GEMM_PLAIN) {
@@ -124,9 +152,11 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   }
   p.rb_tile = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, (p.N % 128 == 0) ? 1 : 2, st);
   int cfg = 1, ns = 2;
-  choose(p, batch, a->tile, cfg, ns);
+  pick(a, cfg, ns);
+  FYC_REQUIRE((a->chan_stats == nullptr && a->row_parts == nullptr) || (cfg != 8 && cfg != 10), "fyc_gemm: output statistics are not built for the 64-byte K-tile configs");
+  FYC_REQUIRE(a->row_parts == nullptr || a->dtype == FYC_F32 || p.wide, "fyc_gemm: row_parts in bf16 needs the 16-byte aligned layout (N, ldo, ldr multiples of 8; aligned pointers)");
+  if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, cfg, st);
   if (p.act != FYC_ACT_NONE) {
     FYC_REQUIRE(a->mode == FYC_GEMM_PLAIN, "fyc_gemm: act needs the PLAIN mode");
     return fycg::run_bf16_act(p, batch, cfg, st);

@@ -3,8 +3,9 @@
 #include "gemm_kernel.h"
 namespace fycg {
 int run_bf16_act(const GemmP& p, int batch, int cfg, hipStream_t st) {
-  if (cfg == 6 || cfg == 5) return launch<bf16_t, 128, 320, 2, 4, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2>(p, batch, st);
-  if (cfg == 1 || cfg == 3 || cfg == 7) return launch<bf16_t, 128, 128, 2, 2, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2>(p, batch, st);
-  return launch<bf16_t, 128, 64, 2, 2, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2>(p, batch, st);
+  if (!p.wide) return dispatch_cfg<bf16_t, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, false>(cfg, 2, p, batch, st);
+  if (cfg == 6 || cfg == 5) return launch<bf16_t, 128, 320, 2, 4, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2, 128, true>(p, batch, st);
+  if (cfg == 1 || cfg == 3 || cfg == 7) return launch<bf16_t, 128, 128, 2, 2, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2, 128, true>(p, batch, st);
+  return launch<bf16_t, 128, 64, 2, 2, FYC_GEMM_PLAIN, EPI_LINEAR_ACT, 2, 128, true>(p, batch, st);
 }
 }  // namespace fycg

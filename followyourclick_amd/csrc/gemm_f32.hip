@@ -3,8 +3,7 @@
 namespace fycg {
 template <int MODE, int EPI>
 static int run_tile(const GemmP& p, int batch, int cfg, hipStream_t st) {
-  if (cfg == 1) return launch<float, 128, 128, 2, 2, MODE, EPI, 2>(p, batch, st);
-  return launch<float, 128, 64, 2, 2, MODE, EPI, 2>(p, batch, st);
+  return dispatch_cfg<float, MODE, EPI, false>(cfg, 2, p, batch, st);
 }
 int run_f32(const GemmP& p, int batch, int cfg, hipStream_t st) {
   if (p.mode == FYC_GEMM_CONV3X3) return run_tile<FYC_GEMM_CONV3X3, FYC_EPI_LINEAR>(p, batch, cfg, st);

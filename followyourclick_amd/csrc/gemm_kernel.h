@@ -24,9 +24,13 @@
 //
 // f32 parity mode uses the same kernel with v_mfma_f32_16x16x4_f32 (exact f32, 1/16 rate).
 #pragma once
+#include <mutex>
+
 #include "fyc_common.h"
 
 namespace fycg {
+
+constexpr int FYC_MAX_DEVICES = 64;
 
 struct GemmP {
   const char* a; const char* a2; const char* w; const float* bias; const float* rowbias; const char* residual; char* out;
@@ -39,6 +43,10 @@ struct GemmP {
   float out_scale;
   int act;    // FYC_ACT_* (LINEAR epilogue)
   const float* ln_stats; const float* ln_colsum;   // folded LayerNorm (see fyc.h): acc := rstd*(acc - mean*colsum[n])
+  int ln_nparts; float ln_eps;                     // ln_nparts > 0: ln_stats holds [M][ln_nparts] partial {sum, sum sq} (row_parts of the producer)
+  // statistics of the OUTPUT for the GroupNorm / LayerNorm that consumes it (LINEAR epilogue), see fyc.h
+  double* chan_stats; int cs_rows;                 // [M / cs_rows][N][2] += {sum, sum sq} of the stored values per (sample, channel)
+  float* row_parts; int row_nparts;                // [M][row_nparts][2] = per row, per column tile {sum, sum sq}
   int tiles_m, tiles_n;
   int strip;  // > 0: tiles are walked in column strips of this many tiles (row-major inside a strip), see tile_coords
   int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
@@ -104,6 +112,66 @@ template <int RB> __device__ __forceinline__ int swz_key(int row) {
   return (0x78 >> (((row >> 2) & 3) * 2)) & 3;   // {0, 2, 3, 1}
 }
 
+// ---- output statistics (fused GroupNorm / LayerNorm statistics passes) ----------------------------------------------------
+// LDS accumulators of one output tile, placed behind the column constants: cacc[STAT_SLOTS][BN][2] per (sample slot, column)
+// and racc[BM][2] per row.  A tile of BM rows touches at most STAT_SLOTS samples (host: cs_rows % 16 == 0 and 64 or >= 128).
+constexpr int STAT_SLOTS = 4;
+template <int BM, int BN> constexpr int stat_bytes() { return (STAT_SLOTS * BN * 2 + BM * 2) * 4; }
+
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void stats_zero(float* cacc, int tid) {
+  for (int i = tid; i < STAT_SLOTS * BN * 2 + BM * 2; i += NT) cacc[i] = 0.f;
+}
+
+// after every wave finished accumulating: one f64 atomic pair per (sample slot, column) and one plain float2 store per row
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void stats_flush(const GemmP& p, const float* cacc, int tile_m, int tile_n, int tid) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const float* racc = cacc + STAT_SLOTS * BN * 2;
+  if (p.chan_stats != nullptr) {
+    const int first = (tile_m * BM) / p.cs_rows, nsamp = p.M / p.cs_rows;
+    for (int i = tid; i < STAT_SLOTS * BN; i += NT) {
+      const int slot = i / BN, col = i - slot * BN, n = tile_n * BN + col;
+      const float2 v = *reinterpret_cast<const float2*>(cacc + 2 * i);
+      if (n < p.N && first + slot < nsamp && (v.x != 0.f || v.y != 0.f)) {
+        double* dst = p.chan_stats + ((long long)(first + slot) * p.N + n) * 2;
+        unsafeAtomicAdd(dst, (double)v.x);
+        unsafeAtomicAdd(dst + 1, (double)v.y);
+      }
+    }
+  }
+  if (p.row_parts != nullptr) {
+    for (int r = tid; r < BM; r += NT) {
+      const int m = tile_m * BM + r;
+      if (m < p.M) *reinterpret_cast<float2*>(p.row_parts + ((long long)m * p.row_nparts + tile_n) * 2) = *reinterpret_cast<const float2*>(racc + 2 * r);
+    }
+  }
+}
+
+// {mean, rstd} of row m for the folded LayerNorm: either stored as such (fyc_row_stats) or derived from the producer's partial sums
+__device__ __forceinline__ void ln_row(const GemmP& p, int m, float& mu, float& rs) {
+  if (p.ln_nparts <= 0) {
+    const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2ll * m);
+    mu = ms.x; rs = ms.y;
+    return;
+  }
+  const float2* q = reinterpret_cast<const float2*>(p.ln_stats) + (long long)m * p.ln_nparts;
+  float2 t = q[0];
+  for (int i = 1; i < p.ln_nparts; ++i) { const float2 u = q[i]; t.x += u.x; t.y += u.y; }
+  const float inv = 1.0f / (float)p.K;
+  mu = t.x * inv;
+  rs = rsqrtf(fmaxf(t.y * inv - mu * mu, 0.f) + p.ln_eps);
+}
+
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+
 // Column constants of one output tile, staged through LDS once per tile: colc[0..BN) = bias (+ the rowbias row when it is the
 // same for the whole tile), colc[BN..2BN) = LayerNorm column sums.  Every global load in the epilogue is followed by an
 // s_waitcnt that also drains the next tile's K-tile DMA (loads return in order) and, with one block per CU, nothing hides
@@ -128,7 +196,10 @@ __device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc,
 
 // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j).
 // `stg_stage`: an LDS region of STG_BYTES that no wave reads any more once all waves passed the barrier inside.
-template <typename T, int BM, int BN, int WGM, int WGN, int EPI, int STG_BYTES, int MODE = FYC_GEMM_PLAIN>
+// WIDE (bf16 only, host-checked alignment: GemmP::wide) selects the LDS-staged 16-byte-access epilogues; the narrow per-lane
+// epilogue is a separate instantiation so that the hot kernels carry neither its code nor its register pressure (with both
+// in one kernel the narrow loops no longer unrolled and the whole accumulator array lived in scratch).
+template <typename T, int BM, int BN, int WGM, int WGN, int EPI, int STG_BYTES, int MODE, bool WIDE>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
                                               long long bz, char* stg_stage, int wave, int lane) {
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
@@ -138,7 +209,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
   // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
   const T* R = reinterpret_cast<const T*>(p.residual);
-  if (EPI == FYC_EPI_HEADS && sizeof(T) == 2 && p.wide) {
+  if constexpr (WIDE && EPI == FYC_EPI_HEADS) {
     // Wide head-split epilogue.  The plain path stores what a lane holds - 4 consecutive channels (8 B) for q / k and four
     // single bf16 values a whole row pitch apart for the transposed V^T.  Here each wave stages its f32 tile through LDS
     // (as the linear epilogue does) and then writes q / k as 16-byte runs along the head dimension and V^T as 16-byte runs
@@ -156,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     for (int i = 0; i < WTM; ++i) {
       const int m0 = tile_m * BM + (wm * WTM + i) * 16;            // first of the 16 token rows of this block (same batch element)
       float ln_mu = 0.f, ln_rs = 1.f;
-      if (LN && p.ln_stats && m0 + r16 < p.M) { const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2ll * (m0 + r16)); ln_mu = ms.x; ln_rs = ms.y; }
+      if (LN && p.ln_stats && m0 + r16 < p.M) ln_row(p, m0 + r16, ln_mu, ln_rs);
       const int b = m0 / p.tokens, tok0 = m0 - b * p.tokens;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -212,7 +283,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     }
     return;
   }
-  if (EPI != FYC_EPI_HEADS && sizeof(T) == 2 && p.wide) {
+  if constexpr (WIDE && EPI != FYC_EPI_HEADS) {
     // Wide epilogue (bf16 linear / GEGLU): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
     // 32-B row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
     // (profiles/r01_gemm_epilogue_ablation.txt).  Each wave therefore transposes its f32 results through a
@@ -222,6 +293,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     constexpr int OT = GLU ? WTN / 2 : WTN;            // 16-column output tiles per wave
     constexpr int JG = (OT + 1) / 2;                   // output tiles per pass
     constexpr int PITCH = JG * 64 + 16;                // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
+    constexpr bool STATS_FIT = WGM * WGN * 16 * PITCH + 2 * BN * 4 + stat_bytes<BM, BN>() <= STG_BYTES;
     static_assert(WGM * WGN * 16 * PITCH + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
     char* stg = stg_stage + wave * (16 * PITCH);
@@ -229,13 +301,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     const int o_w0 = GLU ? (n_w0 >> 1) : n_w0;         // first output column of this wave
     const int n_out = GLU ? (p.N >> 1) : p.N;
     float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * 16 * PITCH);   // [2][BN], see stage_col_constants
+    // output statistics (LINEAR): per-(sample, column) and per-row {sum, sum sq} of the values as stored, see stats_flush
+    float* cacc = colc + 2 * BN;
+    float* racc = cacc + STAT_SLOTS * BN * 2;
+    const bool do_cs = !GLU && STATS_FIT && p.chan_stats != nullptr, do_rp = !GLU && STATS_FIT && p.row_parts != nullptr;
+    if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);
     stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+    const int first_sample = do_cs ? (tile_m * BM) / p.cs_rows : 0;
     float ln_mu[WTM], ln_rs[WTM];
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
       ln_mu[i] = 0.f; ln_rs[i] = 1.f;
-      if (LN && p.ln_stats && m_lane < p.M) { const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2ll * m_lane); ln_mu[i] = ms.x; ln_rs[i] = ms.y; }
+      if (LN && p.ln_stats && m_lane < p.M) ln_row(p, m_lane, ln_mu[i], ln_rs[i]);
     }
     const int nl_w0 = wn * WTN * 16;                   // this wave's first column inside the tile
 #pragma unroll
@@ -244,6 +322,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
       const int nj = (OT - j0 < JG) ? (OT - j0) : JG;
       if (nj <= 0) continue;
       const int cpr = nj * 2;                           // 8-element chunks per staged row
+      // store pass: a lane keeps ONE 8-column chunk (lch) and walks rows lrow, lrow + rpp, ...: stores still cover whole
+      // contiguous row segments, and the per-column statistics accumulate in registers over all rows of the pass
+      const int rpp = 64 / cpr;                         // rows per store instruction
+      const int lrow = lane / cpr, lch = lane - lrow * cpr;
+      const bool lact = lrow < rpp;
+      float cs8[8], cq8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
+      int cur_slot = -1;
+      auto flush_cols = [&]() {
+        if (do_cs && lact && cur_slot >= 0) {
+          float* dst = cacc + ((cur_slot * BN) + nl_w0 + j0 * 16 + lch * 8) * 2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { lds_add(dst + 2 * e, cs8[e]); lds_add(dst + 2 * e + 1, cq8[e]); cs8[e] = cq8[e] = 0.f; }
+        }
+      };
 #pragma unroll
       for (int i = 0; i < WTM; ++i) {
         const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
@@ -287,11 +381,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int c = lane; c < 16 * cpr; c += 64) {
-          const int row = c / cpr, ch = c - row * cpr;
+        if (do_cs) {                                     // sample slot of this 16-row block (wave-uniform)
+          const int slot = (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample;
+          if (slot != cur_slot) { flush_cols(); cur_slot = slot; }
+        }
+        for (int r0 = 0; r0 < 16; r0 += rpp) {
+          const int row = r0 + lrow, ch = lch;
           const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
           const int n = o_w0 + j0 * 16 + ch * 8;
-          if (m < p.M && n < n_out) {
+          if (lact && row < 16 && m < p.M && n < n_out) {
             float v[8];
             *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
             *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
@@ -306,24 +404,46 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
               for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
             }
             store8<T>(O + (long long)m * p.ldo + n, v);
+            if (do_cs || do_rp) {
+              float rs = 0.f, rq = 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float x = round_to<T>(v[e]);
+                cs8[e] += x; cq8[e] = __builtin_fmaf(x, x, cq8[e]);
+                rs += x; rq = __builtin_fmaf(x, x, rq);
+              }
+              if (do_rp) { float* dst = racc + ((wm * WTM + i) * 16 + row) * 2; lds_add(dst, rs); lds_add(dst + 1, rq); }
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      flush_cols();
     }
+    if (do_cs || do_rp) stats_flush<BM, BN, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
     return;
   }
+  if constexpr (!WIDE) {
   float* colc = reinterpret_cast<float*>(stg_stage);
-  if (p.colc) {
+  constexpr bool STATS_OK = (EPI == FYC_EPI_LINEAR || EPI == EPI_LINEAR_ACT) && 2 * BN * 4 + stat_bytes<BM, BN>() <= STG_BYTES;
+  float* cacc = colc + 2 * BN;
+  float* racc = cacc + STAT_SLOTS * BN * 2;
+  const bool do_cs = STATS_OK && p.chan_stats != nullptr, do_rp = STATS_OK && p.row_parts != nullptr;
+  if (p.colc || do_cs || do_rp) {
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
-    stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+    if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);
+    if (p.colc) stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+    else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
   }
+  const int first_sample = do_cs ? (tile_m * BM) / p.cs_rows : 0;
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
     const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
     if (m >= p.M) continue;
+    float st_rs = 0.f, st_rq = 0.f;                    // row statistics of this lane's columns
+    const int st_slot = do_cs ? (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample : 0;
     float ln_mu = 0.f, ln_rs = 1.f;
-    if (LN && p.ln_stats) { const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2ll * m); ln_mu = ms.x; ln_rs = ms.y; }
+    if (LN && p.ln_stats) ln_row(p, m, ln_mu, ln_rs);
     if (EPI == FYC_EPI_GEGLU) {
       // packed columns: [32b, 32b+16) = value channels 16b.., [32b+16, 32b+32) = their gates
 #pragma unroll
@@ -394,6 +514,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           } else {
             for (int r = 0; r < 4 && n + r < p.N; ++r) ElemIO<T>::st(O + (long long)m * p.ldo + n + r, v[r]);
           }
+          if (do_cs || do_rp) {
+            const int nl = (wn * WTN + j) * 16 + g * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (full || n + r < p.N) {
+                const float x = round_to<T>(v[r]);
+                st_rs += x; st_rq = __builtin_fmaf(x, x, st_rq);
+                if (do_cs) { float* dst = cacc + ((st_slot * BN) + nl + r) * 2; lds_add(dst, x); lds_add(dst + 1, x * x); }
+              }
+            }
+          }
         } else {  // FYC_EPI_HEADS: split columns into segments (q|k|v) and heads
           const int seg = n / p.seg_cols, c = n - seg * p.seg_cols;
           const int h = c / p.head_dim, di = c - h * p.head_dim;
@@ -410,11 +541,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           }
         }
       }
+      if (do_rp) { float* dst = racc + ((wm * WTM + i) * 16 + r16) * 2; lds_add(dst, st_rs); lds_add(dst + 1, st_rq); }
     }
   }
+  if (do_cs || do_rp) stats_flush<BM, BN, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
+  }  // !WIDE
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false>
 __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) {
   typedef Mma<T> Tr;
   typedef typename Tr::Frag Frag;
@@ -452,52 +586,31 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   const T* __restrict__ A2 = reinterpret_cast<const T*>(p.a2);   // optional second K source (PLAIN): A = [a | a2]
   const T* zero = reinterpret_cast<const T*>(p.zero);
 
-  // ---- per-thread loader descriptors of the tile being ISSUED ----------------------------------
-  int a_koff[A_IT];
-  long long a_row[A_IT];   // PLAIN: m*lda, or -1 when the row is outside M
-  long long a_row2[A_IT];  // PLAIN dual source: m*lda2
-  int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
-  int b_koff[B_IT];
-  long long b_row[B_IT];
+  // ---- per-thread loader state of the tile being ISSUED --------------------------------------------
+  // Kept small on purpose (the 256x320 tile runs at the 256-VGPR cap and used to spill its 45 descriptor registers around the
+  // epilogue): a thread's LDS row inside a tile is lrow + it*(NT/CPR) and, because NT/CPR is a multiple of 16, its swizzled
+  // K offset is the same for every `it` and for both operands.  Addresses are rebuilt from (tile, it) at issue time (a few
+  // VALU ops per 1 KiB DMA); only the conv gather keeps per-row state (pixel base and packed top-left tap position).
+  const int lrow = tid / CPR;
+  const int koff = ((tid % CPR) ^ swz_key<RB>(lrow)) * CH;
+  constexpr int ROWS_IT = NT / CPR;
+  static_assert(ROWS_IT % 16 == 0, "row stride per DMA instruction must keep the swizzle key");
+  int i_tm = 0, i_tn = 0;                 // tile coordinates of the tile being issued (wave-uniform)
+  int a_pix[MODE == FYC_GEMM_PLAIN ? 1 : A_IT], a_yx[MODE == FYC_GEMM_PLAIN ? 1 : A_IT];   // conv: frame pixel base (-1: row outside M), (iy0 << 16) | (ix0 & 0xffff)
   int tap = 0, c0 = 0;  // conv: filter tap and channel offset of the K tile being issued
-#pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    const int idx = tid + it * NT, row = idx / CPR, slot = idx % CPR;
-    a_koff[it] = ((slot ^ swz_key<RB>(row)) * CH);
-  }
-#pragma unroll
-  for (int it = 0; it < B_IT; ++it) {
-    const int idx = tid + it * NT, row = idx / CPR, slot = idx % CPR;
-    b_koff[it] = ((slot ^ swz_key<RB>(row)) * CH);
-  }
   auto setup_issue = [&](int tile) {
     const int t = remap(tile);
-    int tile_m, tile_n;
-    tile_coords(p, t, tile_m, tile_n);
+    tile_coords(p, t, i_tm, i_tn);
     tap = 0; c0 = 0;
+    if (MODE != FYC_GEMM_PLAIN) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int row = (tid + it * NT) / CPR;
-      const int m = tile_m * BM + row;
-      if (MODE == FYC_GEMM_PLAIN) {
-        a_row[it] = (m < p.M) ? (long long)m * p.lda : -1;
-        a_row2[it] = (long long)m * p.lda2;
-        a_pix[it] = a_iy0[it] = a_ix0[it] = 0;
-      } else {
+      for (int it = 0; it < A_IT; ++it) {
+        const int m = i_tm * BM + lrow + it * ROWS_IT;
         const int hw = p.Hout * p.Wout;
         const int fr = m / hw, rem = m - fr * hw, oy = rem / p.Wout, ox = rem - oy * p.Wout;
-        a_row[it] = (m < p.M) ? 0 : -1;
-        a_row2[it] = 0;
-        a_pix[it] = fr * p.Hin * p.Win;
-        a_iy0[it] = oy * p.conv_stride - p.conv_pad;
-        a_ix0[it] = ox * p.conv_stride - p.conv_pad;
+        a_pix[it] = (m < p.M) ? fr * p.Hin * p.Win : -1;
+        a_yx[it] = ((oy * p.conv_stride - p.conv_pad) << 16) | ((ox * p.conv_stride - p.conv_pad) & 0xffff);
       }
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int row = (tid + it * NT) / CPR;
-      const int n = tile_n * BN + row;
-      b_row[it] = (n < p.N) ? (long long)n * p.ldw : -1;
     }
   };
 
@@ -505,31 +618,33 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 
   auto src_a = [&](int it, int k0) -> const T* {
     if (MODE == FYC_GEMM_PLAIN) {
-      const int k = k0 + a_koff[it];
-      if (a_row[it] < 0 || k >= p.K) return zero;
-      if (A2 != nullptr && k >= p.k_split) return A2 + a_row2[it] + (k - p.k_split);
-      return A + a_row[it] + k;
+      const int m = i_tm * BM + lrow + it * ROWS_IT;
+      const int k = k0 + koff;
+      if (m >= p.M || k >= p.K) return zero;
+      if (A2 != nullptr && k >= p.k_split) return A2 + (long long)m * p.lda2 + (k - p.k_split);
+      return A + (long long)m * p.lda + k;
     } else {
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const int iy = a_iy0[it] + ky, ix = a_ix0[it] + kx;
+      const int iy = (a_yx[it] >> 16) + ky, ix = (int)(short)(a_yx[it] & 0xffff) + kx;
       if (MODE == FYC_GEMM_CONV3X3) {
-        const bool ok = a_row[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-        return ok ? A + (long long)(a_pix[it] + iy * p.Win + ix) * p.Cin + c0 + a_koff[it] : zero;
+        const bool ok = a_pix[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        return ok ? A + (long long)(a_pix[it] + iy * p.Win + ix) * p.Cin + c0 + koff : zero;
       } else {  // nearest-upsampled input of virtual size (Hout, Wout): F.interpolate(mode="nearest") folded into the gather
-        const bool ok = a_row[it] >= 0 && (unsigned)iy < (unsigned)p.Hout && (unsigned)ix < (unsigned)p.Wout;
+        const bool ok = a_pix[it] >= 0 && (unsigned)iy < (unsigned)p.Hout && (unsigned)ix < (unsigned)p.Wout;
         int sy, sx;
         if (p.up_exact2) { sy = iy >> 1; sx = ix >> 1; }
         else {  // torch: src = min(floor(dst * (in / out)), in - 1), scale in f32
           sy = min((int)floorf((float)iy * p.up_sh), p.Hin - 1);
           sx = min((int)floorf((float)ix * p.up_sw), p.Win - 1);
         }
-        return ok ? A + (long long)(a_pix[it] + sy * p.Win + sx) * p.Cin + c0 + a_koff[it] : zero;
+        return ok ? A + (long long)(a_pix[it] + sy * p.Win + sx) * p.Cin + c0 + koff : zero;
       }
     }
   };
   auto src_b = [&](int it, int k0) -> const T* {
-    const int k = k0 + b_koff[it];
-    return (b_row[it] >= 0 && k < p.K) ? W + b_row[it] + k : zero;
+    const int n = i_tn * BN + lrow + it * ROWS_IT;
+    const int k = k0 + koff;
+    return (n < p.N && k < p.K) ? W + (long long)n * p.ldw + k : zero;
   };
 
   f32x4 acc[WTM][WTN];
@@ -611,19 +726,33 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     int tile_m, tile_n;
     tile_coords(p, t, tile_m, tile_n);
 
-    gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
+    gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE, WIDE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
   }  // tile stream
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false>
 int launch(const GemmP& p, int batch, hipStream_t st) {
   constexpr int smem = NS * (BM + BN) * RB;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS, RB>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS, RB, WIDE>;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  // per-device one-time setup (attribute + CU count), guarded: one process may drive several GPUs from several threads
+  static std::mutex mu;
+  static bool attr_done[FYC_MAX_DEVICES] = {};
+  static int n_cu_dev[FYC_MAX_DEVICES] = {};
+  int n_cu = 256;
+  if (dev >= 0 && dev < FYC_MAX_DEVICES) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr_done[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      hipDeviceProp_t pr;
+      n_cu_dev[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+      attr_done[dev] = true;
+    }
+    n_cu = n_cu_dev[dev];
+  } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
   }
   GemmP q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
@@ -631,13 +760,6 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
   q.strip = (q.tiles_n > 4 && g_fyc_tuning[4] >= 0) ? (g_fyc_tuning[4] > 0 ? g_fyc_tuning[4] : (q.tiles_n >= 16 ? 8 : 4)) : 0;   // measured: profiles/r01_gemm_strip_order.txt
   // persistent grid: as many blocks as stay resident (LDS-limited), each walks a strided tile list
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
   int occ = (160 * 1024) / smem;
   const int wave_cap = 32 / (WGM * WGN);
   if (occ > wave_cap) occ = wave_cap;
@@ -653,33 +775,41 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
 
 // tile configurations: id -> (BM, BN, WGM, WGN)
 //   1: 128x128, 4 waves   2: 128x64, 4 waves   3: 256x128, 8 waves   4: 256x64, 4 waves
-//   5: 256x320, 8 waves   6: 128x320, 8 waves  7: 256x256, 8 waves   (5-7: 2-deep ring only, 1 block/CU)
-template <typename T, int MODE, int EPI, int NS>
-int dispatch_cfg(int cfg, const GemmP& p, int batch, hipStream_t st) {
-  switch (cfg) {
-    case 1: return launch<T, 128, 128, 2, 2, MODE, EPI, NS>(p, batch, st);
-    case 2: return launch<T, 128, 64, 2, 2, MODE, EPI, NS>(p, batch, st);
-    case 3: if constexpr (NS <= 3) return launch<T, 256, 128, 4, 2, MODE, EPI, NS>(p, batch, st); else break;
-    case 4: return launch<T, 256, 64, 4, 1, MODE, EPI, NS>(p, batch, st);
-    // N = 320*k (every layer width of SD-1.5): 320-wide tiles read the A panel once per 320 columns
-    case 5: if constexpr (NS == 2) return launch<T, 256, 320, 4, 2, MODE, EPI, NS>(p, batch, st); else break;
-    case 6: if constexpr (NS == 2) return launch<T, 128, 320, 2, 4, MODE, EPI, NS>(p, batch, st); else break;
-    case 7: if constexpr (NS == 2) return launch<T, 256, 256, 2, 4, MODE, EPI, NS>(p, batch, st); else break;
-    // 64-byte K tiles: half the LDS per stage -> two independent 4-wave blocks per CU with 64x160 wave tiles (8)
-    case 8: if constexpr (NS == 2 && sizeof(T) == 2) return launch<T, 128, 320, 2, 2, MODE, EPI, 2, 64>(p, batch, st); else break;
-    case 10: if constexpr (NS == 2 && sizeof(T) == 2) return launch<T, 128, 128, 2, 2, MODE, EPI, 2, 64>(p, batch, st); else break;
+//   5: 256x320, 8 waves   6: 128x320, 8 waves  7: 256x256, 8 waves   8 / 10: 128x320 / 128x128 with 64-byte K tiles
+// All use the 2-deep ring (deeper rings measured no gain, profiles/r01_gemm_tile_sweep*.txt); config 1 is also built 3-deep so
+// that the counted-wait ring logic stays exercised (tests).  The narrow epilogue (WIDE = false: f32 parity mode and bf16
+// problems whose shapes / alignment rule out 16-byte accesses) only exists for configs 1 and 2.
+template <typename T, int MODE, int EPI, bool WIDE>
+int dispatch_cfg(int cfg, int ns, const GemmP& p, int batch, hipStream_t st) {
+  if constexpr (!WIDE) {
+    if (cfg != 1 && cfg != 2) cfg = (p.N % 128 == 0 || p.N > 512) ? 1 : 2;
+    if (cfg == 1) return launch<T, 128, 128, 2, 2, MODE, EPI, 2, 128, false>(p, batch, st);
+    return launch<T, 128, 64, 2, 2, MODE, EPI, 2, 128, false>(p, batch, st);
+  } else {
+    switch (cfg) {
+      case 1: if (ns == 3) return launch<T, 128, 128, 2, 2, MODE, EPI, 3, 128, true>(p, batch, st);
+              return launch<T, 128, 128, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
+      case 2: return launch<T, 128, 64, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
+      case 3: return launch<T, 256, 128, 4, 2, MODE, EPI, 2, 128, true>(p, batch, st);
+      case 4: return launch<T, 256, 64, 4, 1, MODE, EPI, 2, 128, true>(p, batch, st);
+      // N = 320*k (every layer width of SD-1.5): 320-wide tiles read the A panel once per 320 columns
+      case 5: return launch<T, 256, 320, 4, 2, MODE, EPI, 2, 128, true>(p, batch, st);
+      case 6: return launch<T, 128, 320, 2, 4, MODE, EPI, 2, 128, true>(p, batch, st);
+      case 7: return launch<T, 256, 256, 2, 4, MODE, EPI, 2, 128, true>(p, batch, st);
+      // 64-byte K tiles: half the LDS per stage -> two independent 4-wave blocks per CU with 64x160 wave tiles (8)
+      case 8: return launch<T, 128, 320, 2, 2, MODE, EPI, 2, 64, true>(p, batch, st);
+      case 10: return launch<T, 128, 128, 2, 2, MODE, EPI, 2, 64, true>(p, batch, st);
+    }
+    FYC_FAIL(-2, "fyc_gemm: tile config %d not built", cfg);
   }
-  FYC_FAIL(-2, "fyc_gemm: tile config %d / ring depth %d not built", cfg, NS);
 }
 
 template <typename T, int MODE, int EPI>
 int dispatch_ns(int ns, int cfg, const GemmP& p, int batch, hipStream_t st) {
-  switch (ns) {
-    case 2: return dispatch_cfg<T, MODE, EPI, 2>(cfg, p, batch, st);
-    case 3: return dispatch_cfg<T, MODE, EPI, 3>(cfg, p, batch, st);
-    case 4: return dispatch_cfg<T, MODE, EPI, 4>(cfg, p, batch, st);
+  if constexpr (sizeof(T) == 2) {
+    if (p.wide) return dispatch_cfg<T, MODE, EPI, true>(cfg, ns, p, batch, st);
   }
-  FYC_FAIL(-2, "fyc_gemm: ring depth %d not built", ns);
+  return dispatch_cfg<T, MODE, EPI, false>(cfg, ns, p, batch, st);
 }
 
 // one translation unit per (dtype, family) keeps the build parallel

@@ -108,6 +108,87 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// ---- GroupNorm apply from per-(sample, channel) sums (+SiLU), optional channel concat of two sources ---------------------
+// The sums come from the epilogues of the GEMMs / convs that produced x1 (and x2): no statistics pass over the tensor.
+// grid = (row chunks, samples).  Prologue: 8 lanes per group fold the group's channels (f64), every thread then keeps
+// scale = rstd*gamma and shift = beta - mean*scale of ITS 8 channels in registers; the loop is load - fma - (silu) - store.
+template <typename T>
+__global__ void __launch_bounds__(512) gn_apply_cs_kernel(const T* __restrict__ x1, const double* __restrict__ cs1, int C1,
+                                                          const T* __restrict__ x2, const double* __restrict__ cs2, int C2,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          T* __restrict__ y, int groups, int rows_per_sample, int rows_per_block,
+                                                          float eps, int silu, int stat_samples) {
+  extern __shared__ float sh[];   // [2][groups]: mean, rstd
+  const int tid = threadIdx.x, nthr = blockDim.x, C = C1 + C2, C8 = C >> 3, cpg = C / groups;
+  const int sample = blockIdx.y;
+  {
+    const double inv_cnt = 1.0 / ((double)rows_per_sample * cpg);
+    for (int gi = tid >> 3; gi < groups; gi += nthr >> 3) {
+      double s = 0.0, q = 0.0;
+      // the sums come per statistics sample (a frame); a GroupNorm sample spans `stat_samples` of them (cross-frame norms: F)
+      for (int c = gi * cpg + (tid & 7); c < (gi + 1) * cpg; c += 8) {
+        for (int f = 0; f < stat_samples; ++f) {
+          const long long ss = (long long)sample * stat_samples + f;
+          const double* src = c < C1 ? cs1 + (ss * C1 + c) * 2 : cs2 + (ss * C2 + (c - C1)) * 2;
+          s += src[0]; q += src[1];
+        }
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+      if ((tid & 7) == 0) {
+        const double m = s * inv_cnt;
+        double var = q * inv_cnt - m * m;   // f64 subtraction keeps the cancellation harmless
+        var = var > 0.0 ? var : 0.0;
+        sh[gi] = (float)m;
+        sh[groups + gi] = rsqrtf((float)var + eps);
+      }
+    }
+  }
+  __syncthreads();
+  const int rpi = nthr / C8;
+  if (tid >= rpi * C8) return;
+  const int c8 = tid % C8, r0 = tid / C8;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c8 * 8 + i, gi = c / cpg;
+    sc[i] = sh[groups + gi] * gamma[c];
+    sf[i] = beta[c] - sh[gi] * sc[i];
+  }
+  const bool from1 = c8 * 8 < C1;
+  const T* src = from1 ? x1 + (long long)sample * rows_per_sample * C1 + c8 * 8 : x2 + (long long)sample * rows_per_sample * C2 + (c8 * 8 - C1);
+  const int ld = from1 ? C1 : C2;
+  T* dst = y + (long long)sample * rows_per_sample * C + c8 * 8;
+  const int row_begin = blockIdx.x * rows_per_block;
+  const int row_end = min(row_begin + rows_per_block, rows_per_sample);
+  auto fin = [&](float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float o = __builtin_fmaf(v[i], sc[i], sf[i]);
+      v[i] = silu ? silu_f(o) : o;
+    }
+  };
+  int r = row_begin + r0;
+  for (; r + 3 * rpi < row_end; r += 4 * rpi) {
+    float v0[8], v1[8], v2[8], v3[8];
+    load8<T>(src + (long long)r * ld, v0);
+    load8<T>(src + (long long)(r + rpi) * ld, v1);
+    load8<T>(src + (long long)(r + 2 * rpi) * ld, v2);
+    load8<T>(src + (long long)(r + 3 * rpi) * ld, v3);
+    fin(v0); fin(v1); fin(v2); fin(v3);
+    store8<T>(dst + (long long)r * C, v0);
+    store8<T>(dst + (long long)(r + rpi) * C, v1);
+    store8<T>(dst + (long long)(r + 2 * rpi) * C, v2);
+    store8<T>(dst + (long long)(r + 3 * rpi) * C, v3);
+  }
+  for (; r < row_end; r += rpi) {
+    float v[8];
+    load8<T>(src + (long long)r * ld, v);
+    fin(v);
+    store8<T>(dst + (long long)r * C, v);
+  }
+}
+
 // ---- LayerNorm: 16 lanes per row (4 rows per wave, 16 rows per block) -----------------------------
 // A row of C = 320..1280 channels is only 640..2560 B: one wave per row leaves most lanes idle and
 // little memory in flight.  Here 16 lanes own a row (lane p takes 16-B chunks p, p+16, ...), the two
@@ -244,6 +325,38 @@ extern "C" int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream) {
                        (float*)a->y, chunks, a->C, a->groups, a->rows_per_sample, a->eps, a->silu);
   else FYC_FAIL(-2, "fyc_gn_apply: bad dtype");
   FYC_CHECK_LAUNCH("fyc_gn_apply");
+  return 0;
+}
+
+extern "C" int fyc_gn_apply_cs(const fyc_gn_apply_cs_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x1 && a->cs1 && a->gamma && a->beta && a->y, "fyc_gn_apply_cs: null pointer");
+  FYC_REQUIRE((a->x2 == nullptr) == (a->C2 == 0) && (a->x2 == nullptr) == (a->cs2 == nullptr), "fyc_gn_apply_cs: x2 / cs2 / C2 must come together");
+  const int C = a->C1 + a->C2;
+  FYC_REQUIRE(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->groups > 0 && C % a->groups == 0 && C / 8 <= 512, "fyc_gn_apply_cs: C1=%d C2=%d groups=%d", a->C1, a->C2, a->groups);
+  FYC_REQUIRE(a->rows_per_sample > 0 && a->rows % a->rows_per_sample == 0, "fyc_gn_apply_cs: rows=%d rows_per_sample=%d", a->rows, a->rows_per_sample);
+  const int cs_rows = a->cs_rows > 0 ? a->cs_rows : a->rows_per_sample;
+  FYC_REQUIRE(a->rows_per_sample % cs_rows == 0, "fyc_gn_apply_cs: rows_per_sample=%d is not a multiple of cs_rows=%d", a->rows_per_sample, cs_rows);
+  const int stat_samples = a->rows_per_sample / cs_rows;
+  hipStream_t st = (hipStream_t)stream;
+  const int samples = a->rows / a->rows_per_sample;
+  const int c8 = C / 8;
+  const int nthr = c8 >= 256 ? ((c8 + 63) / 64) * 64 : 256;
+  const int rpi = nthr / c8;
+  // ~2048 blocks in total, at least 8 row iterations per block so that the prologue (statistics fold) amortises
+  int chunks = (int)ceil_div64(2048, samples);
+  int rpb = (int)ceil_div64(a->rows_per_sample, chunks);
+  if (rpb < 8 * rpi) rpb = 8 * rpi;
+  chunks = (int)ceil_div64(a->rows_per_sample, rpb);
+  dim3 grid(chunks, samples);
+  const size_t sh = sizeof(float) * 2 * a->groups;
+  if (a->dtype == FYC_BF16)
+    hipLaunchKernelGGL(gn_apply_cs_kernel<bf16_t>, grid, dim3(nthr), sh, st, (const bf16_t*)a->x1, a->cs1, a->C1, (const bf16_t*)a->x2, a->cs2, a->C2,
+                       a->gamma, a->beta, (bf16_t*)a->y, a->groups, a->rows_per_sample, rpb, a->eps, a->silu, stat_samples);
+  else if (a->dtype == FYC_F32)
+    hipLaunchKernelGGL(gn_apply_cs_kernel<float>, grid, dim3(nthr), sh, st, (const float*)a->x1, a->cs1, a->C1, (const float*)a->x2, a->cs2, a->C2,
+                       a->gamma, a->beta, (float*)a->y, a->groups, a->rows_per_sample, rpb, a->eps, a->silu, stat_samples);
+  else FYC_FAIL(-2, "fyc_gn_apply_cs: bad dtype");
+  FYC_CHECK_LAUNCH("fyc_gn_apply_cs");
   return 0;
 }
 

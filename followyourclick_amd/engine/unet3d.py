@@ -17,7 +17,8 @@ The only torch calls are allocation (`torch.empty/zeros`) and host->device copie
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Sequence
+import os
+from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -28,6 +29,20 @@ from .config import UNet3DConfig
 from .weights import Packed
 
 Tensor = torch.Tensor
+
+# Statistics of an activation are accumulated by the epilogue of the GEMM / conv that writes it (fyc_gemm chan_stats / row_parts)
+# instead of by a read pass per GroupNorm / LayerNorm.  FYC_FUSE_STATS=0 restores the separate passes (A/B measurements).
+FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
+ARENA_DOUBLES = 8 << 20      # 64 MiB of f64 sums per forward (cfg2 needs ~2.5 M doubles); larger requests get their own buffer
+
+
+class Act:
+    """an activation [rows][C] plus what its producer already knows about it: `cs` = per-(GroupNorm sample, channel)
+    {sum, sum of squares} ([rows / cs_rows][C][2] f64), `rp` = per-row partial {sum, sum sq} ([rows][rp_n][2] f32)"""
+    __slots__ = ("t", "C", "cs", "cs_rows", "rp", "rp_n")
+
+    def __init__(self, t: Tensor, C: int, cs: Optional[Tensor] = None, cs_rows: int = 0, rp: Optional[Tensor] = None, rp_n: int = 0):
+        self.t, self.C, self.cs, self.cs_rows, self.rp, self.rp_n = t, C, cs, cs_rows, rp, rp_n
 
 
 def sinusoid_host(values: Sequence[float], dim: int) -> Tensor:
@@ -59,6 +74,9 @@ class UNet3DEngine(EngineBase):
         for i, t in enumerate(self.transformers):
             t["idx"] = i
         self.ctx_cache = None
+        self.fuse_stats = FUSE_STATS
+        self._arena = None           # f64 bump arena for the channel statistics of one forward
+        self._arena_off = self._arena_dirty = 0
         self.ops.ensure_init(self.device)
 
     # ---- once per clip ---------------------------------------------------------------------
@@ -153,6 +171,68 @@ class UNet3DEngine(EngineBase):
         self.ops.row_stats(x, st, rows=rows, C_=C, eps=eps)
         return st
 
+    # ---- fused statistics ------------------------------------------------------------------------
+    def _begin_forward(self) -> None:
+        if self._arena is None:
+            self._arena = torch.zeros(ARENA_DOUBLES, dtype=torch.float64, device=self.device)
+        elif self._arena_dirty:
+            self._arena[: self._arena_dirty].zero_()     # one memset for all GroupNorm statistics of the forward
+        self._arena_off = self._arena_dirty = 0
+
+    def _cs_ok(self, rows_per_sample: int) -> bool:
+        return self.fuse_stats and rows_per_sample % 16 == 0 and (rows_per_sample == 64 or rows_per_sample >= 128)
+
+    def _cs_new(self, rows: int, rows_per_sample: int, C: int) -> Optional[Tensor]:
+        """zeroed [rows / rows_per_sample][C][2] f64 for the producer's epilogue, or None when the shape cannot be fused"""
+        if not self._cs_ok(rows_per_sample) or rows % rows_per_sample:
+            return None
+        n = (rows // rows_per_sample) * C * 2
+        if self._arena is None or self._arena_off + n > self._arena.numel():
+            return torch.zeros(n, dtype=torch.float64, device=self.device)
+        v = self._arena[self._arena_off: self._arena_off + n]
+        self._arena_off += n
+        self._arena_dirty = self._arena_off
+        return v
+
+    def _gn(self, x: Union[Act, Tuple[Act, Act]], gamma: Tensor, beta: Tensor, rows: int, rows_per_sample: int, eps: float,
+            silu: bool) -> Tuple[Tensor, Optional[Tensor]]:
+        """GroupNorm (+SiLU) of an activation or of the channel concat of two (up blocks: cat([hidden, skip], dim=1),
+        reference unet_blocks.py:763,885).  Returns (normalised tensor, materialised concat or None)."""
+        o = self.ops
+        if isinstance(x, Act):
+            if x.cs is not None and rows_per_sample % x.cs_rows == 0:
+                y = self.new(rows, x.C)
+                o.gn_apply_cs(x.t, x.cs, gamma, beta, y, rows=rows, C1=x.C, groups=self.groups, rows_per_sample=rows_per_sample,
+                              eps=eps, silu=silu, cs_rows=x.cs_rows)
+                return y, None
+            return self.group_norm(x.t, gamma, beta, rows, x.C, rows_per_sample, eps, silu), None
+        a, b = x
+        if a.cs is not None and b.cs is not None and a.cs_rows == b.cs_rows and rows_per_sample % a.cs_rows == 0:
+            y = self.new(rows, a.C + b.C)
+            o.gn_apply_cs(a.t, a.cs, gamma, beta, y, rows=rows, C1=a.C, groups=self.groups, rows_per_sample=rows_per_sample,
+                          eps=eps, silu=silu, x2=b.t, cs2=b.cs, C2=b.C, cs_rows=a.cs_rows)
+            return y, None
+        cat = self.new(rows, a.C + b.C)
+        o.concat_channels(a.t, b.t, cat, rows=rows, c1=a.C, c2=b.C)
+        return self.group_norm(cat, gamma, beta, rows, a.C + b.C, rows_per_sample, eps, silu), cat
+
+    def _lin_rp(self, x: Tensor, w: Tensor, rows: int, bias=None, residual=None) -> Act:
+        """Linear whose output feeds a (folded) LayerNorm: the epilogue also writes the per-row partial sums"""
+        N, K = w.shape
+        out = self.new(rows, N, dtype=x.dtype)
+        rp, n = None, 0
+        if self.fuse_stats:
+            n = self.ops.gemm_row_parts(x.dtype, M=rows, N=N, K=K)
+            rp = torch.empty(rows, n, 2, dtype=torch.float32, device=self.device)
+        self.ops.gemm(x, w, out, M=rows, N=N, K=K, lda=K, ldw=K, ldo=N, bias=bias, residual=residual, ldr=N, row_parts=rp, row_nparts=n)
+        return Act(out, N, rp=rp, rp_n=n)
+
+    def _ln_args(self, tok: Act, rows: int, C: int) -> dict:
+        """ln_stats arguments of the GEMM that consumes LayerNorm(tok): the producer's partial sums, or a statistics pass"""
+        if tok.rp is not None:
+            return dict(ln_stats=tok.rp, ln_nparts=tok.rp_n, ln_eps=1e-5)
+        return dict(ln_stats=self.row_stats(tok.t, rows, C))
+
     def _pe_rowbias(self, a: Packed, B: int, F: int) -> Tensor:
         """pe_f W_qkv^T for token rows ordered [(b f)][pixel]: one row per (b, f)"""
         key = (B, F)
@@ -173,67 +253,94 @@ class UNet3DEngine(EngineBase):
         self.ops.gemm(x, self._eyes[key], y, M=rows, N=C, K=C, lda=C, ldw=C, ldo=C, residual=y, ldr=C)
 
     # ---- blocks --------------------------------------------------------------------------------
-    def resnet(self, r: Packed, x: Tensor, temb: Tensor, g: dict) -> Tensor:
-        """ResnetBlock3D (reference resnet.py:296-342): cross-frame GroupNorm statistics."""
+    # `nxt` = rows per statistics sample the producing epilogue accumulates for the GroupNorm that consumes a block's output.  It
+    # is always one frame (H*W rows): per-frame norms (transformer / motion module) use the sums as they are, cross-frame norms
+    # (ResNet, conv_norm_out) add up the F frame sums in fyc_gn_apply_cs - 16x more atomic targets than per-clip sums.
+    def _conv_act(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, nxt: int, **kw) -> Act:
+        Cout = w.shape[0]
+        if kw.get("up2"):
+            Ho, Wo = kw["up_size"]
+        else:
+            st = kw.get("stride", 1)
+            Ho, Wo = (Hin - 1) // st + 1, (Win - 1) // st + 1
+        rows = frames * Ho * Wo
+        cs = self._cs_new(rows, nxt, Cout) if nxt else None
+        return Act(self.conv(x, w, b, frames, Hin, Win, chan_stats=cs, cs_rows=nxt if cs is not None else 0, **kw), Cout, cs, nxt)
+
+    def resnet(self, r: Packed, x: Union[Act, Tuple[Act, Act]], temb: Tensor, g: dict, nxt: int) -> Act:
+        """ResnetBlock3D (reference resnet.py:296-342): cross-frame GroupNorm statistics.  x may be the (hidden, skip) pair of an
+        up block: the concat only ever exists normalised (norm1's output); the 1x1 shortcut reads both sources (dual-K GEMM)."""
         rows, rpb = g["rows"], g["F"] * g["H"] * g["W"]
         frames = g["B"] * g["F"]
-        cin_p = r.c1_w.shape[1] // 9
-        h = self.group_norm(x, r.n1_g, r.n1_b, rows, cin_p, rpb, self.cfg.norm_eps, True)
+        h, cat = self._gn(x, r.n1_g, r.n1_b, rows, rpb, self.cfg.norm_eps, True)
         tb = temb[:, r.temb_off:]  # view: row pitch stays temb_total (ldrb)
         # time-embedding row per clip, or per (clip, frame) when frame 0 carries the timestep-0 embedding (use_first_frame_condition)
-        h = self.conv(h, r.c1_w, r.c1_b, frames, g["H"], g["W"], rowbias=tb, rpb=g["H"] * g["W"] if g.get("temb_per_frame") else rpb,
-                      ldrb=temb.shape[1])
-        h = self.group_norm(h, r.n2_g, r.n2_b, rows, r.cout, rpb, self.cfg.norm_eps, True)
-        sc = self.lin(x, r.sc_w, rows, bias=r.sc_b) if r.sc_w is not None else x
-        return self.conv(h, r.c2_w, r.c2_b, frames, g["H"], g["W"], residual=sc)
+        h1 = self._conv_act(h, r.c1_w, r.c1_b, frames, g["H"], g["W"], g["H"] * g["W"], rowbias=tb,
+                            rpb=g["H"] * g["W"] if g.get("temb_per_frame") else rpb, ldrb=temb.shape[1])
+        h2, _ = self._gn(h1, r.n2_g, r.n2_b, rows, rpb, self.cfg.norm_eps, True)
+        if r.sc_w is None:
+            sc = x.t
+        elif isinstance(x, Act) or cat is not None:
+            sc = self.lin(cat if cat is not None else x.t, r.sc_w, rows, bias=r.sc_b)
+        else:                       # conv_shortcut over cat([hidden, skip]) without materialising the concat
+            a, b = x
+            sc = self.new(rows, r.cout)
+            self.ops.gemm(a.t, r.sc_w, sc, M=rows, N=r.cout, K=a.C + b.C, lda=a.C, ldw=a.C + b.C, ldo=r.cout, bias=r.sc_b,
+                          a2=b.t, k_split=a.C, lda2=b.C)
+        return self._conv_act(h2, r.c2_w, r.c2_b, frames, g["H"], g["W"], nxt, residual=sc)
 
-    def feed_forward_out(self, ff: Packed, ln, tok: Tensor, residual: Tensor, rows: int, C: int) -> Tensor:
+    def feed_forward_out(self, ff: Packed, ln, tok: Act, residual: Optional[Tensor], rows: int, C: int, nxt: int = 0) -> Act:
         """LN -> GEGLU FF -> (+tok) -> output projection (+residual) with FF2 and the projection merged into one GEMM
         over [tok | h] (see weights._ff): returns residual + Wp (tok + W2 h + b2) + bp."""
-        if ff.cs1 is not None:      # LayerNorm folded into FF1: one statistics pass instead of a normalise-and-write pass
+        if ff.cs1 is not None:      # LayerNorm folded into FF1: statistics from the producer of tok (or one statistics pass)
             N1 = ff.w1.shape[0]
             hmid = self.new(rows, N1 // 2)
-            self.ops.gemm(tok, ff.w1, hmid, M=rows, N=N1, K=C, lda=C, ldw=C, ldo=N1 // 2, bias=ff.b1, epilogue=L.EPI_GEGLU,
-                          ln_stats=self.row_stats(tok, rows, C), ln_colsum=ff.cs1)
+            self.ops.gemm(tok.t, ff.w1, hmid, M=rows, N=N1, K=C, lda=C, ldw=C, ldo=N1 // 2, bias=ff.b1, epilogue=L.EPI_GEGLU,
+                          ln_colsum=ff.cs1, **self._ln_args(tok, rows, C))
         else:
-            n = self.layer_norm(tok, ln, rows, C)
+            n = self.layer_norm(tok.t, ln, rows, C)
             hmid = self.lin(n, ff.w1, rows, bias=ff.b1, geglu=True)
         out = self.new(rows, C)
         K = ff.po_w.shape[1]
-        self.ops.gemm(tok, ff.po_w, out, M=rows, N=C, K=K, lda=C, ldw=K, ldo=C, bias=ff.po_b, residual=residual, ldr=C,
-                      a2=hmid, k_split=C, lda2=K - C)
-        return out
+        cs = self._cs_new(rows, nxt, C) if nxt else None
+        rp, rp_n = None, 0
+        if residual is None and self.fuse_stats:     # inner motion blocks: the output is the next block's token stream (LayerNorm input)
+            rp_n = self.ops.gemm_row_parts(tok.t.dtype, M=rows, N=C, K=K)
+            rp = torch.empty(rows, rp_n, 2, dtype=torch.float32, device=self.device)
+        self.ops.gemm(tok.t, ff.po_w, out, M=rows, N=C, K=K, lda=C, ldw=K, ldo=C, bias=ff.po_b, residual=residual, ldr=C,
+                      a2=hmid, k_split=C, lda2=K - C, chan_stats=cs, cs_rows=nxt if cs is not None else 0, row_parts=rp, row_nparts=rp_n)
+        return Act(out, C, cs, nxt, rp, rp_n)
 
-    def transformer(self, t: Packed, x: Tensor, g: dict) -> Tensor:
+    def transformer(self, t: Packed, x: Act, g: dict, nxt: int) -> Act:
         """Transformer3DModel + BasicTransformerBlock (reference attention.py:217-308, 489-564)."""
         rows, C, H, o = g["rows"], t.C, self.heads, self.ops
         BF, N = g["B"] * g["F"], g["H"] * g["W"]
         d = C // H
-        h = self.group_norm(x, t.norm_g, t.norm_b, rows, C, N, 1e-6, False)
-        tok = self.lin(h, t.pin_w, rows, bias=t.pin_b)
+        h, _ = self._gn(x, t.norm_g, t.norm_b, rows, N, 1e-6, False)
+        tok = self._lin_rp(h, t.pin_w, rows, bias=t.pin_b)
         # --- attn1: spatial self-attention
         ld = ((N + 7) // 8) * 8
         q, k, vt = self.new(BF, H, N, d), self.new(BF, H, N, d), (self.zeros(BF, H, d, ld) if ld != N else self.new(BF, H, d, ld))
         hd = dict(seg_cols=C, heads=H, tokens=N, outs=[q, k, vt], transposed=[0, 0, 1], ld=[0, 0, ld])
         if t.qkv_f is not None:     # LayerNorm (norm1) folded into the fused QKV projection
             w, b, cs = t.qkv_f
-            o.gemm(tok, w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, bias=b, epilogue=L.EPI_HEADS, heads=hd,
-                   ln_stats=self.row_stats(tok, rows, C), ln_colsum=cs)
+            o.gemm(tok.t, w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, bias=b, epilogue=L.EPI_HEADS, heads=hd, ln_colsum=cs,
+                   **self._ln_args(tok, rows, C))
         else:
-            n1 = self.layer_norm(tok, t.ln1, rows, C)
+            n1 = self.layer_norm(tok.t, t.ln1, rows, C)
             o.gemm(n1, t.qkv_w, None, M=rows, N=3 * C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS, heads=hd)
         att = self.new(rows, C)
         self._attend(q, k, vt, att, batch=BF, n_q=N, n_k=N, d=d, ldvt=ld, C=C, kv_div=1)
-        tok = self.lin(att, t.o1_w, rows, bias=t.o1_b, residual=tok)
+        tok = self._lin_rp(att, t.o1_w, rows, bias=t.o1_b, residual=tok.t)
         # --- attn2: cross-attention on the cached text (and IP) K/V
         q2 = self.new(BF, H, N, d)
         hd2 = dict(seg_cols=C, heads=H, tokens=N, outs=[q2], transposed=[0], ld=[0])
         if t.q2_f is not None:
             w, b, cs = t.q2_f
-            o.gemm(tok, w, None, M=rows, N=C, K=C, lda=C, ldw=C, bias=b, epilogue=L.EPI_HEADS, heads=hd2,
-                   ln_stats=self.row_stats(tok, rows, C), ln_colsum=cs)
+            o.gemm(tok.t, w, None, M=rows, N=C, K=C, lda=C, ldw=C, bias=b, epilogue=L.EPI_HEADS, heads=hd2, ln_colsum=cs,
+                   **self._ln_args(tok, rows, C))
         else:
-            n2 = self.layer_norm(tok, t.ln2, rows, C)
+            n2 = self.layer_norm(tok.t, t.ln2, rows, C)
             o.gemm(n2, t.q2_w, None, M=rows, N=C, K=C, lda=C, ldw=C, epilogue=L.EPI_HEADS, heads=hd2)
         cache = self.ctx_cache[t.idx]
         kt, vtt, ldt = cache["text"]
@@ -243,32 +350,32 @@ class UNet3DEngine(EngineBase):
             ki, vti, ldi = cache["ip"]
             self._attend(q2, ki, vti, att2, batch=BF, n_q=N, n_k=cache["n_ip"], d=d, ldvt=ldi, C=C, kv_div=g["F"],
                          accumulate=True, o_scale=self.cfg.ip_scale)
-        tok = self.lin(att2, t.o2_w, rows, bias=t.o2_b, residual=tok)
-        return self.feed_forward_out(t.ff, t.ln3, tok, x, rows, C)
+        tok = self._lin_rp(att2, t.o2_w, rows, bias=t.o2_b, residual=tok.t)
+        return self.feed_forward_out(t.ff, t.ln3, tok, x.t, rows, C, nxt)
 
-    def motion(self, m: Packed, x: Tensor, g: dict) -> Tensor:
+    def motion(self, m: Packed, x: Act, g: dict, nxt: int) -> Act:
         """VanillaTemporalModule (reference motion_module.py:157-208, 270-283, 371-464)."""
         rows, C, o = g["rows"], m.C, self.ops
         N, Hm = g["H"] * g["W"], self.cfg.motion_num_attention_heads
         d = C // Hm
-        h = self.group_norm(x, m.norm_g, m.norm_b, rows, C, N, 1e-6, False)
-        tok = self.lin(h, m.pin_w, rows, bias=m.pin_b)
+        h, _ = self._gn(x, m.norm_g, m.norm_b, rows, N, 1e-6, False)
+        tok = self._lin_rp(h, m.pin_w, rows, bias=m.pin_b)
         for bi, blk in enumerate(m.blocks):
             for a in blk.attns:
                 if a.qkv_f is not None:     # LayerNorm folded into the QKV projection, positional table as a per-frame row bias
                     w, b, cs = a.qkv_f
                     qkv = self.new(rows, 3 * C)
                     rb = self._pe_rowbias(a, g["B"], g["F"]) if a.pe_w is not None else None
-                    o.gemm(tok, w, qkv, M=rows, N=3 * C, K=C, lda=C, ldw=C, ldo=3 * C, bias=b, rowbias=rb, rows_per_batch=N,
-                           ln_stats=self.row_stats(tok, rows, C), ln_colsum=cs)
+                    o.gemm(tok.t, w, qkv, M=rows, N=3 * C, K=C, lda=C, ldw=C, ldo=3 * C, bias=b, rowbias=rb, rows_per_batch=N,
+                           ln_colsum=cs, **self._ln_args(tok, rows, C))
                 else:
-                    n = self.layer_norm(tok, a.ln, rows, C, pe=a.pe, pe_div=N, pe_rows=g["F"])
+                    n = self.layer_norm(tok.t, a.ln, rows, C, pe=a.pe, pe_div=N, pe_rows=g["F"])
                     qkv = self.lin(n, a.qkv_w, rows)
                 att = self.new(rows, C)
                 o.temporal_attention(qkv, att, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5)
-                tok = self.lin(att, a.o_w, rows, bias=a.o_b, residual=tok)
+                tok = self._lin_rp(att, a.o_w, rows, bias=a.o_b, residual=tok.t)
             last = bi == len(m.blocks) - 1
-            tok = self.feed_forward_out(blk.ff, blk.ff_ln, tok, x if last else None, rows, C)   # inner blocks: identity projection
+            tok = self.feed_forward_out(blk.ff, blk.ff_ln, tok, x.t if last else None, rows, C, nxt if last else 0)   # inner blocks: identity projection
         return tok
 
     # ---- forward -------------------------------------------------------------------------------
@@ -278,56 +385,59 @@ class UNet3DEngine(EngineBase):
         temb_first ([1, temb_total], optional): time-embedding row of timestep 0 that every ResNet adds to FRAME 0 instead of
         the clip's own row (reference `use_first_frame_condition`, unet.py:523-524, resnet.py:310-317)."""
         assert self.ctx_cache is not None, "call prepare_context() first"
-        cfg, P, o = self.cfg, self.P, self.ops
+        cfg, P = self.cfg, self.P
         g = dict(B=B, F=F, H=H, W=W, rows=B * F * H * W)
         if temb_first is not None:
             temb = temb.repeat_interleave(F, dim=0)            # one row per (clip, frame)
             temb[0::F] = temb_first
             g["temb_per_frame"] = True
-        frames = B * F
-        x = self.conv(x, P.conv_in_w, P.conv_in_b, frames, H, W)
         if cfg.use_first_frame_condition_concat:
             raise NotImplementedError("use_first_frame_condition_concat (sample/2 path, reference unet.py:589-590)")
-        skips = [(x, P.conv_in_w.shape[0])]
+        self._begin_forward()
+        frames = B * F
+
+        def hw(gg):         # rows of one frame = one statistics sample of every producer
+            return gg["H"] * gg["W"]
+
+        def layer(l, xin, gg):
+            """resnet [-> transformer] [-> motion module]"""
+            y = self.resnet(l.resnet, xin, temb, gg, hw(gg))
+            if l.attn is not None:
+                y = self.transformer(l.attn, y, gg, hw(gg))
+            if l.motion is not None:
+                y = self.motion(l.motion, y, gg, hw(gg))
+            return y
+
+        x = self._conv_act(x, P.conv_in_w, P.conv_in_b, frames, H, W, hw(g))
+        skips = [x]
         sizes = [(H, W)]                       # spatial size per resolution level (odd sizes: ceil-halving on the way down)
         for blk in P.down:
             for l in blk.layers:
-                x = self.resnet(l.resnet, x, temb, g)
-                if l.attn is not None:
-                    x = self.transformer(l.attn, x, g)
-                if l.motion is not None:
-                    x = self.motion(l.motion, x, g)
-                skips.append((x, l.resnet.cout))
+                x = layer(l, x, g)
+                skips.append(x)
             if blk.down is not None:
-                x = self.conv(x, blk.down.w, blk.down.b, frames, g["H"], g["W"], stride=2)
-                g = dict(g, H=(g["H"] - 1) // 2 + 1, W=(g["W"] - 1) // 2 + 1)
-                g["rows"] = B * F * g["H"] * g["W"]
+                g2 = dict(g, H=(g["H"] - 1) // 2 + 1, W=(g["W"] - 1) // 2 + 1)
+                g2["rows"] = B * F * g2["H"] * g2["W"]
+                x = self._conv_act(x.t, blk.down.w, blk.down.b, frames, g["H"], g["W"], hw(g2), stride=2)
+                g = g2
                 sizes.append((g["H"], g["W"]))
-                skips.append((x, blk.down.w.shape[0]))
-        x = self.resnet(P.mid.r0, x, temb, g)
-        x = self.transformer(P.mid.attn, x, g)
+                skips.append(x)
+        x = self.resnet(P.mid.r0, x, temb, g, hw(g))
+        x = self.transformer(P.mid.attn, x, g, hw(g))
         if P.mid.motion is not None:
-            x = self.motion(P.mid.motion, x, g)
-        x = self.resnet(P.mid.r1, x, temb, g)
-        c_cur = P.mid.r1.cout
+            x = self.motion(P.mid.motion, x, g, hw(g))
+        x = self.resnet(P.mid.r1, x, temb, g, hw(g))
         for blk in P.up:
             for l in blk.layers:
-                skip, c_skip = skips.pop()
-                cat = self.new(g["rows"], c_cur + c_skip)
-                o.concat_channels(x, skip, cat, rows=g["rows"], c1=c_cur, c2=c_skip)  # cat([hidden, skip], dim=1)
-                x = self.resnet(l.resnet, cat, temb, g)
-                c_cur = l.resnet.cout
-                if l.attn is not None:
-                    x = self.transformer(l.attn, x, g)
-                if l.motion is not None:
-                    x = self.motion(l.motion, x, g)
+                x = layer(l, (x, skips.pop()), g)      # cat([hidden, skip], dim=1) folded into norm1 / the shortcut
             if blk.up is not None:
                 # Upsample3D: nearest to the size of the next skip connection (exactly 2x unless a level was odd:
                 # the reference forwards `upsample_size`, unet.py:466-474, 644-645)
                 sizes.pop()
                 Hn, Wn = sizes[-1]
-                x = self.conv(x, blk.up.w, blk.up.b, frames, g["H"], g["W"], up2=True, up_size=(Hn, Wn))
-                g = dict(g, H=Hn, W=Wn)
-                g["rows"] = B * F * Hn * Wn
-        h = self.group_norm(x, P.out_g, P.out_b, g["rows"], c_cur, F * g["H"] * g["W"], cfg.norm_eps, True)
+                g2 = dict(g, H=Hn, W=Wn)
+                g2["rows"] = B * F * Hn * Wn
+                x = self._conv_act(x.t, blk.up.w, blk.up.b, frames, g["H"], g["W"], hw(g2), up2=True, up_size=(Hn, Wn))
+                g = g2
+        h, _ = self._gn(x, P.out_g, P.out_b, g["rows"], F * hw(g), cfg.norm_eps, True)
         return self.conv(h, P.conv_out_w, P.conv_out_b, frames, g["H"], g["W"])

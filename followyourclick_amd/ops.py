@@ -87,8 +87,27 @@ class HipOps:
              mode: int = L.GEMM_PLAIN, conv: Optional[dict] = None, batch: int = 1, stride_a: int = 0,
              stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None, tile: int = 0,
              a2: Optional[Tensor] = None, k_split: int = 0, lda2: int = 0, act: int = L.ACT_NONE,
-             ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None) -> None:
+             ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None, ln_nparts: int = 0, ln_eps: float = 1e-5,
+             chan_stats: Optional[Tensor] = None, cs_rows: int = 0, row_parts: Optional[Tensor] = None, row_nparts: int = 0) -> None:
         self.ensure_init(a.device)
+        g = self._gemm_args(a, w, out, M=M, N=N, K=K, lda=lda, ldw=ldw, ldo=ldo, bias=bias, rowbias=rowbias, rows_per_batch=rows_per_batch,
+                            residual=residual, ldr=ldr, ldrb=ldrb, out_scale=out_scale, epilogue=epilogue, mode=mode, conv=conv, batch=batch,
+                            stride_a=stride_a, stride_w=stride_w, stride_o=stride_o, heads=heads, tile=tile, a2=a2, k_split=k_split,
+                            lda2=lda2, act=act, ln_stats=ln_stats, ln_colsum=ln_colsum, ln_nparts=ln_nparts, ln_eps=ln_eps,
+                            chan_stats=chan_stats, cs_rows=cs_rows, row_parts=row_parts, row_nparts=row_nparts)
+        self._call("fyc_gemm", g)
+
+    def gemm_row_parts(self, dtype: torch.dtype, *, M: int, N: int, K: int, mode: int = L.GEMM_PLAIN, batch: int = 1, tile: int = 0) -> int:
+        """column tiles fyc_gemm will use for this problem = row_nparts of its `row_parts` output (fyc_gemm_row_parts)"""
+        g = L.GemmArgs()
+        g.M, g.N, g.K, g.mode, g.batch, g.tile = M, N, K, mode, batch, tile
+        g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+        return int(self.lib.fyc_gemm_row_parts(C.byref(g)))
+
+    @staticmethod
+    def _gemm_args(a, w, out, *, M, N, K, lda, ldw, ldo, bias, rowbias, rows_per_batch, residual, ldr, ldrb, out_scale, epilogue, mode,
+                   conv, batch, stride_a, stride_w, stride_o, heads, tile, a2, k_split, lda2, act, ln_stats, ln_colsum, ln_nparts,
+                   ln_eps, chan_stats, cs_rows, row_parts, row_nparts):
         g = L.GemmArgs()
         g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
         g.residual, g.out = _p(residual), _p(out)
@@ -108,7 +127,12 @@ class HipOps:
             g.seg_cols, g.heads, g.tokens = heads["seg_cols"], heads["heads"], heads["tokens"]
             for i, (t, tr, ld) in enumerate(zip(heads["outs"], heads["transposed"], heads["ld"])):
                 g.seg_out[i], g.seg_transposed[i], g.seg_ld[i] = _p(t), int(tr), int(ld)
-        self._call("fyc_gemm", g)
+        g.ln_nparts, g.ln_eps = ln_nparts, ln_eps
+        if chan_stats is not None and chan_stats.dtype != torch.float64:
+            raise TypeError("chan_stats must be float64")
+        g.chan_stats, g.cs_rows = _p(chan_stats), cs_rows
+        g.row_parts, g.row_nparts = _f32(row_parts, "row_parts"), row_nparts
+        return g
 
     # -- attention ---------------------------------------------------------------------------
     def attention(self, q: Tensor, k: Tensor, vt: Tensor, o: Tensor, *, batch: int, heads: int, n_q: int, n_k: int,
@@ -143,6 +167,19 @@ class HipOps:
         a.x, a.stats, a.gamma, a.beta, a.y = _p(x), _p(stats), _f32(gamma, "gamma"), _f32(beta, "beta"), _p(y)
         a.rows, a.C, a.groups, a.rows_per_sample, a.eps, a.silu, a.dtype = rows, C_, groups, rows_per_sample, eps, int(silu), _dt(x)
         self._call("fyc_gn_apply", a)
+
+    def gn_apply_cs(self, x1: Tensor, cs1: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, *, rows: int, C1: int, groups: int,
+                    rows_per_sample: int, eps: float, silu: bool, x2: Optional[Tensor] = None, cs2: Optional[Tensor] = None,
+                    C2: int = 0, cs_rows: int = 0) -> None:
+        a = L.GnApplyCsArgs()
+        for t in (cs1, cs2):
+            if t is not None and t.dtype != torch.float64:
+                raise TypeError("channel statistics must be float64")
+        a.x1, a.cs1, a.x2, a.cs2 = _p(x1), _p(cs1), _p(x2), _p(cs2)
+        a.gamma, a.beta, a.y = _f32(gamma, "gamma"), _f32(beta, "beta"), _p(y)
+        a.C1, a.C2, a.rows, a.groups, a.rows_per_sample, a.eps, a.silu, a.dtype = C1, C2, rows, groups, rows_per_sample, eps, int(silu), _dt(x1)
+        a.cs_rows = cs_rows
+        self._call("fyc_gn_apply_cs", a)
 
     def layernorm(self, x: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, *, rows: int, C_: int, eps: float = 1e-5,
                   pe: Optional[Tensor] = None, pe_div: int = 1, pe_rows: int = 1) -> None:

@@ -83,6 +83,12 @@ class TimedOps:
     def gn_apply(self, x, stats, g, b, y, **kw):
         return self._timed("gn_apply", 0.0, 2.0 * kw["rows"] * kw["C_"] * _esize(x), self.inner.gn_apply, x, stats, g, b, y, **kw)
 
+    def gn_apply_cs(self, x1, cs1, g, b, y, **kw):
+        return self._timed("gn_apply", 0.0, 2.0 * kw["rows"] * (kw["C1"] + kw.get("C2", 0)) * _esize(x1), self.inner.gn_apply_cs, x1, cs1, g, b, y, **kw)
+
+    def gemm_row_parts(self, dtype, **kw):      # host-side query, no kernel
+        return self.inner.gemm_row_parts(dtype, **kw)
+
     def layernorm(self, x, g, b, y, **kw):
         return self._timed("layernorm", 0.0, 2.0 * kw["rows"] * kw["C_"] * _esize(x), self.inner.layernorm, x, g, b, y, **kw)
 

@@ -91,8 +91,23 @@ typedef struct {
    * ln_stats[m] = {mean, rstd} of row m (fyc_row_stats).  acc := rstd[m] * (acc - mean[m] * ln_colsum[n]) before bias.  NULL = off. */
   const float* ln_stats;
   const float* ln_colsum;
+  /* ln_nparts > 0: ln_stats is not {mean, rstd} but the `row_parts` buffer of the GEMM that produced `a`: [M][ln_nparts][2] partial
+   * {sum, sum of squares} per row; mean / rstd are derived in the epilogue over the K columns with ln_eps.  0 = {mean, rstd}. */
+  int32_t ln_nparts; float ln_eps;
+  /* Statistics of the OUTPUT, accumulated by the epilogue that writes it (LINEAR epilogue, batch <= 1), so that the GroupNorm /
+   * LayerNorm consuming `out` needs no read pass of its own (reference resnet.py:299,322, attention.py:269,383,412,418,
+   * motion_module.py:181,261,267).  The sums are of the values AS STORED (rounded to `dtype`).
+   *  chan_stats [M / cs_rows][N][2] doubles: per (sample, channel) {sum, sum of squares}, ADDED to the buffer with atomics (the
+   *    caller zeroes it).  cs_rows = rows per GroupNorm sample (H*W per-frame, F*H*W cross-frame): a multiple of 16, 64 or >= 128.
+   *    Consumed by fyc_gn_apply_cs.
+   *  row_parts [M][row_nparts][2] floats: per row and column tile {sum, sum of squares} (plain stores, nothing to zero);
+   *    row_nparts must equal fyc_gemm_row_parts(args).  Consumed through ln_stats / ln_nparts of the next GEMM. */
+  double* chan_stats; int32_t cs_rows;
+  float* row_parts; int32_t row_nparts;
 } fyc_gemm_args;
 int fyc_gemm(const fyc_gemm_args* a, void* stream);
+/* number of column tiles fyc_gemm will use for these arguments (M, N, K, mode, dtype, batch, tile are read) = row_nparts */
+int fyc_gemm_row_parts(const fyc_gemm_args* a);
 
 /* ---- fused flash attention (bf16 MFMA, online softmax) ----------------------------------
  * o[b][tok][h*d + i] = softmax_k( q[b,h,tok,:] . k[b,h,key,:] * scale ) @ v
@@ -151,6 +166,22 @@ typedef struct {
   int32_t dtype;
 } fyc_gn_apply_args;
 int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream);
+
+/* GroupNorm apply (+SiLU) from per-(sample, channel) sums written by the producers' epilogues (fyc_gemm chan_stats), with the
+ * channel concat of the up blocks folded in (torch.cat([hidden, skip], dim=1) -> norm1, reference unet_blocks.py:763,885;
+ * resnet.py:299-302): y[r][0:C1] from x1, y[r][C1:C1+C2] from x2 (x2 = NULL, C2 = 0: one source).  Groups are taken over the
+ * concatenated channel index and may straddle the two sources.  cs1 / cs2: [rows / cs_rows][C][2] doubles. */
+typedef struct {
+  const void* x1; const double* cs1; const void* x2; const double* cs2;
+  const float* gamma; const float* beta; void* y;
+  int32_t C1, C2, rows, groups, rows_per_sample;
+  float eps; int32_t silu;
+  int32_t dtype;
+  int32_t cs_rows;       /* rows per statistics sample of cs1 / cs2 (0 = rows_per_sample): the producers accumulate per frame (H*W
+                          * rows) so that their atomics spread over F times more addresses; a cross-frame norm (rows_per_sample =
+                          * F*H*W) adds up the F frame sums here */
+} fyc_gn_apply_cs_args;
+int fyc_gn_apply_cs(const fyc_gn_apply_cs_args* a, void* stream);
 
 /* LayerNorm over C (eps 1e-5, affine) + optional additive table pe[(row / pe_div) % pe_rows][c]
  * (motion module: PositionalEncoding added to the normalised tokens, motion_module.py:272-278,377) */

@@ -39,8 +39,15 @@ class EmuOps:
     # ------------------------------------------------------------------------------------
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
              ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
-             heads=None, tile=0, a2=None, k_split=0, lda2=0, act=0, ln_stats=None, ln_colsum=None):
+             heads=None, tile=0, a2=None, k_split=0, lda2=0, act=0, ln_stats=None, ln_colsum=None, ln_nparts=0, ln_eps=1e-5,
+             chan_stats=None, cs_rows=0, row_parts=None, row_nparts=0):
         acc_t = self.acc
+        if chan_stats is not None or row_parts is not None:
+            assert epilogue == LINEAR and batch == 1
+        if chan_stats is not None:
+            assert cs_rows % 16 == 0 and (cs_rows == 64 or cs_rows >= 128) and M % cs_rows == 0, (cs_rows, M)
+        if row_parts is not None:
+            assert row_nparts == self.gemm_row_parts(a.dtype, M=M, N=N, K=K, mode=mode)
         af, wf = _flat(a), _flat(w)
         for z in range(batch):
             W = _strided(wf, (N, K), (ldw, 1), z * stride_w).to(acc_t)
@@ -69,7 +76,13 @@ class EmuOps:
                 assert y.shape[2] == Hout and y.shape[3] == Wout, (y.shape, Hout, Wout)
                 acc = y.permute(0, 2, 3, 1).reshape(M, N)
             if ln_stats is not None:      # folded LayerNorm: rstd * (x W'^T - mean * colsum)
-                st = ln_stats.reshape(-1, 2)[:M].to(acc_t)
+                if ln_nparts > 0:         # partial {sum, sum sq} per row from the producer's epilogue
+                    pr = _flat(ln_stats)[: M * ln_nparts * 2].reshape(M, ln_nparts, 2).float().sum(dim=1)
+                    mean = pr[:, 0] / K
+                    rstd = torch.rsqrt((pr[:, 1] / K - mean * mean).clamp_min(0) + ln_eps)
+                    st = torch.stack([mean, rstd], dim=1).to(acc_t)
+                else:
+                    st = ln_stats.reshape(-1, 2)[:M].to(acc_t)
                 acc = st[:, 1:2] * (acc - st[:, 0:1] * ln_colsum.to(acc_t)[None, :N])
             if bias is not None:
                 acc = acc + bias.to(acc_t)[None, :N]
@@ -92,6 +105,20 @@ class EmuOps:
                 acc = acc * out_scale
                 o = _strided(_flat(out), (M, N), (ldo, 1), z * stride_o)
                 o.copy_(acc.to(out.dtype))
+                if chan_stats is not None or row_parts is not None:      # statistics of the values as stored
+                    v = o.double()
+                    if chan_stats is not None:
+                        cs = _flat(chan_stats)[: (M // cs_rows) * N * 2].reshape(M // cs_rows, N, 2)
+                        vs = v.reshape(M // cs_rows, cs_rows, N)
+                        cs[:, :, 0] += vs.sum(dim=1)
+                        cs[:, :, 1] += (vs * vs).sum(dim=1)
+                    if row_parts is not None:
+                        rp = _flat(row_parts)[: M * row_nparts * 2].reshape(M, row_nparts, 2)
+                        edges = [round(i * N / row_nparts) for i in range(row_nparts + 1)]
+                        for i in range(row_nparts):
+                            blk = v[:, edges[i]:edges[i + 1]]
+                            rp[:, i, 0] = blk.sum(dim=1).float()
+                            rp[:, i, 1] = (blk * blk).sum(dim=1).float()
             else:
                 acc = acc * out_scale
                 sc, H, T = heads["seg_cols"], heads["heads"], heads["tokens"]
@@ -104,6 +131,10 @@ class EmuOps:
                         ld = ld if ld > 0 else T
                         v = _strided(_flat(t), (Bn, H, d, T), (H * d * ld, d * ld, ld, 1), 0)
                         v.copy_(seg.permute(0, 2, 3, 1).to(t.dtype))
+
+    def gemm_row_parts(self, dtype, *, M, N, K, mode=PLAIN, batch=1, tile=0):
+        """any partition of the columns is valid for the consumer; use several parts so that their summation is exercised"""
+        return 3 if N % 3 == 0 else (2 if N % 2 == 0 else 1)
 
     # ------------------------------------------------------------------------------------
     def attention(self, q, k, vt, o, *, batch, heads, n_q, n_k, d, ldo, ldvt, scale, kv_batch_div=1, accumulate=False,
@@ -157,6 +188,27 @@ class EmuOps:
         if silu:
             yv = F.silu(yv)
         _flat(y)[: rows * C_].reshape(S, rows_per_sample, C_).copy_(yv.to(y.dtype))
+
+    def gn_apply_cs(self, x1, cs1, gamma, beta, y, *, rows, C1, groups, rows_per_sample, eps, silu, x2=None, cs2=None, C2=0,
+                    cs_rows=0):
+        S, Cc = rows // rows_per_sample, C1 + C2
+        cpg = Cc // groups
+        nf = rows_per_sample // (cs_rows or rows_per_sample)      # statistics samples (frames) per GroupNorm sample
+        assert rows_per_sample % (cs_rows or rows_per_sample) == 0
+        xs = _flat(x1)[: rows * C1].reshape(rows, C1).float()
+        cs = _flat(cs1)[: S * nf * C1 * 2].reshape(S, nf, C1, 2).sum(dim=1)
+        if x2 is not None:
+            xs = torch.cat([xs, _flat(x2)[: rows * C2].reshape(rows, C2).float()], dim=1)
+            cs = torch.cat([cs, _flat(cs2)[: S * nf * C2 * 2].reshape(S, nf, C2, 2).sum(dim=1)], dim=1)
+        st = cs.reshape(S, groups, cpg, 2).sum(dim=2)
+        cnt = rows_per_sample * cpg
+        mean = st[..., 0] / cnt
+        rstd = 1.0 / torch.sqrt((st[..., 1] / cnt - mean * mean).clamp_min(0) + eps)
+        yv = (xs.reshape(S, rows_per_sample, groups, cpg) - mean.float()[:, None, :, None]) * rstd.float()[:, None, :, None]
+        yv = yv.reshape(S, rows_per_sample, Cc) * gamma.float() + beta.float()
+        if silu:
+            yv = F.silu(yv)
+        _flat(y)[: rows * Cc].reshape(S, rows_per_sample, Cc).copy_(yv.to(y.dtype))
 
     def layernorm(self, x, gamma, beta, y, *, rows, C_, eps=1e-5, pe=None, pe_div=1, pe_rows=1):
         xs = _flat(x)[: rows * C_].reshape(rows, C_).float()

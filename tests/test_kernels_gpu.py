@@ -45,8 +45,16 @@ def close(hip_t, emu_t, tag, rtol):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 2), (1, 4), (2, 3), (2, 4), (3, 2), (3, 3), (4, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)])
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+PLAIN_TILES = [(0, 0), (1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)]
+CONV_TILES = [(0, 0), (1, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)]
+
+
+def _dt_tiles(tiles):
+    """f32 parity mode has a fixed tile choice: only the automatic one is parametrised for it"""
+    return [("bf16", t) for t in tiles] + [("f32", (0, 0))]
+
+
+@pytest.mark.parametrize("dt,tile_ring", _dt_tiles(PLAIN_TILES))
 @pytest.mark.parametrize("M,N,K", [(256, 128, 128), (300, 320, 320), (154, 64, 768), (8, 256, 64), (1000, 960, 40), (513, 4, 576)])
 def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
     T = DT[dt]
@@ -55,8 +63,6 @@ def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
     rpb = 50
     rowb = rnd(((M + rpb - 1) // rpb, N), torch.float32, 5)
     kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, rows_per_batch=rpb, out_scale=0.75)
-    if dt == "f32" and tile_ring != (0, 0):
-        pytest.skip("f32 parity mode has a fixed tile choice")
     hip.set_tuning(1, tile_ring[0])
     hip.set_tuning(2, tile_ring[1])
     try:
@@ -71,8 +77,7 @@ def test_gemm_plain(hip, emu, dt, tile_ring, M, N, K):
     close(o_h, o_e, f"gemm {dt} {M}x{N}x{K} tile/ring={tile_ring}", RTOL[dt])
 
 
-@pytest.mark.parametrize("tile_ring", [(0, 0), (1, 3), (3, 3), (4, 4), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)])
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt,tile_ring", _dt_tiles(CONV_TILES))
 @pytest.mark.parametrize("mode,stride,frames,H,W,Cin,Cout", [
     (1, 1, 3, 8, 8, 64, 64), (1, 1, 2, 16, 12, 128, 320), (1, 2, 2, 16, 16, 64, 128), (2, 1, 2, 6, 5, 64, 64),
     (1, 1, 5, 1, 1, 64, 64), (1, 1, 1, 32, 32, 192, 4), (1, 2, 3, 2, 2, 64, 64), (3, 1, 2, 3, 5, 64, 64), (3, 1, 1, 2, 2, 64, 128)])
@@ -89,8 +94,6 @@ def test_gemm_conv(hip, emu, dt, tile_ring, mode, stride, frames, H, W, Cin, Cou
     res = rnd((M, Cout), T, 6)
     conv = dict(Hout=Ho, Wout=Wo, Hin=H, Win=W, Cin=Cin, stride=stride)
     kw = dict(M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, ldr=Cout, mode=mode, conv=conv, rows_per_batch=Ho * Wo)
-    if dt == "f32" and tile_ring != (0, 0):
-        pytest.skip("f32 parity mode has a fixed tile choice")
     o_h = torch.full((M, Cout), float("nan"), dtype=T, device="cuda")
     hip.set_tuning(1, tile_ring[0])
     hip.set_tuning(2, tile_ring[1])
@@ -210,6 +213,62 @@ def test_attention_peaked_softmax(hip, emu):
     o_e = torch.zeros(B * n, H * d, dtype=T)
     emu.attention(q, k, vt, o_e, **kw)
     close(o_h, o_e, "attn peaked", 6e-3)
+
+
+@pytest.mark.parametrize("d", list(range(8, 161, 8)))
+def test_attention_every_head_dim(hip, emu, d):
+    """every supported head dim (multiples of 8 up to 160): 32-wide + 16-wide k-steps, the in-MFMA max subtraction (d % 16 == 8)
+    and the plain one, the row of ones that carries the softmax denominator; 2.5 key tiles with a ragged tail"""
+    T = torch.bfloat16
+    B, H, nq, nk = 2, 3, 80, 150
+    ldvt = ((nk + 7) // 8) * 8
+    q, k = rnd((B * H, nq, d), T, 11), rnd((B * H, nk, d), T, 12)
+    vt = torch.zeros(B * H, d, ldvt, dtype=T)
+    vt[..., :nk] = rnd((B * H, d, nk), T, 13)
+    kw = dict(batch=B, heads=H, n_q=nq, n_k=nk, d=d, ldo=H * d, ldvt=ldvt, scale=d ** -0.5)
+    for qt in (2, 4):
+        hip.set_tuning(3, qt)
+        try:
+            o_h = torch.full((B * nq, H * d), float("nan"), dtype=T, device="cuda")
+            hip.attention(q.cuda(), k.cuda(), vt.cuda(), o_h, **kw)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_tuning(3, 0)
+        o_e = torch.zeros(B * nq, H * d, dtype=T)
+        emu.attention(q, k, vt, o_e, **kw)
+        close(o_h, o_e, f"attn d{d} qt{qt}", 6e-3)
+
+
+@pytest.mark.parametrize("d", [24, 40, 64, 80, 160])
+@pytest.mark.parametrize("offset", [-120.0, 0.0, 90.0])
+def test_attention_score_offsets_and_late_spikes(hip, emu, d, offset):
+    """the running max is only moved when a score exceeds it by 2^6 and the first key block always fixes it: scores far from 0
+    (a common offset of +-100 in the exponent), a key that beats everything in the LAST tile, one in the first tile, and rows whose
+    maximum creeps up a little in every tile (below the threshold) must all come out right"""
+    T = torch.bfloat16
+    B, H, n = 1, 4, 448
+    g = torch.Generator().manual_seed(5)
+    q, k = rnd((B * H, n, d), T, 1), rnd((B * H, n, d), T, 2)
+    # a shared direction u: q.u = 1 for every query, k.u = offset / scale -> every score moves by `offset` (natural-log units * scale)
+    u = torch.zeros(d)
+    u[0] = 1.0
+    qf, kf = q.float(), k.float()
+    qf[..., 0] = 1.0
+    kf[..., 0] = offset * math.sqrt(d) / math.log2(math.e)       # offset is in log2 units
+    kf[:, 440] = kf[:, 440] + qf[:, 17] * 5                       # late spike for query 17
+    kf[:, 2] = kf[:, 2] + qf[:, 90] * 7                           # early spike for query 90
+    ramp = torch.arange(n).float()[None, :, None] * 0.004        # slowly growing scores for all queries
+    kf[..., 1] = ramp[..., 0]
+    qf[..., 1] = 2.0
+    q, k = qf.to(T), kf.to(T)
+    vt = rnd((B * H, d, n), T, 3)
+    kw = dict(batch=B, heads=H, n_q=n, n_k=n, d=d, ldo=H * d, ldvt=n, scale=d ** -0.5)
+    o_h = torch.zeros(B * n, H * d, dtype=T, device="cuda")
+    hip.attention(q.cuda(), k.cuda(), vt.cuda(), o_h, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(B * n, H * d, dtype=T)
+    emu.attention(q, k, vt, o_e, **kw)
+    close(o_h, o_e, f"attn offsets d{d} off{offset}", 8e-3)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
@@ -489,3 +548,113 @@ def test_ddim_three_way_guidance(hip, emu, dt):
     close(l_h, l_e, f"three-way guidance {dt}", 1e-5)
     with pytest.raises(Exception, match="needs classifier-free"):
         hip.cfg_ddim_step(pred.cuda(), l_h, coef.cuda(), pred_single=single.cuda(), **dict(kw, cfg=False))
+
+
+# ---- statistics fused into the producing epilogue (fyc_gemm chan_stats / row_parts, fyc_gn_apply_cs) --------------------------
+STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7]
+
+
+@pytest.mark.parametrize("dt,tile", [("bf16", t) for t in STAT_TILES] + [("f32", 0)])
+@pytest.mark.parametrize("M,N,K,cs_rows,res", [(512, 320, 320, 64, True), (768, 640, 128, 128, True), (1152, 128, 64, 192, False),
+                                               (4096, 320, 64, 4096, True), (1280, 328, 72, 640, False)])
+def test_gemm_output_statistics(hip, emu, dt, tile, M, N, K, cs_rows, res):
+    """per-(sample, channel) and per-row {sum, sum of squares} written by the LINEAR epilogue == sums of the values it stored
+    (partial row / column tiles, up to 4 samples per tile, samples straddling tiles, accumulation into a non-zero buffer)"""
+    T = DT[dt]
+    a, w = rnd((M, K), T, 1), rnd((N, K), T, 2, 1 / math.sqrt(K))
+    bias, r = rnd((N,), torch.float32, 3), (rnd((M, N), T, 4) if res else None)
+    init = rnd((M // cs_rows, N, 2), torch.float64, 7)
+    hip.set_tuning(1, tile)
+    try:
+        nparts = hip.gemm_row_parts(T, M=M, N=N, K=K)
+        o_h = torch.full((M, N), float("nan"), dtype=T, device="cuda")
+        cs = init.clone().cuda()
+        rp = torch.full((M, nparts, 2), float("nan"), dtype=torch.float32, device="cuda")
+        hip.gemm(a.cuda(), w.cuda(), o_h, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, bias=bias.cuda(), residual=None if r is None else r.cuda(),
+                 out_scale=1.25, chan_stats=cs, cs_rows=cs_rows, row_parts=rp, row_nparts=nparts)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_tuning(1, 0)
+    o_e = torch.zeros(M, N, dtype=T)
+    emu.gemm(a, w, o_e, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, bias=bias, residual=r, out_scale=1.25)
+    close(o_h, o_e, f"gemm+stats {dt} tile {tile}", RTOL[dt])
+    v = o_h.cpu().double()
+    vs = v.reshape(M // cs_rows, cs_rows, N)
+    want = init + torch.stack([vs.sum(dim=1), (vs * vs).sum(dim=1)], dim=-1)
+    close(cs, want, f"chan_stats {dt} tile {tile}", 2e-6)
+    rows = rp.cpu().double().sum(dim=1)
+    close(rows, torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], dim=-1), f"row_parts {dt} tile {tile} ({nparts} parts)", 2e-6)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_conv_output_statistics(hip, emu, dt):
+    T = DT[dt]
+    frames, H, W, Cin, Cout = 4, 16, 16, 64, 320
+    M, K = frames * H * W, 9 * Cin
+    x, w, bias = rnd((M, Cin), T, 1), rnd((Cout, K), T, 2, 1 / math.sqrt(K)), rnd((Cout,), torch.float32, 3)
+    res = rnd((M, Cout), T, 4)
+    conv = dict(Hout=H, Wout=W, Hin=H, Win=W, Cin=Cin, stride=1)
+    for cs_rows in (H * W, 2 * H * W):
+        cs = torch.zeros(M // cs_rows, Cout, 2, dtype=torch.float64, device="cuda")
+        o_h = torch.empty(M, Cout, dtype=T, device="cuda")
+        hip.gemm(x.cuda(), w.cuda(), o_h, M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, ldr=Cout, bias=bias.cuda(), residual=res.cuda(),
+                 mode=1, conv=conv, chan_stats=cs, cs_rows=cs_rows)
+        torch.cuda.synchronize()
+        vs = o_h.cpu().double().reshape(M // cs_rows, cs_rows, Cout)
+        close(cs, torch.stack([vs.sum(dim=1), (vs * vs).sum(dim=1)], dim=-1), f"conv chan_stats {dt} rows/sample {cs_rows}", 2e-6)
+    with pytest.raises(Exception, match="cs_rows"):
+        hip.gemm(x.cuda(), w.cuda(), o_h, M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, mode=1, conv=conv, chan_stats=cs, cs_rows=48)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("M,C", [(384, 320), (200, 640), (512, 1280)])
+def test_layernorm_fold_from_producer_row_parts(hip, emu, dt, M, C):
+    """producer GEMM writes row partial sums -> consumer GEMM derives mean / rstd from them == LayerNorm + GEMM"""
+    T = DT[dt]
+    a, wp = rnd((M, C), T, 1), rnd((C, C), T, 2, 1 / math.sqrt(C))
+    bp = 0.5 + rnd((C,), torch.float32, 9)           # a non-zero mean: the variance comes from E[x^2] - mean^2
+    gamma, beta = 1 + 0.2 * rnd((C,), torch.float32, 3), 0.1 * rnd((C,), torch.float32, 4)
+    w = rnd((2 * C, C), torch.float32, 5, 1 / math.sqrt(C))
+    wf = (w * gamma[None, :]).to(T)
+    bias, cs = w @ beta, wf.float().sum(dim=1)
+    n = hip.gemm_row_parts(T, M=M, N=C, K=C)
+    tok = torch.empty(M, C, dtype=T, device="cuda")
+    rp = torch.empty(M, n, 2, dtype=torch.float32, device="cuda")
+    hip.gemm(a.cuda(), wp.cuda(), tok, M=M, N=C, K=C, lda=C, ldw=C, ldo=C, bias=bp.cuda(), row_parts=rp, row_nparts=n)
+    o_h = torch.empty(M, 2 * C, dtype=T, device="cuda")
+    hip.gemm(tok, wf.cuda(), o_h, M=M, N=2 * C, K=C, lda=C, ldw=C, ldo=2 * C, bias=bias.cuda(), ln_stats=rp, ln_nparts=n, ln_eps=1e-5,
+             ln_colsum=cs.cuda())
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(tok.cpu().double(), (C,), gamma.double(), beta.double()) @ w.double().t()
+    err = ((o_h.cpu().double() - ref).norm() / ref.norm()).item()
+    assert err < (1.2e-2 if dt == "bf16" else 2e-5), err
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("samples,rps,C1,C2,silu,nf", [(2, 256, 320, 0, True, 1), (3, 64, 64, 64, False, 1), (2, 640, 1280, 640, True, 5),
+                                                       (1, 4096, 320, 320, True, 16), (4, 128, 2560 - 1280, 1280, True, 2)])
+def test_groupnorm_apply_from_channel_sums(hip, emu, dt, samples, rps, C1, C2, silu, nf):
+    """fyc_gn_apply_cs: GroupNorm (+SiLU) from per-(sample, channel) sums, channel concat of two sources with groups that
+    straddle them (1280 + 640 channels: 60 channels per group)"""
+    T = DT[dt]
+    rows, Cc = samples * rps, C1 + C2
+    x1 = (rnd((rows, C1), torch.float32, 1) * 1.3 + 0.4).to(T)
+    x2 = (rnd((rows, C2), torch.float32, 2) * 0.7 - 0.2).to(T) if C2 else None
+    gamma, beta = 1 + 0.2 * rnd((Cc,), torch.float32, 3), 0.1 * rnd((Cc,), torch.float32, 4)
+
+    def sums(x):          # per statistics sample (frame): nf of them make up one GroupNorm sample
+        v = x.double().reshape(samples * nf, rps // nf, -1)
+        return torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], dim=-1).contiguous()
+    cs1, cs2 = sums(x1), (sums(x2) if C2 else None)
+    y_h = torch.full((rows, Cc), float("nan"), dtype=T, device="cuda")
+    kw = dict(rows=rows, C1=C1, groups=32, rows_per_sample=rps, eps=1e-5, silu=silu, cs_rows=rps // nf)
+    hip.gn_apply_cs(x1.cuda(), cs1.cuda(), gamma.cuda(), beta.cuda(), y_h, x2=None if x2 is None else x2.cuda(),
+                    cs2=None if cs2 is None else cs2.cuda(), C2=C2, **kw)
+    torch.cuda.synchronize()
+    y_e = torch.zeros(rows, Cc, dtype=T)
+    emu.gn_apply_cs(x1, cs1, gamma, beta, y_e, x2=x2, cs2=cs2, C2=C2, **kw)
+    close(y_h, y_e, f"gn_apply_cs {dt} {samples}x{rps}x({C1}+{C2})", RTOL[dt])
+    ref = torch.nn.functional.group_norm(torch.cat([x1] + ([x2] if C2 else []), dim=1).float().reshape(samples, rps, Cc).permute(0, 2, 1), 32,
+                                         gamma, beta, 1e-5).permute(0, 2, 1).reshape(rows, Cc)
+    ref = torch.nn.functional.silu(ref) if silu else ref
+    assert ((y_e.float() - ref).norm() / ref.norm()).item() < (5e-3 if dt == "bf16" else 1e-5)
