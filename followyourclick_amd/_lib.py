@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
                 ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32), ("conv_pad", i32),
                 ("rows_per_batch", i32), ("seg_cols", i32), ("heads", i32), ("tokens", i32),
                 ("out_scale", f32), ("dtype", i32), ("tile", i32), ("act", i32), ("ln_stats", vp), ("ln_colsum", vp),
-                ("ln_nparts", i32), ("ln_eps", f32), ("chan_stats", vp), ("cs_rows", i32), ("row_parts", vp), ("row_nparts", i32)]
+                ("ln_nparts", i32), ("ln_eps", f32), ("chan_parts", vp), ("cs_rows", i32), ("row_parts", vp), ("row_nparts", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -51,6 +51,10 @@ class GnStatsArgs(C.Structure):
 class GnApplyArgs(C.Structure):
     _fields_ = [("x", vp), ("stats", vp), ("gamma", vp), ("beta", vp), ("y", vp),
                 ("rows", i32), ("C", i32), ("groups", i32), ("rows_per_sample", i32), ("eps", f32), ("silu", i32), ("dtype", i32)]
+
+
+class ChanStatsReduceArgs(C.Structure):
+    _fields_ = [("parts", vp), ("cs", vp), ("rows", i32), ("N", i32), ("cs_rows", i32), ("tile_rows", i32), ("slots", i32)]
 
 
 class GnApplyCsArgs(C.Structure):
@@ -122,9 +126,9 @@ OPS = {
     "fyc_cast_from_f32": CastArgs, "fyc_cast_to_f32": CastArgs, "fyc_unet_input": UnetInputArgs,
     "fyc_cfg_ddim_step": CfgDdimArgs, "fyc_nchw_to_nhwc": NchwInArgs, "fyc_nhwc_to_nchw": NhwcOutArgs,
     "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs, "fyc_row_stats": RowStatsArgs,
-    "fyc_gn_apply_cs": GnApplyCsArgs,
+    "fyc_gn_apply_cs": GnApplyCsArgs, "fyc_chan_stats_reduce": ChanStatsReduceArgs,
 }
-MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts"]
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout"]
 
 _lib = None
 
@@ -149,6 +153,8 @@ def load() -> C.CDLL:
     lib.fyc_set_tuning.argtypes = [C.c_int, C.c_int]
     lib.fyc_gemm_row_parts.argtypes = [C.POINTER(GemmArgs)]
     lib.fyc_gemm_row_parts.restype = C.c_int
+    lib.fyc_gemm_stat_layout.argtypes = [C.POINTER(GemmArgs), C.POINTER(i32), C.POINTER(i32)]
+    lib.fyc_gemm_stat_layout.restype = C.c_int
     for name, st in OPS.items():
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(st), vp]

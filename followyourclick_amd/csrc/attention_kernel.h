@@ -201,31 +201,42 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
       if (tile * KB + kb * 32 >= p.n_k) break;  // whole 32-key block out of range (uniform)
       // ---- S^T tiles: tile t row i <-> key kb*32 + 8*(i>>2) + 4t + (i&3)
       f32x4 s[2][QT];
-      __builtin_amdgcn_s_setprio(1);
+      bf16x8 kf[2][KS > 0 ? KS : 1];
+      s16x4 kt4[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int krow = kb * 32 + 8 * (r16 >> 2) + 4 * t + (r16 & 3);
         const char* kr = sK + krow * (PC * 16);
-        bf16x8 kf[KS > 0 ? KS : 1];
-        s16x4 kt4;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int chunk = 4 * ks + g;
-          kf[ks] = *reinterpret_cast<const bf16x8*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16);
+          kf[t][ks] = *reinterpret_cast<const bf16x8*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16);
         }
         if (TAIL) {
           const int chunk = 4 * KS + (g >> 1);
-          kt4 = *reinterpret_cast<const s16x4*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16 + (g & 1) * 8);
-        }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[qt][ks], a, 0, 0, 0);
-          if (TAIL) a = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt4, qt4[qt], a, 0, 0, 0);
-          s[t][qt] = a;
+          kt4[t] = *reinterpret_cast<const s16x4*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16 + (g & 1) * 8);
         }
       }
+      __builtin_amdgcn_s_setprio(1);
+      // The 16-wide steps of all 2*QT score tiles first (onto zero), then the 32-wide chains on top, with the two groups pinned:
+      // hipcc 7.2 puts no wait state between a v_mfma_f32_16x16x32_bf16 and a v_mfma_f32_16x16x16_bf16 that accumulates onto its
+      // result (or vice versa), and the consumer then reads a stale accumulator (measured: head dims with full steps + a tail
+      // came out wrong whenever the two were adjacent).  This order puts 2*QT-1 independent MFMAs (>= 24 cycles) behind each
+      // 4-pass producer before its accumulator is read again; the 32-wide chains are same-opcode back-to-back (interlocked).
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          s[t][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (TAIL) s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt4[t], qt4[qt], s[t][qt], 0, 0, 0);
+        }
+      if (TAIL && KS > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[qt][ks], s[t][qt], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       // ---- online softmax; lane holds keys kb*32 + 8g + 4t + r of query r16.  MSUB: s already is score - m_run.
       float mx[QT];
@@ -256,7 +267,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
             // new max = bf16(m_run + mx) so that it fits Q' exactly; this block's scores are still relative to the old one
             const float m_new = mv ? bf16_bits_to_f32(f32_to_bf16_bits(m_run[qt] + mx[qt])) : m_run[qt];
             const float delta = m_new - m_run[qt];
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            const float alpha = started ? __builtin_amdgcn_exp2f(-delta) : 1.0f;    // first block: O^T is 0, and 2^-delta may overflow
             m_run[qt] = m_new;
             shift[qt] = delta;
             set_neg_max(qt, m_new);
@@ -264,7 +275,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
             for (int dv = 0; dv < DVT; ++dv) { o[qt][dv][0] *= alpha; o[qt][dv][1] *= alpha; o[qt][dv][2] *= alpha; o[qt][dv][3] *= alpha; }
           } else {
             const float m_new = mv ? mx[qt] : m_run[qt];
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+            const float alpha = started ? __builtin_amdgcn_exp2f(m_run[qt] - m_new) : 1.0f;
             m_run[qt] = m_new;
             shift[qt] = m_new;
 #pragma unroll

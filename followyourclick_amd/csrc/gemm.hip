@@ -26,9 +26,18 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   if (g_fyc_tuning[2] > 0) ns = g_fyc_tuning[2];
   if (cfg != 1 || ns != 3) ns = 2;   // only config 1 is also built 3-deep
 }
-// column-tile width of a tile config (gemm_kernel.h::dispatch_cfg)
+// column-tile width / row-tile height of a tile config (gemm_kernel.h::dispatch_cfg)
 int tile_bn(int cfg) {
   switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: return 320; case 7: return 256; default: return 128; }
+}
+int tile_bm(int cfg) {
+  switch (cfg) { case 3: case 4: case 5: case 7: return 256; default: return 128; }
+}
+// sample slots a row tile of bm rows can touch when a sample has cs_rows rows
+int stat_slots(int bm, int cs_rows) {
+  if (cs_rows % bm == 0) return 1;
+  if (bm % cs_rows == 0) return bm / cs_rows;
+  return (bm - 1) / cs_rows + 2;
 }
 void pick(const fyc_gemm_args* a, int& cfg, int& ns) {
   if (a->dtype == FYC_F32) { cfg = (a->N % 128 == 0) ? 1 : 2; ns = 2; return; }
@@ -45,6 +54,16 @@ extern "C" int fyc_gemm_row_parts(const fyc_gemm_args* a) {
   pick(a, cfg, ns);
   const int bn = tile_bn(cfg);
   return (a->N + bn - 1) / bn;
+}
+
+extern "C" int fyc_gemm_stat_layout(const fyc_gemm_args* a, int32_t* tile_rows, int32_t* slots) {
+  if (a == nullptr || a->M <= 0 || a->cs_rows <= 0) return 0;
+  int cfg = 1, ns = 2;
+  pick(a, cfg, ns);
+  const int bm = tile_bm(cfg);
+  if (tile_rows) *tile_rows = bm;
+  if (slots) *slots = stat_slots(bm, a->cs_rows);
+  return (a->M + bm - 1) / bm;
 }
 
 extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
@@ -76,11 +95,14 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum;
   p.ln_nparts = a->ln_nparts; p.ln_eps = a->ln_eps;
   FYC_REQUIRE(a->ln_nparts >= 0 && (a->ln_nparts == 0 || (a->ln_stats != nullptr && a->a2 == nullptr)), "fyc_gemm: ln_nparts=%d needs ln_stats (and no a2)", a->ln_nparts);
-  p.chan_stats = a->chan_stats; p.cs_rows = a->cs_rows; p.row_parts = a->row_parts; p.row_nparts = a->row_nparts;
-  if (a->chan_stats != nullptr || a->row_parts != nullptr) {
+  p.chan_parts = a->chan_parts; p.cs_rows = a->cs_rows; p.row_parts = a->row_parts; p.row_nparts = a->row_nparts;
+  if (a->chan_parts != nullptr || a->row_parts != nullptr) {
     FYC_REQUIRE(a->epilogue == FYC_EPI_LINEAR && (a->batch <= 1), "fyc_gemm: output statistics need the LINEAR epilogue without batch");
-    FYC_REQUIRE(a->chan_stats == nullptr || (a->cs_rows > 0 && a->cs_rows % 16 == 0 && (a->cs_rows == 64 || a->cs_rows >= 128) && a->M % a->cs_rows == 0 && ((uintptr_t)a->chan_stats % 8) == 0),
-                "fyc_gemm: chan_stats needs cs_rows (=%d) a multiple of 16 that is 64 or >= 128 and divides M=%d", a->cs_rows, a->M);
+    int32_t bm = 0, slots = 0;
+    if (a->chan_parts != nullptr) (void)fyc_gemm_stat_layout(a, &bm, &slots);
+    p.cs_slots = slots;
+    FYC_REQUIRE(a->chan_parts == nullptr || (a->cs_rows > 0 && a->cs_rows % 16 == 0 && slots >= 1 && slots <= 4 && a->M % a->cs_rows == 0 && ((uintptr_t)a->chan_parts % 8) == 0),
+                "fyc_gemm: chan_parts needs cs_rows (=%d) a multiple of 16 dividing M=%d, and at most 4 samples per row tile (%d)", a->cs_rows, a->M, slots);
     FYC_REQUIRE(a->row_parts == nullptr || (((uintptr_t)a->row_parts % 8) == 0 && a->row_nparts == fyc_gemm_row_parts(a)),
                 "fyc_gemm: row_parts needs row_nparts == fyc_gemm_row_parts() = %d (got %d)", fyc_gemm_row_parts(a), a->row_nparts);
   }
@@ -154,7 +176,8 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int cfg = 1, ns = 2;
   pick(a, cfg, ns);
-  FYC_REQUIRE((a->chan_stats == nullptr && a->row_parts == nullptr) || (cfg != 8 && cfg != 10), "fyc_gemm: output statistics are not built for the 64-byte K-tile configs");
+  FYC_REQUIRE((a->chan_parts == nullptr && a->row_parts == nullptr) || (cfg != 8 && cfg != 10), "fyc_gemm: output statistics are not built for the 64-byte K-tile configs");
+  FYC_REQUIRE(a->chan_parts == nullptr || a->dtype == FYC_F32 || p.wide || cfg == 1 || cfg == 2, "fyc_gemm: chan_parts in bf16 needs the 16-byte aligned layout or tile config 1 / 2");
   FYC_REQUIRE(a->row_parts == nullptr || a->dtype == FYC_F32 || p.wide, "fyc_gemm: row_parts in bf16 needs the 16-byte aligned layout (N, ldo, ldr multiples of 8; aligned pointers)");
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, cfg, st);
   if (p.act != FYC_ACT_NONE) {

@@ -45,7 +45,7 @@ struct GemmP {
   const float* ln_stats; const float* ln_colsum;   // folded LayerNorm (see fyc.h): acc := rstd*(acc - mean*colsum[n])
   int ln_nparts; float ln_eps;                     // ln_nparts > 0: ln_stats holds [M][ln_nparts] partial {sum, sum sq} (row_parts of the producer)
   // statistics of the OUTPUT for the GroupNorm / LayerNorm that consumes it (LINEAR epilogue), see fyc.h
-  double* chan_stats; int cs_rows;                 // [M / cs_rows][N][2] += {sum, sum sq} of the stored values per (sample, channel)
+  float* chan_parts; int cs_rows, cs_slots;        // [tiles_m][cs_slots][N][2] = {sum, sum sq} of the stored values per (row tile, sample slot, channel)
   float* row_parts; int row_nparts;                // [M][row_nparts][2] = per row, per column tile {sum, sum sq}
   int tiles_m, tiles_n;
   int strip;  // > 0: tiles are walked in column strips of this many tiles (row-major inside a strip), see tile_coords
@@ -127,22 +127,17 @@ __device__ __forceinline__ void stats_zero(float* cacc, int tid) {
   for (int i = tid; i < STAT_SLOTS * BN * 2 + BM * 2; i += NT) cacc[i] = 0.f;
 }
 
-// after every wave finished accumulating: one f64 atomic pair per (sample slot, column) and one plain float2 store per row
+// after every wave finished accumulating: plain stores of the tile's partial sums (no atomics: 640 device-scope f64 atomics per
+// tile, 327 K per launch, cost the 64x64 convs +77 us each); fyc_chan_stats_reduce adds the row tiles of a sample up
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void stats_flush(const GemmP& p, const float* cacc, int tile_m, int tile_n, int tid) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const float* racc = cacc + STAT_SLOTS * BN * 2;
-  if (p.chan_stats != nullptr) {
-    const int first = (tile_m * BM) / p.cs_rows, nsamp = p.M / p.cs_rows;
-    for (int i = tid; i < STAT_SLOTS * BN; i += NT) {
+  if (p.chan_parts != nullptr) {
+    for (int i = tid; i < p.cs_slots * BN; i += NT) {
       const int slot = i / BN, col = i - slot * BN, n = tile_n * BN + col;
-      const float2 v = *reinterpret_cast<const float2*>(cacc + 2 * i);
-      if (n < p.N && first + slot < nsamp && (v.x != 0.f || v.y != 0.f)) {
-        double* dst = p.chan_stats + ((long long)(first + slot) * p.N + n) * 2;
-        unsafeAtomicAdd(dst, (double)v.x);
-        unsafeAtomicAdd(dst + 1, (double)v.y);
-      }
+      if (n < p.N) *reinterpret_cast<float2*>(p.chan_parts + (((long long)tile_m * p.cs_slots + slot) * p.N + n) * 2) = *reinterpret_cast<const float2*>(cacc + 2 * i);
     }
   }
   if (p.row_parts != nullptr) {
@@ -304,7 +299,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     // output statistics (LINEAR): per-(sample, column) and per-row {sum, sum sq} of the values as stored, see stats_flush
     float* cacc = colc + 2 * BN;
     float* racc = cacc + STAT_SLOTS * BN * 2;
-    const bool do_cs = !GLU && STATS_FIT && p.chan_stats != nullptr, do_rp = !GLU && STATS_FIT && p.row_parts != nullptr;
+    const bool do_cs = !GLU && STATS_FIT && p.chan_parts != nullptr, do_rp = !GLU && STATS_FIT && p.row_parts != nullptr;
     if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);
     stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
     const int first_sample = do_cs ? (tile_m * BM) / p.cs_rows : 0;
@@ -338,10 +333,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           for (int e = 0; e < 8; ++e) { lds_add(dst + 2 * e, cs8[e]); lds_add(dst + 2 * e + 1, cq8[e]); cs8[e] = cq8[e] = 0.f; }
         }
       };
+      // residual rows of a 16-row block are fetched one block ahead (the kernel has one workgroup per CU: nothing else would
+      // hide the HBM round trip, and 8 exposed round trips per tile were most of the time of the K = 320 layers)
+      constexpr int NP = 3;                             // store instructions per 16-row block: ceil(16 / rpp) <= 3
+      u32x4 rres[2][NP];
+      auto fetch_res = [&](int i, u32x4 (&dst)[NP]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int row = q * rpp + lrow;
+          const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
+          const int n = o_w0 + j0 * 16 + lch * 8;
+          dst[q] = (u32x4){0u, 0u, 0u, 0u};
+          if (q * rpp < 16 && lact && row < 16 && m < p.M && n < n_out) dst[q] = *reinterpret_cast<const u32x4*>(R + (long long)m * p.ldr + n);
+        }
+      };
+      if (!GLU && R) fetch_res(0, rres[0]);
 #pragma unroll
       for (int i = 0; i < WTM; ++i) {
         const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
         const float* rb = (!GLU && p.rowbias && !p.rb_tile && m_lane < p.M) ? p.rowbias + (long long)(m_lane / p.rows_per_batch) * p.ldrb : nullptr;
+        if (!GLU && R && i + 1 < WTM) fetch_res(i + 1, rres[(i + 1) & 1]);
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) {
           const int jo = j0 + jj;
@@ -385,7 +396,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           const int slot = (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample;
           if (slot != cur_slot) { flush_cols(); cur_slot = slot; }
         }
-        for (int r0 = 0; r0 < 16; r0 += rpp) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int r0 = q * rpp;
+          if (r0 >= 16) continue;
           const int row = r0 + lrow, ch = lch;
           const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
           const int n = o_w0 + j0 * 16 + ch * 8;
@@ -395,10 +409,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
             *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
             if (!GLU) {
               if (R) {
-                float rr[8];
-                load8<T>(R + (long long)m * p.ldr + n, rr);
+                const u32x4 t = rres[i & 1][q];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
               }
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
@@ -428,7 +441,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
   constexpr bool STATS_OK = (EPI == FYC_EPI_LINEAR || EPI == EPI_LINEAR_ACT) && 2 * BN * 4 + stat_bytes<BM, BN>() <= STG_BYTES;
   float* cacc = colc + 2 * BN;
   float* racc = cacc + STAT_SLOTS * BN * 2;
-  const bool do_cs = STATS_OK && p.chan_stats != nullptr, do_rp = STATS_OK && p.row_parts != nullptr;
+  const bool do_cs = STATS_OK && p.chan_parts != nullptr, do_rp = STATS_OK && p.row_parts != nullptr;
   if (p.colc || do_cs || do_rp) {
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
     if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);

@@ -108,6 +108,26 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// ---- per-(sample, channel) sums from the row-tile partials of the producing GEMM (fyc_gemm chan_parts) ----------------------
+// thread = (sample, channel): adds the {sum, sum sq} of every row tile that overlaps the sample.  Tiny (<= a few MB read).
+__global__ void __launch_bounds__(256) chan_stats_reduce_kernel(const float* __restrict__ parts, double* __restrict__ cs, int samples, int N,
+                                                              int tiles_m, int tile_rows, int slots, int cs_rows) {
+  const int n = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  if (n >= N) return;
+  const int t0 = (int)(((long long)f * cs_rows) / tile_rows);
+  int t1 = (int)((((long long)f + 1) * cs_rows - 1) / tile_rows);
+  if (t1 >= tiles_m) t1 = tiles_m - 1;
+  double s = 0.0, q = 0.0;
+  for (int t = t0; t <= t1; ++t) {
+    const int slot = f - (int)(((long long)t * tile_rows) / cs_rows);
+    if (slot < 0 || slot >= slots) continue;
+    const float2 v = *reinterpret_cast<const float2*>(parts + (((long long)t * slots + slot) * N + n) * 2);
+    s += (double)v.x; q += (double)v.y;
+  }
+  double* dst = cs + ((long long)f * N + n) * 2;
+  dst[0] = s; dst[1] = q;
+}
+
 // ---- GroupNorm apply from per-(sample, channel) sums (+SiLU), optional channel concat of two sources ---------------------
 // The sums come from the epilogues of the GEMMs / convs that produced x1 (and x2): no statistics pass over the tensor.
 // grid = (row chunks, samples).  Prologue: 8 lanes per group fold the group's channels (f64), every thread then keeps
@@ -325,6 +345,17 @@ extern "C" int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream) {
                        (float*)a->y, chunks, a->C, a->groups, a->rows_per_sample, a->eps, a->silu);
   else FYC_FAIL(-2, "fyc_gn_apply: bad dtype");
   FYC_CHECK_LAUNCH("fyc_gn_apply");
+  return 0;
+}
+
+extern "C" int fyc_chan_stats_reduce(const fyc_chan_stats_reduce_args* a, void* stream) {
+  FYC_REQUIRE(a && a->parts && a->cs, "fyc_chan_stats_reduce: null pointer");
+  FYC_REQUIRE(a->rows > 0 && a->N > 0 && a->cs_rows > 0 && a->rows % a->cs_rows == 0 && a->tile_rows > 0 && a->slots >= 1,
+              "fyc_chan_stats_reduce: rows=%d N=%d cs_rows=%d tile_rows=%d slots=%d", a->rows, a->N, a->cs_rows, a->tile_rows, a->slots);
+  const int samples = a->rows / a->cs_rows, tiles_m = (a->rows + a->tile_rows - 1) / a->tile_rows;
+  dim3 grid((a->N + 255) / 256, samples);
+  hipLaunchKernelGGL(chan_stats_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, a->parts, a->cs, samples, a->N, tiles_m, a->tile_rows, a->slots, a->cs_rows);
+  FYC_CHECK_LAUNCH("fyc_chan_stats_reduce");
   return 0;
 }
 

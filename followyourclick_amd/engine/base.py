@@ -28,7 +28,7 @@ class EngineBase:
         return out
 
     def conv(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, stride: int = 1, up2: bool = False,
-             rowbias=None, rpb: int = 1, residual=None, ldrb: int = 0, up_size=None, pad: int = 1, chan_stats=None, cs_rows: int = 0) -> Tensor:
+             rowbias=None, rpb: int = 1, residual=None, ldrb: int = 0, up_size=None, pad: int = 1, chan_parts=None, cs_rows: int = 0) -> Tensor:
         Cout, K = w.shape
         Cin = K // 9
         if up2:
@@ -39,7 +39,7 @@ class EngineBase:
         out = self.new(M, Cout)
         self.ops.gemm(x, w, out, M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, bias=b, rowbias=rowbias, rows_per_batch=rpb, ldrb=ldrb,
                       residual=residual, ldr=Cout, mode=L.GEMM_CONV3X3_UP2 if up2 else L.GEMM_CONV3X3,
-                      conv=dict(Hout=Ho, Wout=Wo, Hin=Hin, Win=Win, Cin=Cin, stride=stride, pad=pad), chan_stats=chan_stats, cs_rows=cs_rows)
+                      conv=dict(Hout=Ho, Wout=Wo, Hin=Hin, Win=Win, Cin=Cin, stride=stride, pad=pad), chan_parts=chan_parts, cs_rows=cs_rows)
         return out
 
     def group_norm(self, x: Tensor, g: Tensor, b: Tensor, rows: int, C: int, rows_per_sample: int, eps: float, silu: bool) -> Tensor:

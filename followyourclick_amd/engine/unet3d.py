@@ -33,12 +33,12 @@ Tensor = torch.Tensor
 # Statistics of an activation are accumulated by the epilogue of the GEMM / conv that writes it (fyc_gemm chan_stats / row_parts)
 # instead of by a read pass per GroupNorm / LayerNorm.  FYC_FUSE_STATS=0 restores the separate passes (A/B measurements).
 FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
-ARENA_DOUBLES = 8 << 20      # 64 MiB of f64 sums per forward (cfg2 needs ~2.5 M doubles); larger requests get their own buffer
+FUSE_ROWS = os.environ.get("FYC_FUSE_ROWS", "1") != "0"      # the LayerNorm half (row_parts) on its own
 
 
 class Act:
-    """an activation [rows][C] plus what its producer already knows about it: `cs` = per-(GroupNorm sample, channel)
-    {sum, sum of squares} ([rows / cs_rows][C][2] f64), `rp` = per-row partial {sum, sum sq} ([rows][rp_n][2] f32)"""
+    """an activation [rows][C] plus what its producer already knows about it: `cs` = per-(frame, channel) {sum, sum of
+    squares} ([rows / cs_rows][C][2] f64), `rp` = per-row partial {sum, sum sq} ([rows][rp_n][2] f32)"""
     __slots__ = ("t", "C", "cs", "cs_rows", "rp", "rp_n")
 
     def __init__(self, t: Tensor, C: int, cs: Optional[Tensor] = None, cs_rows: int = 0, rp: Optional[Tensor] = None, rp_n: int = 0):
@@ -75,8 +75,7 @@ class UNet3DEngine(EngineBase):
             t["idx"] = i
         self.ctx_cache = None
         self.fuse_stats = FUSE_STATS
-        self._arena = None           # f64 bump arena for the channel statistics of one forward
-        self._arena_off = self._arena_dirty = 0
+        self.fuse_rows = FUSE_STATS and FUSE_ROWS
         self.ops.ensure_init(self.device)
 
     # ---- once per clip ---------------------------------------------------------------------
@@ -172,27 +171,22 @@ class UNet3DEngine(EngineBase):
         return st
 
     # ---- fused statistics ------------------------------------------------------------------------
-    def _begin_forward(self) -> None:
-        if self._arena is None:
-            self._arena = torch.zeros(ARENA_DOUBLES, dtype=torch.float64, device=self.device)
-        elif self._arena_dirty:
-            self._arena[: self._arena_dirty].zero_()     # one memset for all GroupNorm statistics of the forward
-        self._arena_off = self._arena_dirty = 0
-
-    def _cs_ok(self, rows_per_sample: int) -> bool:
-        return self.fuse_stats and rows_per_sample % 16 == 0 and (rows_per_sample == 64 or rows_per_sample >= 128)
-
-    def _cs_new(self, rows: int, rows_per_sample: int, C: int) -> Optional[Tensor]:
-        """zeroed [rows / rows_per_sample][C][2] f64 for the producer's epilogue, or None when the shape cannot be fused"""
-        if not self._cs_ok(rows_per_sample) or rows % rows_per_sample:
+    def _cs_plan(self, rows: int, rows_per_sample: int, N: int, K: int, mode: int):
+        """row-tile partial buffer for the producer's epilogue: (parts, tile_rows, slots), or None when the shape cannot be fused
+        (rows per frame not a multiple of 16, or a row tile would touch more than 4 frames)"""
+        if not self.fuse_stats or rows_per_sample % 16 or rows % rows_per_sample:
             return None
-        n = (rows // rows_per_sample) * C * 2
-        if self._arena is None or self._arena_off + n > self._arena.numel():
-            return torch.zeros(n, dtype=torch.float64, device=self.device)
-        v = self._arena[self._arena_off: self._arena_off + n]
-        self._arena_off += n
-        self._arena_dirty = self._arena_off
-        return v
+        nt, tile_rows, slots = self.ops.gemm_stat_layout(self.dtype, M=rows, N=N, K=K, cs_rows=rows_per_sample, mode=mode)
+        if not 1 <= slots <= 4:
+            return None
+        return torch.empty(nt * slots * N * 2, dtype=torch.float32, device=self.device), tile_rows, slots
+
+    def _cs_finish(self, plan, rows: int, rows_per_sample: int, N: int) -> Tensor:
+        """per-(frame, channel) f64 sums from the epilogue's row-tile partials"""
+        parts, tile_rows, slots = plan
+        cs = torch.empty(rows // rows_per_sample, N, 2, dtype=torch.float64, device=self.device)
+        self.ops.chan_stats_reduce(parts, cs, rows=rows, N=N, cs_rows=rows_per_sample, tile_rows=tile_rows, slots=slots)
+        return cs
 
     def _gn(self, x: Union[Act, Tuple[Act, Act]], gamma: Tensor, beta: Tensor, rows: int, rows_per_sample: int, eps: float,
             silu: bool) -> Tuple[Tensor, Optional[Tensor]]:
@@ -221,7 +215,7 @@ class UNet3DEngine(EngineBase):
         N, K = w.shape
         out = self.new(rows, N, dtype=x.dtype)
         rp, n = None, 0
-        if self.fuse_stats:
+        if self.fuse_rows:
             n = self.ops.gemm_row_parts(x.dtype, M=rows, N=N, K=K)
             rp = torch.empty(rows, n, 2, dtype=torch.float32, device=self.device)
         self.ops.gemm(x, w, out, M=rows, N=N, K=K, lda=K, ldw=K, ldo=N, bias=bias, residual=residual, ldr=N, row_parts=rp, row_nparts=n)
@@ -257,15 +251,16 @@ class UNet3DEngine(EngineBase):
     # is always one frame (H*W rows): per-frame norms (transformer / motion module) use the sums as they are, cross-frame norms
     # (ResNet, conv_norm_out) add up the F frame sums in fyc_gn_apply_cs - 16x more atomic targets than per-clip sums.
     def _conv_act(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, nxt: int, **kw) -> Act:
-        Cout = w.shape[0]
+        Cout, K = w.shape
         if kw.get("up2"):
             Ho, Wo = kw["up_size"]
         else:
             st = kw.get("stride", 1)
             Ho, Wo = (Hin - 1) // st + 1, (Win - 1) // st + 1
         rows = frames * Ho * Wo
-        cs = self._cs_new(rows, nxt, Cout) if nxt else None
-        return Act(self.conv(x, w, b, frames, Hin, Win, chan_stats=cs, cs_rows=nxt if cs is not None else 0, **kw), Cout, cs, nxt)
+        plan = self._cs_plan(rows, nxt, Cout, K, L.GEMM_CONV3X3_UP2 if kw.get("up2") else L.GEMM_CONV3X3) if nxt else None
+        out = self.conv(x, w, b, frames, Hin, Win, chan_parts=None if plan is None else plan[0], cs_rows=nxt if plan is not None else 0, **kw)
+        return Act(out, Cout, None if plan is None else self._cs_finish(plan, rows, nxt, Cout), nxt)
 
     def resnet(self, r: Packed, x: Union[Act, Tuple[Act, Act]], temb: Tensor, g: dict, nxt: int) -> Act:
         """ResnetBlock3D (reference resnet.py:296-342): cross-frame GroupNorm statistics.  x may be the (hidden, skip) pair of an
@@ -302,14 +297,15 @@ class UNet3DEngine(EngineBase):
             hmid = self.lin(n, ff.w1, rows, bias=ff.b1, geglu=True)
         out = self.new(rows, C)
         K = ff.po_w.shape[1]
-        cs = self._cs_new(rows, nxt, C) if nxt else None
+        plan = self._cs_plan(rows, nxt, C, K, L.GEMM_PLAIN) if nxt else None
         rp, rp_n = None, 0
-        if residual is None and self.fuse_stats:     # inner motion blocks: the output is the next block's token stream (LayerNorm input)
+        if residual is None and self.fuse_rows:      # inner motion blocks: the output is the next block's token stream (LayerNorm input)
             rp_n = self.ops.gemm_row_parts(tok.t.dtype, M=rows, N=C, K=K)
             rp = torch.empty(rows, rp_n, 2, dtype=torch.float32, device=self.device)
         self.ops.gemm(tok.t, ff.po_w, out, M=rows, N=C, K=K, lda=C, ldw=K, ldo=C, bias=ff.po_b, residual=residual, ldr=C,
-                      a2=hmid, k_split=C, lda2=K - C, chan_stats=cs, cs_rows=nxt if cs is not None else 0, row_parts=rp, row_nparts=rp_n)
-        return Act(out, C, cs, nxt, rp, rp_n)
+                      a2=hmid, k_split=C, lda2=K - C, chan_parts=None if plan is None else plan[0], cs_rows=nxt if plan is not None else 0,
+                      row_parts=rp, row_nparts=rp_n)
+        return Act(out, C, None if plan is None else self._cs_finish(plan, rows, nxt, C), nxt, rp, rp_n)
 
     def transformer(self, t: Packed, x: Act, g: dict, nxt: int) -> Act:
         """Transformer3DModel + BasicTransformerBlock (reference attention.py:217-308, 489-564)."""
@@ -393,7 +389,6 @@ class UNet3DEngine(EngineBase):
             g["temb_per_frame"] = True
         if cfg.use_first_frame_condition_concat:
             raise NotImplementedError("use_first_frame_condition_concat (sample/2 path, reference unet.py:589-590)")
-        self._begin_forward()
         frames = B * F
 
         def hw(gg):         # rows of one frame = one statistics sample of every producer

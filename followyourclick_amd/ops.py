@@ -88,13 +88,13 @@ class HipOps:
              stride_w: int = 0, stride_o: int = 0, heads: Optional[dict] = None, tile: int = 0,
              a2: Optional[Tensor] = None, k_split: int = 0, lda2: int = 0, act: int = L.ACT_NONE,
              ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None, ln_nparts: int = 0, ln_eps: float = 1e-5,
-             chan_stats: Optional[Tensor] = None, cs_rows: int = 0, row_parts: Optional[Tensor] = None, row_nparts: int = 0) -> None:
+             chan_parts: Optional[Tensor] = None, cs_rows: int = 0, row_parts: Optional[Tensor] = None, row_nparts: int = 0) -> None:
         self.ensure_init(a.device)
         g = self._gemm_args(a, w, out, M=M, N=N, K=K, lda=lda, ldw=ldw, ldo=ldo, bias=bias, rowbias=rowbias, rows_per_batch=rows_per_batch,
                             residual=residual, ldr=ldr, ldrb=ldrb, out_scale=out_scale, epilogue=epilogue, mode=mode, conv=conv, batch=batch,
                             stride_a=stride_a, stride_w=stride_w, stride_o=stride_o, heads=heads, tile=tile, a2=a2, k_split=k_split,
                             lda2=lda2, act=act, ln_stats=ln_stats, ln_colsum=ln_colsum, ln_nparts=ln_nparts, ln_eps=ln_eps,
-                            chan_stats=chan_stats, cs_rows=cs_rows, row_parts=row_parts, row_nparts=row_nparts)
+                            chan_parts=chan_parts, cs_rows=cs_rows, row_parts=row_parts, row_nparts=row_nparts)
         self._call("fyc_gemm", g)
 
     def gemm_row_parts(self, dtype: torch.dtype, *, M: int, N: int, K: int, mode: int = L.GEMM_PLAIN, batch: int = 1, tile: int = 0) -> int:
@@ -104,10 +104,27 @@ class HipOps:
         g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
         return int(self.lib.fyc_gemm_row_parts(C.byref(g)))
 
+    def gemm_stat_layout(self, dtype: torch.dtype, *, M: int, N: int, K: int, cs_rows: int, mode: int = L.GEMM_PLAIN, batch: int = 1,
+                         tile: int = 0):
+        """(row tiles, rows per tile, sample slots per tile) of the `chan_parts` output of this problem (fyc_gemm_stat_layout)"""
+        g = L.GemmArgs()
+        g.M, g.N, g.K, g.mode, g.batch, g.tile, g.cs_rows = M, N, K, mode, batch, tile, cs_rows
+        g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+        tr, sl = L.i32(0), L.i32(0)
+        n = int(self.lib.fyc_gemm_stat_layout(C.byref(g), C.byref(tr), C.byref(sl)))
+        return n, int(tr.value), int(sl.value)
+
+    def chan_stats_reduce(self, parts: Tensor, cs: Tensor, *, rows: int, N: int, cs_rows: int, tile_rows: int, slots: int) -> None:
+        if cs.dtype != torch.float64:
+            raise TypeError("channel statistics must be float64")
+        a = L.ChanStatsReduceArgs()
+        a.parts, a.cs, a.rows, a.N, a.cs_rows, a.tile_rows, a.slots = _f32(parts, "parts"), _p(cs), rows, N, cs_rows, tile_rows, slots
+        self._call("fyc_chan_stats_reduce", a)
+
     @staticmethod
     def _gemm_args(a, w, out, *, M, N, K, lda, ldw, ldo, bias, rowbias, rows_per_batch, residual, ldr, ldrb, out_scale, epilogue, mode,
                    conv, batch, stride_a, stride_w, stride_o, heads, tile, a2, k_split, lda2, act, ln_stats, ln_colsum, ln_nparts,
-                   ln_eps, chan_stats, cs_rows, row_parts, row_nparts):
+                   ln_eps, chan_parts, cs_rows, row_parts, row_nparts):
         g = L.GemmArgs()
         g.a, g.w, g.bias, g.rowbias = _p(a), _p(w), _f32(bias, "bias"), _f32(rowbias, "rowbias")
         g.residual, g.out = _p(residual), _p(out)
@@ -128,9 +145,7 @@ class HipOps:
             for i, (t, tr, ld) in enumerate(zip(heads["outs"], heads["transposed"], heads["ld"])):
                 g.seg_out[i], g.seg_transposed[i], g.seg_ld[i] = _p(t), int(tr), int(ld)
         g.ln_nparts, g.ln_eps = ln_nparts, ln_eps
-        if chan_stats is not None and chan_stats.dtype != torch.float64:
-            raise TypeError("chan_stats must be float64")
-        g.chan_stats, g.cs_rows = _p(chan_stats), cs_rows
+        g.chan_parts, g.cs_rows = _f32(chan_parts, "chan_parts"), cs_rows
         g.row_parts, g.row_nparts = _f32(row_parts, "row_parts"), row_nparts
         return g
 

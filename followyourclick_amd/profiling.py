@@ -86,8 +86,14 @@ class TimedOps:
     def gn_apply_cs(self, x1, cs1, g, b, y, **kw):
         return self._timed("gn_apply", 0.0, 2.0 * kw["rows"] * (kw["C1"] + kw.get("C2", 0)) * _esize(x1), self.inner.gn_apply_cs, x1, cs1, g, b, y, **kw)
 
-    def gemm_row_parts(self, dtype, **kw):      # host-side query, no kernel
+    def gemm_row_parts(self, dtype, **kw):      # host-side queries, no kernel
         return self.inner.gemm_row_parts(dtype, **kw)
+
+    def gemm_stat_layout(self, dtype, **kw):
+        return self.inner.gemm_stat_layout(dtype, **kw)
+
+    def chan_stats_reduce(self, parts, cs, **kw):
+        return self._timed("gn_stats", 0.0, 0.0, self.inner.chan_stats_reduce, parts, cs, **kw)
 
     def layernorm(self, x, g, b, y, **kw):
         return self._timed("layernorm", 0.0, 2.0 * kw["rows"] * kw["C_"] * _esize(x), self.inner.layernorm, x, g, b, y, **kw)

@@ -96,18 +96,27 @@ typedef struct {
   int32_t ln_nparts; float ln_eps;
   /* Statistics of the OUTPUT, accumulated by the epilogue that writes it (LINEAR epilogue, batch <= 1), so that the GroupNorm /
    * LayerNorm consuming `out` needs no read pass of its own (reference resnet.py:299,322, attention.py:269,383,412,418,
-   * motion_module.py:181,261,267).  The sums are of the values AS STORED (rounded to `dtype`).
-   *  chan_stats [M / cs_rows][N][2] doubles: per (sample, channel) {sum, sum of squares}, ADDED to the buffer with atomics (the
-   *    caller zeroes it).  cs_rows = rows per GroupNorm sample (H*W per-frame, F*H*W cross-frame): a multiple of 16, 64 or >= 128.
-   *    Consumed by fyc_gn_apply_cs.
-   *  row_parts [M][row_nparts][2] floats: per row and column tile {sum, sum of squares} (plain stores, nothing to zero);
-   *    row_nparts must equal fyc_gemm_row_parts(args).  Consumed through ln_stats / ln_nparts of the next GEMM. */
-  double* chan_stats; int32_t cs_rows;
+   * motion_module.py:181,261,267).  The sums are of the values AS STORED (rounded to `dtype`); plain stores, nothing to zero.
+   *  chan_parts [row tiles][slots][N][2] floats: per (row tile, sample slot, channel) {sum, sum of squares}; a GroupNorm sample
+   *    (cs_rows rows: one frame, H*W) that a row tile touches gets slot = sample - first sample of the tile.  Row tile height and
+   *    slot count come from fyc_gemm_stat_layout(); fyc_chan_stats_reduce folds the tiles into per-(sample, channel) sums.
+   *    cs_rows must be a multiple of 16 and a row tile may touch at most 4 samples.
+   *  row_parts [M][row_nparts][2] floats: per row and column tile {sum, sum of squares}; row_nparts must equal
+   *    fyc_gemm_row_parts(args).  Consumed through ln_stats / ln_nparts of the next GEMM. */
+  float* chan_parts; int32_t cs_rows;
   float* row_parts; int32_t row_nparts;
 } fyc_gemm_args;
 int fyc_gemm(const fyc_gemm_args* a, void* stream);
 /* number of column tiles fyc_gemm will use for these arguments (M, N, K, mode, dtype, batch, tile are read) = row_nparts */
 int fyc_gemm_row_parts(const fyc_gemm_args* a);
+/* layout of chan_parts for these arguments (also cs_rows is read): returns the number of row tiles, *tile_rows = rows per tile,
+ * *slots = sample slots per tile; chan_parts holds row_tiles * slots * N * 2 floats */
+int fyc_gemm_stat_layout(const fyc_gemm_args* a, int32_t* tile_rows, int32_t* slots);
+
+/* cs[f][n] = {sum, sum of squares} over the rows of sample f (cs_rows rows each) of channel n, in f64, from the row-tile partials
+ * a fyc_gemm epilogue wrote (chan_parts; tile_rows / slots from fyc_gemm_stat_layout).  cs: [rows / cs_rows][N][2] doubles. */
+typedef struct { const float* parts; double* cs; int32_t rows, N, cs_rows, tile_rows, slots; } fyc_chan_stats_reduce_args;
+int fyc_chan_stats_reduce(const fyc_chan_stats_reduce_args* a, void* stream);
 
 /* ---- fused flash attention (bf16 MFMA, online softmax) ----------------------------------
  * o[b][tok][h*d + i] = softmax_k( q[b,h,tok,:] . k[b,h,key,:] * scale ) @ v
@@ -167,7 +176,7 @@ typedef struct {
 } fyc_gn_apply_args;
 int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream);
 
-/* GroupNorm apply (+SiLU) from per-(sample, channel) sums written by the producers' epilogues (fyc_gemm chan_stats), with the
+/* GroupNorm apply (+SiLU) from per-(sample, channel) sums (fyc_gemm chan_parts -> fyc_chan_stats_reduce), with the
  * channel concat of the up blocks folded in (torch.cat([hidden, skip], dim=1) -> norm1, reference unet_blocks.py:763,885;
  * resnet.py:299-302): y[r][0:C1] from x1, y[r][C1:C1+C2] from x2 (x2 = NULL, C2 = 0: one source).  Groups are taken over the
  * concatenated channel index and may straddle the two sources.  cs1 / cs2: [rows / cs_rows][C][2] doubles. */

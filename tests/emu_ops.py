@@ -40,12 +40,12 @@ class EmuOps:
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
              ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
              heads=None, tile=0, a2=None, k_split=0, lda2=0, act=0, ln_stats=None, ln_colsum=None, ln_nparts=0, ln_eps=1e-5,
-             chan_stats=None, cs_rows=0, row_parts=None, row_nparts=0):
+             chan_parts=None, cs_rows=0, row_parts=None, row_nparts=0):
         acc_t = self.acc
-        if chan_stats is not None or row_parts is not None:
+        if chan_parts is not None or row_parts is not None:
             assert epilogue == LINEAR and batch == 1
-        if chan_stats is not None:
-            assert cs_rows % 16 == 0 and (cs_rows == 64 or cs_rows >= 128) and M % cs_rows == 0, (cs_rows, M)
+        if chan_parts is not None:
+            assert cs_rows % 16 == 0 and M % cs_rows == 0, (cs_rows, M)
         if row_parts is not None:
             assert row_nparts == self.gemm_row_parts(a.dtype, M=M, N=N, K=K, mode=mode)
         af, wf = _flat(a), _flat(w)
@@ -105,13 +105,19 @@ class EmuOps:
                 acc = acc * out_scale
                 o = _strided(_flat(out), (M, N), (ldo, 1), z * stride_o)
                 o.copy_(acc.to(out.dtype))
-                if chan_stats is not None or row_parts is not None:      # statistics of the values as stored
+                if chan_parts is not None or row_parts is not None:      # statistics of the values as stored
                     v = o.double()
-                    if chan_stats is not None:
-                        cs = _flat(chan_stats)[: (M // cs_rows) * N * 2].reshape(M // cs_rows, N, 2)
-                        vs = v.reshape(M // cs_rows, cs_rows, N)
-                        cs[:, :, 0] += vs.sum(dim=1)
-                        cs[:, :, 1] += (vs * vs).sum(dim=1)
+                    if chan_parts is not None:       # [row tiles][slots][N][2], slot = sample - first sample of the tile
+                        nt, tr, sl = self.gemm_stat_layout(a.dtype, M=M, N=N, K=K, cs_rows=cs_rows, mode=mode)
+                        cp = _flat(chan_parts)[: nt * sl * N * 2].reshape(nt, sl, N, 2)
+                        cp.zero_()
+                        for t in range(nt):
+                            r0, r1 = t * tr, min((t + 1) * tr, M)
+                            first = r0 // cs_rows
+                            for f in range(first, (r1 - 1) // cs_rows + 1):
+                                blk = v[max(r0, f * cs_rows):min(r1, (f + 1) * cs_rows)]
+                                cp[t, f - first, :, 0] = blk.sum(dim=0).float()
+                                cp[t, f - first, :, 1] = (blk * blk).sum(dim=0).float()
                     if row_parts is not None:
                         rp = _flat(row_parts)[: M * row_nparts * 2].reshape(M, row_nparts, 2)
                         edges = [round(i * N / row_nparts) for i in range(row_nparts + 1)]
@@ -131,6 +137,22 @@ class EmuOps:
                         ld = ld if ld > 0 else T
                         v = _strided(_flat(t), (Bn, H, d, T), (H * d * ld, d * ld, ld, 1), 0)
                         v.copy_(seg.permute(0, 2, 3, 1).to(t.dtype))
+
+    def gemm_stat_layout(self, dtype, *, M, N, K, cs_rows, mode=PLAIN, batch=1, tile=0):
+        """row tiles of 96 rows: neither a divisor nor a multiple of the usual sample sizes, so samples straddle tiles"""
+        tr = 96
+        return (M + tr - 1) // tr, tr, (tr - 1) // cs_rows + 2
+
+    def chan_stats_reduce(self, parts, cs, *, rows, N, cs_rows, tile_rows, slots):
+        nt = (rows + tile_rows - 1) // tile_rows
+        p = _flat(parts)[: nt * slots * N * 2].reshape(nt, slots, N, 2).double()
+        out = torch.zeros(rows // cs_rows, N, 2, dtype=torch.float64)
+        for t in range(nt):
+            first = (t * tile_rows) // cs_rows
+            for sl in range(slots):
+                if first + sl < out.shape[0]:
+                    out[first + sl] += p[t, sl]
+        _flat(cs)[: out.numel()].reshape(out.shape).copy_(out)
 
     def gemm_row_parts(self, dtype, *, M, N, K, mode=PLAIN, batch=1, tile=0):
         """any partition of the columns is valid for the consumer; use several parts so that their summation is exercised"""

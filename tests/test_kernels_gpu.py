@@ -556,22 +556,27 @@ STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7]
 
 @pytest.mark.parametrize("dt,tile", [("bf16", t) for t in STAT_TILES] + [("f32", 0)])
 @pytest.mark.parametrize("M,N,K,cs_rows,res", [(512, 320, 320, 64, True), (768, 640, 128, 128, True), (1152, 128, 64, 192, False),
-                                               (4096, 320, 64, 4096, True), (1280, 328, 72, 640, False)])
+                                               (4096, 320, 64, 4096, True), (1280, 328, 72, 640, False), (1040, 64, 64, 80, False)])
 def test_gemm_output_statistics(hip, emu, dt, tile, M, N, K, cs_rows, res):
-    """per-(sample, channel) and per-row {sum, sum of squares} written by the LINEAR epilogue == sums of the values it stored
-    (partial row / column tiles, up to 4 samples per tile, samples straddling tiles, accumulation into a non-zero buffer)"""
+    """per-(row tile, sample, channel) and per-row {sum, sum of squares} written by the LINEAR epilogue, folded by
+    fyc_chan_stats_reduce == sums of the values it stored (partial row / column tiles, up to 4 samples per tile, samples
+    straddling tiles)"""
     T = DT[dt]
     a, w = rnd((M, K), T, 1), rnd((N, K), T, 2, 1 / math.sqrt(K))
     bias, r = rnd((N,), torch.float32, 3), (rnd((M, N), T, 4) if res else None)
-    init = rnd((M // cs_rows, N, 2), torch.float64, 7)
     hip.set_tuning(1, tile)
     try:
         nparts = hip.gemm_row_parts(T, M=M, N=N, K=K)
+        nt, tile_rows, slots = hip.gemm_stat_layout(T, M=M, N=N, K=K, cs_rows=cs_rows)
+        if slots > 4:
+            pytest.skip("more than 4 samples per row tile: the engine falls back to the separate statistics pass")
         o_h = torch.full((M, N), float("nan"), dtype=T, device="cuda")
-        cs = init.clone().cuda()
+        parts = torch.full((nt * slots * N * 2,), float("nan"), dtype=torch.float32, device="cuda")
         rp = torch.full((M, nparts, 2), float("nan"), dtype=torch.float32, device="cuda")
         hip.gemm(a.cuda(), w.cuda(), o_h, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, bias=bias.cuda(), residual=None if r is None else r.cuda(),
-                 out_scale=1.25, chan_stats=cs, cs_rows=cs_rows, row_parts=rp, row_nparts=nparts)
+                 out_scale=1.25, chan_parts=parts, cs_rows=cs_rows, row_parts=rp, row_nparts=nparts)
+        cs = torch.full((M // cs_rows, N, 2), float("nan"), dtype=torch.float64, device="cuda")
+        hip.chan_stats_reduce(parts, cs, rows=M, N=N, cs_rows=cs_rows, tile_rows=tile_rows, slots=slots)
         torch.cuda.synchronize()
     finally:
         hip.set_tuning(1, 0)
@@ -580,8 +585,7 @@ def test_gemm_output_statistics(hip, emu, dt, tile, M, N, K, cs_rows, res):
     close(o_h, o_e, f"gemm+stats {dt} tile {tile}", RTOL[dt])
     v = o_h.cpu().double()
     vs = v.reshape(M // cs_rows, cs_rows, N)
-    want = init + torch.stack([vs.sum(dim=1), (vs * vs).sum(dim=1)], dim=-1)
-    close(cs, want, f"chan_stats {dt} tile {tile}", 2e-6)
+    close(cs, torch.stack([vs.sum(dim=1), (vs * vs).sum(dim=1)], dim=-1), f"chan stats {dt} tile {tile} ({tile_rows}-row tiles, {slots} slots)", 2e-6)
     rows = rp.cpu().double().sum(dim=1)
     close(rows, torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], dim=-1), f"row_parts {dt} tile {tile} ({nparts} parts)", 2e-6)
 
@@ -595,15 +599,18 @@ def test_conv_output_statistics(hip, emu, dt):
     res = rnd((M, Cout), T, 4)
     conv = dict(Hout=H, Wout=W, Hin=H, Win=W, Cin=Cin, stride=1)
     for cs_rows in (H * W, 2 * H * W):
-        cs = torch.zeros(M // cs_rows, Cout, 2, dtype=torch.float64, device="cuda")
+        nt, tile_rows, slots = hip.gemm_stat_layout(T, M=M, N=Cout, K=K, cs_rows=cs_rows, mode=1)
+        parts = torch.full((nt * slots * Cout * 2,), float("nan"), dtype=torch.float32, device="cuda")
         o_h = torch.empty(M, Cout, dtype=T, device="cuda")
         hip.gemm(x.cuda(), w.cuda(), o_h, M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, ldr=Cout, bias=bias.cuda(), residual=res.cuda(),
-                 mode=1, conv=conv, chan_stats=cs, cs_rows=cs_rows)
+                 mode=1, conv=conv, chan_parts=parts, cs_rows=cs_rows)
+        cs = torch.empty(M // cs_rows, Cout, 2, dtype=torch.float64, device="cuda")
+        hip.chan_stats_reduce(parts, cs, rows=M, N=Cout, cs_rows=cs_rows, tile_rows=tile_rows, slots=slots)
         torch.cuda.synchronize()
         vs = o_h.cpu().double().reshape(M // cs_rows, cs_rows, Cout)
-        close(cs, torch.stack([vs.sum(dim=1), (vs * vs).sum(dim=1)], dim=-1), f"conv chan_stats {dt} rows/sample {cs_rows}", 2e-6)
+        close(cs, torch.stack([vs.sum(dim=1), (vs * vs).sum(dim=1)], dim=-1), f"conv chan stats {dt} rows/sample {cs_rows}", 2e-6)
     with pytest.raises(Exception, match="cs_rows"):
-        hip.gemm(x.cuda(), w.cuda(), o_h, M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, mode=1, conv=conv, chan_stats=cs, cs_rows=48)
+        hip.gemm(x.cuda(), w.cuda(), o_h, M=M, N=Cout, K=K, lda=Cin, ldw=K, ldo=Cout, mode=1, conv=conv, chan_parts=parts, cs_rows=40)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
