@@ -54,7 +54,7 @@ class GnApplyArgs(C.Structure):
 
 
 class ChanStatsReduceArgs(C.Structure):
-    _fields_ = [("parts", vp), ("cs", vp), ("rows", i32), ("N", i32), ("cs_rows", i32), ("tile_rows", i32), ("slots", i32)]
+    _fields_ = [("parts", vp), ("cs", vp), ("rows", i32), ("N", i32), ("cs_rows", i32), ("tile_rows", i32), ("slots", i32), ("out_rows", i32)]
 
 
 class GnApplyCsArgs(C.Structure):

@@ -416,16 +416,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
             }
-            store8<T>(O + (long long)m * p.ldo + n, v);
-            if (do_cs || do_rp) {
+            // statistics of the values AS STORED: pack once (v_cvt_pk_bf16_f32), store, unpack with a shift / mask
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n) = pk;
+            if (do_cs) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x0 = __uint_as_float(pk[e] << 16), x1 = __uint_as_float(pk[e] & 0xffff0000u);
+                cs8[2 * e] += x0; cq8[2 * e] = __builtin_fmaf(x0, x0, cq8[2 * e]);
+                cs8[2 * e + 1] += x1; cq8[2 * e + 1] = __builtin_fmaf(x1, x1, cq8[2 * e + 1]);
+              }
+            }
+            if (do_rp) {
               float rs = 0.f, rq = 0.f;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float x = round_to<T>(v[e]);
-                cs8[e] += x; cq8[e] = __builtin_fmaf(x, x, cq8[e]);
-                rs += x; rq = __builtin_fmaf(x, x, rq);
+              for (int e = 0; e < 4; ++e) {
+                const float x0 = __uint_as_float(pk[e] << 16), x1 = __uint_as_float(pk[e] & 0xffff0000u);
+                rs += x0 + x1; rq = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, rq));
               }
-              if (do_rp) { float* dst = racc + ((wm * WTM + i) * 16 + row) * 2; lds_add(dst, rs); lds_add(dst + 1, rq); }
+              float* dst = racc + ((wm * WTM + i) * 16 + row) * 2;
+              lds_add(dst, rs); lds_add(dst + 1, rq);
             }
           }
         }
@@ -609,20 +621,43 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   constexpr int ROWS_IT = NT / CPR;
   static_assert(ROWS_IT % 16 == 0, "row stride per DMA instruction must keep the swizzle key");
   int i_tm = 0, i_tn = 0;                 // tile coordinates of the tile being issued (wave-uniform)
-  int a_pix[MODE == FYC_GEMM_PLAIN ? 1 : A_IT], a_yx[MODE == FYC_GEMM_PLAIN ? 1 : A_IT];   // conv: frame pixel base (-1: row outside M), (iy0 << 16) | (ix0 & 0xffff)
+  // element offsets of this thread's first row of the tile (row `it` adds it * ROWS_IT * ld, a wave-uniform term)
+  long long a_base = 0, a2_base = 0, b_base = 0;
+  // conv: per row, pixel position of the top-left tap (pos0 = frame base + iy0*Win + ix0, may point outside the image) and a
+  // 9-bit mask of the taps that fall inside the image (0 for rows beyond M) - built once per tile (KT = 45..360 K tiles follow);
+  // per K tile a gather address is pos0 + tap offset (scalar) -> one 64-bit multiply-add
+  constexpr bool C3 = (MODE == FYC_GEMM_CONV3X3);
+  int a_pos[C3 ? A_IT : 1], a_msk[C3 ? A_IT : 1];
+  int a_pix[MODE == FYC_GEMM_CONV3X3_UP2 ? A_IT : 1], a_yx[MODE == FYC_GEMM_CONV3X3_UP2 ? A_IT : 1];   // upsampled conv: frame pixel base (-1: row outside M), (iy0 << 16) | (ix0 & 0xffff)
   int tap = 0, c0 = 0;  // conv: filter tap and channel offset of the K tile being issued
   auto setup_issue = [&](int tile) {
     const int t = remap(tile);
     tile_coords(p, t, i_tm, i_tn);
     tap = 0; c0 = 0;
-    if (MODE != FYC_GEMM_PLAIN) {
+    b_base = (long long)(i_tn * BN + lrow) * p.ldw + koff;
+    if (MODE == FYC_GEMM_PLAIN) {
+      a_base = (long long)(i_tm * BM + lrow) * p.lda + koff;
+      a2_base = (long long)(i_tm * BM + lrow) * p.lda2 + koff - p.k_split;
+    } else {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
         const int m = i_tm * BM + lrow + it * ROWS_IT;
         const int hw = p.Hout * p.Wout;
         const int fr = m / hw, rem = m - fr * hw, oy = rem / p.Wout, ox = rem - oy * p.Wout;
-        a_pix[it] = (m < p.M) ? fr * p.Hin * p.Win : -1;
-        a_yx[it] = ((oy * p.conv_stride - p.conv_pad) << 16) | ((ox * p.conv_stride - p.conv_pad) & 0xffff);
+        const int iy0 = oy * p.conv_stride - p.conv_pad, ix0 = ox * p.conv_stride - p.conv_pad;
+        if (C3) {
+          a_pos[it] = fr * p.Hin * p.Win + iy0 * p.Win + ix0;
+          int msk = 0;
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int iy = iy0 + tp / 3, ix = ix0 + tp % 3;
+            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) msk |= 1 << tp;
+          }
+          a_msk[it] = (m < p.M) ? msk : 0;
+        } else {
+          a_pix[it] = (m < p.M) ? fr * p.Hin * p.Win : -1;
+          a_yx[it] = (iy0 << 16) | (ix0 & 0xffff);
+        }
       }
     }
   };
@@ -634,30 +669,28 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       const int m = i_tm * BM + lrow + it * ROWS_IT;
       const int k = k0 + koff;
       if (m >= p.M || k >= p.K) return zero;
-      if (A2 != nullptr && k >= p.k_split) return A2 + (long long)m * p.lda2 + (k - p.k_split);
-      return A + (long long)m * p.lda + k;
-    } else {
+      if (A2 != nullptr && k >= p.k_split) return A2 + (a2_base + (long long)(it * ROWS_IT) * p.lda2 + k0);
+      return A + (a_base + (long long)(it * ROWS_IT) * p.lda + k0);
+    } else if (C3) {
+      const int ky = tap / 3, kx = tap - 3 * ky;                      // wave-uniform
+      const int pos = a_pos[it] + ky * p.Win + kx;
+      return ((a_msk[it] >> tap) & 1) ? A + ((long long)pos * p.Cin + (c0 + koff)) : zero;
+    } else {  // nearest-upsampled input of virtual size (Hout, Wout): F.interpolate(mode="nearest") folded into the gather
       const int ky = tap / 3, kx = tap - 3 * ky;
       const int iy = (a_yx[it] >> 16) + ky, ix = (int)(short)(a_yx[it] & 0xffff) + kx;
-      if (MODE == FYC_GEMM_CONV3X3) {
-        const bool ok = a_pix[it] >= 0 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-        return ok ? A + (long long)(a_pix[it] + iy * p.Win + ix) * p.Cin + c0 + koff : zero;
-      } else {  // nearest-upsampled input of virtual size (Hout, Wout): F.interpolate(mode="nearest") folded into the gather
-        const bool ok = a_pix[it] >= 0 && (unsigned)iy < (unsigned)p.Hout && (unsigned)ix < (unsigned)p.Wout;
-        int sy, sx;
-        if (p.up_exact2) { sy = iy >> 1; sx = ix >> 1; }
-        else {  // torch: src = min(floor(dst * (in / out)), in - 1), scale in f32
-          sy = min((int)floorf((float)iy * p.up_sh), p.Hin - 1);
-          sx = min((int)floorf((float)ix * p.up_sw), p.Win - 1);
-        }
-        return ok ? A + (long long)(a_pix[it] + sy * p.Win + sx) * p.Cin + c0 + koff : zero;
+      const bool ok = a_pix[it] >= 0 && (unsigned)iy < (unsigned)p.Hout && (unsigned)ix < (unsigned)p.Wout;
+      int sy, sx;
+      if (p.up_exact2) { sy = iy >> 1; sx = ix >> 1; }
+      else {  // torch: src = min(floor(dst * (in / out)), in - 1), scale in f32
+        sy = min((int)floorf((float)iy * p.up_sh), p.Hin - 1);
+        sx = min((int)floorf((float)ix * p.up_sw), p.Win - 1);
       }
+      return ok ? A + (long long)(a_pix[it] + sy * p.Win + sx) * p.Cin + c0 + koff : zero;
     }
   };
   auto src_b = [&](int it, int k0) -> const T* {
     const int n = i_tn * BN + lrow + it * ROWS_IT;
-    const int k = k0 + koff;
-    return (n < p.N && k < p.K) ? W + (long long)n * p.ldw + k : zero;
+    return (n < p.N && k0 + koff < p.K) ? W + (b_base + (long long)(it * ROWS_IT) * p.ldw + k0) : zero;
   };
 
   f32x4 acc[WTM][WTN];

@@ -110,21 +110,23 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
 
 // ---- per-(sample, channel) sums from the row-tile partials of the producing GEMM (fyc_gemm chan_parts) ----------------------
 // thread = (sample, channel): adds the {sum, sum sq} of every row tile that overlaps the sample.  Tiny (<= a few MB read).
-__global__ void __launch_bounds__(256) chan_stats_reduce_kernel(const float* __restrict__ parts, double* __restrict__ cs, int samples, int N,
-                                                              int tiles_m, int tile_rows, int slots, int cs_rows) {
-  const int n = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+__global__ void __launch_bounds__(256) chan_stats_reduce_kernel(const float* __restrict__ parts, double* __restrict__ cs, int N,
+                                                              int tiles_m, int tile_rows, int slots, int cs_rows, int group) {
+  const int n = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;      // output sample o = `group` consecutive statistics samples
   if (n >= N) return;
-  const int t0 = (int)(((long long)f * cs_rows) / tile_rows);
-  int t1 = (int)((((long long)f + 1) * cs_rows - 1) / tile_rows);
-  if (t1 >= tiles_m) t1 = tiles_m - 1;
   double s = 0.0, q = 0.0;
-  for (int t = t0; t <= t1; ++t) {
-    const int slot = f - (int)(((long long)t * tile_rows) / cs_rows);
-    if (slot < 0 || slot >= slots) continue;
-    const float2 v = *reinterpret_cast<const float2*>(parts + (((long long)t * slots + slot) * N + n) * 2);
-    s += (double)v.x; q += (double)v.y;
+  for (int f = o * group; f < (o + 1) * group; ++f) {
+    const int t0 = (int)(((long long)f * cs_rows) / tile_rows);
+    int t1 = (int)((((long long)f + 1) * cs_rows - 1) / tile_rows);
+    if (t1 >= tiles_m) t1 = tiles_m - 1;
+    for (int t = t0; t <= t1; ++t) {
+      const int slot = f - (int)(((long long)t * tile_rows) / cs_rows);
+      if (slot < 0 || slot >= slots) continue;
+      const float2 v = *reinterpret_cast<const float2*>(parts + (((long long)t * slots + slot) * N + n) * 2);
+      s += (double)v.x; q += (double)v.y;
+    }
   }
-  double* dst = cs + ((long long)f * N + n) * 2;
+  double* dst = cs + ((long long)o * N + n) * 2;
   dst[0] = s; dst[1] = q;
 }
 
@@ -352,9 +354,11 @@ extern "C" int fyc_chan_stats_reduce(const fyc_chan_stats_reduce_args* a, void* 
   FYC_REQUIRE(a && a->parts && a->cs, "fyc_chan_stats_reduce: null pointer");
   FYC_REQUIRE(a->rows > 0 && a->N > 0 && a->cs_rows > 0 && a->rows % a->cs_rows == 0 && a->tile_rows > 0 && a->slots >= 1,
               "fyc_chan_stats_reduce: rows=%d N=%d cs_rows=%d tile_rows=%d slots=%d", a->rows, a->N, a->cs_rows, a->tile_rows, a->slots);
-  const int samples = a->rows / a->cs_rows, tiles_m = (a->rows + a->tile_rows - 1) / a->tile_rows;
-  dim3 grid((a->N + 255) / 256, samples);
-  hipLaunchKernelGGL(chan_stats_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, a->parts, a->cs, samples, a->N, tiles_m, a->tile_rows, a->slots, a->cs_rows);
+  const int out_rows = a->out_rows > 0 ? a->out_rows : a->cs_rows;
+  FYC_REQUIRE(out_rows % a->cs_rows == 0 && a->rows % out_rows == 0, "fyc_chan_stats_reduce: out_rows=%d must be a multiple of cs_rows=%d dividing rows=%d", out_rows, a->cs_rows, a->rows);
+  const int tiles_m = (a->rows + a->tile_rows - 1) / a->tile_rows;
+  dim3 grid((a->N + 255) / 256, a->rows / out_rows);
+  hipLaunchKernelGGL(chan_stats_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, a->parts, a->cs, a->N, tiles_m, a->tile_rows, a->slots, a->cs_rows, out_rows / a->cs_rows);
   FYC_CHECK_LAUNCH("fyc_chan_stats_reduce");
   return 0;
 }

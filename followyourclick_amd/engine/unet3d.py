@@ -33,7 +33,7 @@ Tensor = torch.Tensor
 # Statistics of an activation are accumulated by the epilogue of the GEMM / conv that writes it (fyc_gemm chan_stats / row_parts)
 # instead of by a read pass per GroupNorm / LayerNorm.  FYC_FUSE_STATS=0 restores the separate passes (A/B measurements).
 FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
-FUSE_ROWS = os.environ.get("FYC_FUSE_ROWS", "1") != "0"      # the LayerNorm half (row_parts) on its own
+FUSE_ROWS = os.environ.get("FYC_FUSE_ROWS", "0") != "0"      # the LayerNorm half (row_parts): measured slower than the separate fyc_row_stats pass (profiles/r02_stats_fusion_ab.txt), off by default
 
 
 class Act:
@@ -181,11 +181,12 @@ class UNet3DEngine(EngineBase):
             return None
         return torch.empty(nt * slots * N * 2, dtype=torch.float32, device=self.device), tile_rows, slots
 
-    def _cs_finish(self, plan, rows: int, rows_per_sample: int, N: int) -> Tensor:
-        """per-(frame, channel) f64 sums from the epilogue's row-tile partials"""
+    def _cs_finish(self, plan, rows: int, rows_per_sample: int, N: int, out_rows: int) -> Tensor:
+        """per-(GroupNorm sample, channel) f64 sums from the epilogue's row-tile partials; out_rows = rows of the consuming
+        norm's sample (a frame, or the F frames of a clip)"""
         parts, tile_rows, slots = plan
-        cs = torch.empty(rows // rows_per_sample, N, 2, dtype=torch.float64, device=self.device)
-        self.ops.chan_stats_reduce(parts, cs, rows=rows, N=N, cs_rows=rows_per_sample, tile_rows=tile_rows, slots=slots)
+        cs = torch.empty(rows // out_rows, N, 2, dtype=torch.float64, device=self.device)
+        self.ops.chan_stats_reduce(parts, cs, rows=rows, N=N, cs_rows=rows_per_sample, tile_rows=tile_rows, slots=slots, out_rows=out_rows)
         return cs
 
     def _gn(self, x: Union[Act, Tuple[Act, Act]], gamma: Tensor, beta: Tensor, rows: int, rows_per_sample: int, eps: float,
@@ -247,10 +248,10 @@ class UNet3DEngine(EngineBase):
         self.ops.gemm(x, self._eyes[key], y, M=rows, N=C, K=C, lda=C, ldw=C, ldo=C, residual=y, ldr=C)
 
     # ---- blocks --------------------------------------------------------------------------------
-    # `nxt` = rows per statistics sample the producing epilogue accumulates for the GroupNorm that consumes a block's output.  It
-    # is always one frame (H*W rows): per-frame norms (transformer / motion module) use the sums as they are, cross-frame norms
-    # (ResNet, conv_norm_out) add up the F frame sums in fyc_gn_apply_cs - 16x more atomic targets than per-clip sums.
-    def _conv_act(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, nxt: int, **kw) -> Act:
+    # `nxt` = (rows per statistics sample of the producing epilogue = one frame, rows per sample of the GroupNorm that consumes
+    # the block's output: one frame for the per-frame norm of a transformer / motion module, F frames for the cross-frame norm
+    # of a ResNet / conv_norm_out); fyc_chan_stats_reduce folds the row-tile partials to the consumer's granularity.
+    def _conv_act(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, nxt: Tuple[int, int], **kw) -> Act:
         Cout, K = w.shape
         if kw.get("up2"):
             Ho, Wo = kw["up_size"]
@@ -258,11 +259,11 @@ class UNet3DEngine(EngineBase):
             st = kw.get("stride", 1)
             Ho, Wo = (Hin - 1) // st + 1, (Win - 1) // st + 1
         rows = frames * Ho * Wo
-        plan = self._cs_plan(rows, nxt, Cout, K, L.GEMM_CONV3X3_UP2 if kw.get("up2") else L.GEMM_CONV3X3) if nxt else None
-        out = self.conv(x, w, b, frames, Hin, Win, chan_parts=None if plan is None else plan[0], cs_rows=nxt if plan is not None else 0, **kw)
-        return Act(out, Cout, None if plan is None else self._cs_finish(plan, rows, nxt, Cout), nxt)
+        plan = self._cs_plan(rows, nxt[0], Cout, K, L.GEMM_CONV3X3_UP2 if kw.get("up2") else L.GEMM_CONV3X3) if nxt else None
+        out = self.conv(x, w, b, frames, Hin, Win, chan_parts=None if plan is None else plan[0], cs_rows=nxt[0] if plan is not None else 0, **kw)
+        return Act(out, Cout, None if plan is None else self._cs_finish(plan, rows, nxt[0], Cout, nxt[1]), nxt[1] if nxt else 0)
 
-    def resnet(self, r: Packed, x: Union[Act, Tuple[Act, Act]], temb: Tensor, g: dict, nxt: int) -> Act:
+    def resnet(self, r: Packed, x: Union[Act, Tuple[Act, Act]], temb: Tensor, g: dict, nxt: Tuple[int, int]) -> Act:
         """ResnetBlock3D (reference resnet.py:296-342): cross-frame GroupNorm statistics.  x may be the (hidden, skip) pair of an
         up block: the concat only ever exists normalised (norm1's output); the 1x1 shortcut reads both sources (dual-K GEMM)."""
         rows, rpb = g["rows"], g["F"] * g["H"] * g["W"]
@@ -270,7 +271,7 @@ class UNet3DEngine(EngineBase):
         h, cat = self._gn(x, r.n1_g, r.n1_b, rows, rpb, self.cfg.norm_eps, True)
         tb = temb[:, r.temb_off:]  # view: row pitch stays temb_total (ldrb)
         # time-embedding row per clip, or per (clip, frame) when frame 0 carries the timestep-0 embedding (use_first_frame_condition)
-        h1 = self._conv_act(h, r.c1_w, r.c1_b, frames, g["H"], g["W"], g["H"] * g["W"], rowbias=tb,
+        h1 = self._conv_act(h, r.c1_w, r.c1_b, frames, g["H"], g["W"], (g["H"] * g["W"], rpb), rowbias=tb,
                             rpb=g["H"] * g["W"] if g.get("temb_per_frame") else rpb, ldrb=temb.shape[1])
         h2, _ = self._gn(h1, r.n2_g, r.n2_b, rows, rpb, self.cfg.norm_eps, True)
         if r.sc_w is None:
@@ -284,7 +285,7 @@ class UNet3DEngine(EngineBase):
                           a2=b.t, k_split=a.C, lda2=b.C)
         return self._conv_act(h2, r.c2_w, r.c2_b, frames, g["H"], g["W"], nxt, residual=sc)
 
-    def feed_forward_out(self, ff: Packed, ln, tok: Act, residual: Optional[Tensor], rows: int, C: int, nxt: int = 0) -> Act:
+    def feed_forward_out(self, ff: Packed, ln, tok: Act, residual: Optional[Tensor], rows: int, C: int, nxt=None) -> Act:
         """LN -> GEGLU FF -> (+tok) -> output projection (+residual) with FF2 and the projection merged into one GEMM
         over [tok | h] (see weights._ff): returns residual + Wp (tok + W2 h + b2) + bp."""
         if ff.cs1 is not None:      # LayerNorm folded into FF1: statistics from the producer of tok (or one statistics pass)
@@ -297,17 +298,17 @@ class UNet3DEngine(EngineBase):
             hmid = self.lin(n, ff.w1, rows, bias=ff.b1, geglu=True)
         out = self.new(rows, C)
         K = ff.po_w.shape[1]
-        plan = self._cs_plan(rows, nxt, C, K, L.GEMM_PLAIN) if nxt else None
+        plan = self._cs_plan(rows, nxt[0], C, K, L.GEMM_PLAIN) if nxt else None
         rp, rp_n = None, 0
         if residual is None and self.fuse_rows:      # inner motion blocks: the output is the next block's token stream (LayerNorm input)
             rp_n = self.ops.gemm_row_parts(tok.t.dtype, M=rows, N=C, K=K)
             rp = torch.empty(rows, rp_n, 2, dtype=torch.float32, device=self.device)
         self.ops.gemm(tok.t, ff.po_w, out, M=rows, N=C, K=K, lda=C, ldw=K, ldo=C, bias=ff.po_b, residual=residual, ldr=C,
-                      a2=hmid, k_split=C, lda2=K - C, chan_parts=None if plan is None else plan[0], cs_rows=nxt if plan is not None else 0,
+                      a2=hmid, k_split=C, lda2=K - C, chan_parts=None if plan is None else plan[0], cs_rows=nxt[0] if plan is not None else 0,
                       row_parts=rp, row_nparts=rp_n)
-        return Act(out, C, None if plan is None else self._cs_finish(plan, rows, nxt, C), nxt, rp, rp_n)
+        return Act(out, C, None if plan is None else self._cs_finish(plan, rows, nxt[0], C, nxt[1]), nxt[1] if nxt else 0, rp, rp_n)
 
-    def transformer(self, t: Packed, x: Act, g: dict, nxt: int) -> Act:
+    def transformer(self, t: Packed, x: Act, g: dict, nxt: Tuple[int, int]) -> Act:
         """Transformer3DModel + BasicTransformerBlock (reference attention.py:217-308, 489-564)."""
         rows, C, H, o = g["rows"], t.C, self.heads, self.ops
         BF, N = g["B"] * g["F"], g["H"] * g["W"]
@@ -349,7 +350,7 @@ class UNet3DEngine(EngineBase):
         tok = self._lin_rp(att2, t.o2_w, rows, bias=t.o2_b, residual=tok.t)
         return self.feed_forward_out(t.ff, t.ln3, tok, x.t, rows, C, nxt)
 
-    def motion(self, m: Packed, x: Act, g: dict, nxt: int) -> Act:
+    def motion(self, m: Packed, x: Act, g: dict, nxt: Tuple[int, int]) -> Act:
         """VanillaTemporalModule (reference motion_module.py:157-208, 270-283, 371-464)."""
         rows, C, o = g["rows"], m.C, self.ops
         N, Hm = g["H"] * g["W"], self.cfg.motion_num_attention_heads
@@ -371,7 +372,7 @@ class UNet3DEngine(EngineBase):
                 o.temporal_attention(qkv, att, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5)
                 tok = self._lin_rp(att, a.o_w, rows, bias=a.o_b, residual=tok.t)
             last = bi == len(m.blocks) - 1
-            tok = self.feed_forward_out(blk.ff, blk.ff_ln, tok, x.t if last else None, rows, C, nxt if last else 0)   # inner blocks: identity projection
+            tok = self.feed_forward_out(blk.ff, blk.ff_ln, tok, x.t if last else None, rows, C, nxt if last else None)   # inner blocks: identity projection
         return tok
 
     # ---- forward -------------------------------------------------------------------------------
@@ -394,16 +395,22 @@ class UNet3DEngine(EngineBase):
         def hw(gg):         # rows of one frame = one statistics sample of every producer
             return gg["H"] * gg["W"]
 
+        def frame(gg):      # the consumer is a per-frame GroupNorm (transformer / motion module)
+            return hw(gg), hw(gg)
+
+        def clip(gg):       # the consumer is a cross-frame GroupNorm (ResNet norm1 / conv_norm_out)
+            return hw(gg), F * hw(gg)
+
         def layer(l, xin, gg):
-            """resnet [-> transformer] [-> motion module]"""
-            y = self.resnet(l.resnet, xin, temb, gg, hw(gg))
+            """resnet [-> transformer] [-> motion module]; each stage tells its producer which norm consumes its output"""
+            y = self.resnet(l.resnet, xin, temb, gg, frame(gg) if (l.attn is not None or l.motion is not None) else clip(gg))
             if l.attn is not None:
-                y = self.transformer(l.attn, y, gg, hw(gg))
+                y = self.transformer(l.attn, y, gg, frame(gg) if l.motion is not None else clip(gg))
             if l.motion is not None:
-                y = self.motion(l.motion, y, gg, hw(gg))
+                y = self.motion(l.motion, y, gg, clip(gg))
             return y
 
-        x = self._conv_act(x, P.conv_in_w, P.conv_in_b, frames, H, W, hw(g))
+        x = self._conv_act(x, P.conv_in_w, P.conv_in_b, frames, H, W, clip(g))
         skips = [x]
         sizes = [(H, W)]                       # spatial size per resolution level (odd sizes: ceil-halving on the way down)
         for blk in P.down:
@@ -413,15 +420,15 @@ class UNet3DEngine(EngineBase):
             if blk.down is not None:
                 g2 = dict(g, H=(g["H"] - 1) // 2 + 1, W=(g["W"] - 1) // 2 + 1)
                 g2["rows"] = B * F * g2["H"] * g2["W"]
-                x = self._conv_act(x.t, blk.down.w, blk.down.b, frames, g["H"], g["W"], hw(g2), stride=2)
+                x = self._conv_act(x.t, blk.down.w, blk.down.b, frames, g["H"], g["W"], clip(g2), stride=2)
                 g = g2
                 sizes.append((g["H"], g["W"]))
                 skips.append(x)
-        x = self.resnet(P.mid.r0, x, temb, g, hw(g))
-        x = self.transformer(P.mid.attn, x, g, hw(g))
+        x = self.resnet(P.mid.r0, x, temb, g, frame(g))
+        x = self.transformer(P.mid.attn, x, g, frame(g) if P.mid.motion is not None else clip(g))
         if P.mid.motion is not None:
-            x = self.motion(P.mid.motion, x, g, hw(g))
-        x = self.resnet(P.mid.r1, x, temb, g, hw(g))
+            x = self.motion(P.mid.motion, x, g, clip(g))
+        x = self.resnet(P.mid.r1, x, temb, g, clip(g))
         for blk in P.up:
             for l in blk.layers:
                 x = layer(l, (x, skips.pop()), g)      # cat([hidden, skip], dim=1) folded into norm1 / the shortcut
@@ -432,7 +439,7 @@ class UNet3DEngine(EngineBase):
                 Hn, Wn = sizes[-1]
                 g2 = dict(g, H=Hn, W=Wn)
                 g2["rows"] = B * F * Hn * Wn
-                x = self._conv_act(x.t, blk.up.w, blk.up.b, frames, g["H"], g["W"], hw(g2), up2=True, up_size=(Hn, Wn))
+                x = self._conv_act(x.t, blk.up.w, blk.up.b, frames, g["H"], g["W"], clip(g2), up2=True, up_size=(Hn, Wn))
                 g = g2
         h, _ = self._gn(x, P.out_g, P.out_b, g["rows"], F * hw(g), cfg.norm_eps, True)
         return self.conv(h, P.conv_out_w, P.conv_out_b, frames, g["H"], g["W"])

@@ -114,11 +114,13 @@ class HipOps:
         n = int(self.lib.fyc_gemm_stat_layout(C.byref(g), C.byref(tr), C.byref(sl)))
         return n, int(tr.value), int(sl.value)
 
-    def chan_stats_reduce(self, parts: Tensor, cs: Tensor, *, rows: int, N: int, cs_rows: int, tile_rows: int, slots: int) -> None:
+    def chan_stats_reduce(self, parts: Tensor, cs: Tensor, *, rows: int, N: int, cs_rows: int, tile_rows: int, slots: int,
+                          out_rows: int = 0) -> None:
         if cs.dtype != torch.float64:
             raise TypeError("channel statistics must be float64")
         a = L.ChanStatsReduceArgs()
         a.parts, a.cs, a.rows, a.N, a.cs_rows, a.tile_rows, a.slots = _f32(parts, "parts"), _p(cs), rows, N, cs_rows, tile_rows, slots
+        a.out_rows = out_rows
         self._call("fyc_chan_stats_reduce", a)
 
     @staticmethod

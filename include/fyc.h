@@ -113,9 +113,11 @@ int fyc_gemm_row_parts(const fyc_gemm_args* a);
  * *slots = sample slots per tile; chan_parts holds row_tiles * slots * N * 2 floats */
 int fyc_gemm_stat_layout(const fyc_gemm_args* a, int32_t* tile_rows, int32_t* slots);
 
-/* cs[f][n] = {sum, sum of squares} over the rows of sample f (cs_rows rows each) of channel n, in f64, from the row-tile partials
- * a fyc_gemm epilogue wrote (chan_parts; tile_rows / slots from fyc_gemm_stat_layout).  cs: [rows / cs_rows][N][2] doubles. */
-typedef struct { const float* parts; double* cs; int32_t rows, N, cs_rows, tile_rows, slots; } fyc_chan_stats_reduce_args;
+/* cs[o][n] = {sum, sum of squares} over the rows of output sample o (out_rows rows each, a multiple of cs_rows; 0 = cs_rows) of
+ * channel n, in f64, from the row-tile partials a fyc_gemm epilogue wrote with cs_rows rows per statistics sample (chan_parts;
+ * tile_rows / slots from fyc_gemm_stat_layout).  out_rows = H*W for a per-frame GroupNorm, F*H*W for a cross-frame one.
+ * cs: [rows / out_rows][N][2] doubles. */
+typedef struct { const float* parts; double* cs; int32_t rows, N, cs_rows, tile_rows, slots, out_rows; } fyc_chan_stats_reduce_args;
 int fyc_chan_stats_reduce(const fyc_chan_stats_reduce_args* a, void* stream);
 
 /* ---- fused flash attention (bf16 MFMA, online softmax) ----------------------------------

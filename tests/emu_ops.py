@@ -143,7 +143,7 @@ class EmuOps:
         tr = 96
         return (M + tr - 1) // tr, tr, (tr - 1) // cs_rows + 2
 
-    def chan_stats_reduce(self, parts, cs, *, rows, N, cs_rows, tile_rows, slots):
+    def chan_stats_reduce(self, parts, cs, *, rows, N, cs_rows, tile_rows, slots, out_rows=0):
         nt = (rows + tile_rows - 1) // tile_rows
         p = _flat(parts)[: nt * slots * N * 2].reshape(nt, slots, N, 2).double()
         out = torch.zeros(rows // cs_rows, N, 2, dtype=torch.float64)
@@ -152,6 +152,8 @@ class EmuOps:
             for sl in range(slots):
                 if first + sl < out.shape[0]:
                     out[first + sl] += p[t, sl]
+        grp = (out_rows or cs_rows) // cs_rows
+        out = out.reshape(out.shape[0] // grp, grp, N, 2).sum(dim=1)
         _flat(cs)[: out.numel()].reshape(out.shape).copy_(out)
 
     def gemm_row_parts(self, dtype, *, M, N, K, mode=PLAIN, batch=1, tile=0):
