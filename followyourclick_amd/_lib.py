@@ -151,11 +151,15 @@ def load() -> C.CDLL:
     lib.fyc_init.argtypes = [vp]
     lib.fyc_device_caps.argtypes = [C.POINTER(i64)]
     lib.fyc_set_tuning.argtypes = [C.c_int, C.c_int]
-    lib.fyc_gemm_row_parts.argtypes = [C.POINTER(GemmArgs)]
-    lib.fyc_gemm_row_parts.restype = C.c_int
-    lib.fyc_gemm_stat_layout.argtypes = [C.POINTER(GemmArgs), C.POINTER(i32), C.POINTER(i32)]
-    lib.fyc_gemm_stat_layout.restype = C.c_int
+    ab_build = bool(os.environ.get("FYC_LIB_PATH"))      # an older library for A/B timing (tools/): newer entry points may be absent
+    if not ab_build or hasattr(lib, "fyc_gemm_row_parts"):
+        lib.fyc_gemm_row_parts.argtypes = [C.POINTER(GemmArgs)]
+        lib.fyc_gemm_row_parts.restype = C.c_int
+        lib.fyc_gemm_stat_layout.argtypes = [C.POINTER(GemmArgs), C.POINTER(i32), C.POINTER(i32)]
+        lib.fyc_gemm_stat_layout.restype = C.c_int
     for name, st in OPS.items():
+        if ab_build and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(st), vp]
         fn.restype = C.c_int

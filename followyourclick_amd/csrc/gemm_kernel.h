@@ -52,6 +52,7 @@ struct GemmP {
   int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
   int colc;   // bias / colsum / tile-uniform rowbias may be fetched 16 B at a time and staged through LDS once per tile
   int rb_tile; // rowbias row is the same for every row of a tile (rows_per_batch % BM == 0): folded into the staged bias
+  int stagger; // 8-wave tiles: the upper half of the waves issues its DMAs between its two MFMA k-steps (fyc_set_tuning key 5 = 1: off)
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
 };
@@ -586,6 +587,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   constexpr int LOADS = A_IT + B_IT;       // DMA instructions per thread per K tile
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
   constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB;
+  constexpr bool STAGGER = (WGM * WGN == 8) && KSTEPS >= 2 && NS == 2;
   static_assert(A_IT * NT == BM * CPR && B_IT * NT == BN * CPR, "tile/threads mismatch");
   static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LOADS < 64, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -697,11 +699,12 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 
   const int g = lane >> 4, r16 = lane & 15;
   const int sw = swz_key<RB>(r16);   // all fragment rows are r16 + multiples of 16: same key
-  auto compute = [&](int stage) {
+  auto compute = [&](int stage, int s0, int s1) {     // MFMA k-steps [s0, s1) of one staged K tile
     const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * RB;
     const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * RB;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
+      if (s < s0 || s >= s1) continue;
       const int coff = ((4 * s + g) ^ sw) * 16;
       Frag af[WTM], bf[WTN];
 #pragma unroll
@@ -764,8 +767,17 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       --n_ahead;
-      if (i_tile < ntiles) issue_next();
-      compute(st_c);
+      // Role stagger (8-wave workgroups, waves w and w+4 share a SIMD): the ~130-instruction address + DMA issue block of a K
+      // tile keeps the matrix pipe idle when both waves of a SIMD run it at the same time right behind the barrier.  The
+      // second half of the waves therefore runs its first MFMA k-step FIRST and issues in the middle: on every SIMD one wave's
+      // issue block sits beside its partner's MFMAs.  (Safe with the 2-deep ring: the stage being refilled was consumed by
+      // every wave before this barrier, and the late DMAs still have a k-step of both waves to land.)
+      // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
+      const bool late = STAGGER && p.stagger && wave >= (WGM * WGN) / 2;
+      if (!late && i_tile < ntiles) issue_next();
+      compute(st_c, 0, 1);
+      if (late && i_tile < ntiles) issue_next();
+      compute(st_c, 1, KSTEPS);
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     }
     const int t = remap(tile);
@@ -804,6 +816,7 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
+  q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
   q.strip = (q.tiles_n > 4 && g_fyc_tuning[4] >= 0) ? (g_fyc_tuning[4] > 0 ? g_fyc_tuning[4] : (q.tiles_n >= 16 ? 8 : 4)) : 0;   // measured: profiles/r01_gemm_strip_order.txt
   // persistent grid: as many blocks as stay resident (LDS-limited), each walks a strided tile list
   int occ = (160 * 1024) / smem;

@@ -109,25 +109,37 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---- per-(sample, channel) sums from the row-tile partials of the producing GEMM (fyc_gemm chan_parts) ----------------------
-// thread = (sample, channel): adds the {sum, sum sq} of every row tile that overlaps the sample.  Tiny (<= a few MB read).
+// block = 32 channels x 8 lanes of one output sample: the lanes stride over the row tiles that overlap the sample (up to 256
+// for a cross-frame norm at 64x64), then fold through LDS.  Tiny (<= a few MB read) but latency-bound: keep it parallel.
 __global__ void __launch_bounds__(256) chan_stats_reduce_kernel(const float* __restrict__ parts, double* __restrict__ cs, int N,
-                                                              int tiles_m, int tile_rows, int slots, int cs_rows, int group) {
-  const int n = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;      // output sample o = `group` consecutive statistics samples
-  if (n >= N) return;
+                                                              int tiles_m, int tile_rows, int slots, int cs_rows, int group, int nsamp) {
+  __shared__ double red[2][8][32];
+  const int c = threadIdx.x & 31, ln = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c, o = blockIdx.y;      // output sample o = `group` consecutive statistics samples
+  const long long row0 = (long long)o * group * cs_rows, row1 = row0 + (long long)group * cs_rows;
+  const int t0 = (int)(row0 / tile_rows);
+  int t1 = (int)((row1 - 1) / tile_rows);
+  if (t1 >= tiles_m) t1 = tiles_m - 1;
   double s = 0.0, q = 0.0;
-  for (int f = o * group; f < (o + 1) * group; ++f) {
-    const int t0 = (int)(((long long)f * cs_rows) / tile_rows);
-    int t1 = (int)((((long long)f + 1) * cs_rows - 1) / tile_rows);
-    if (t1 >= tiles_m) t1 = tiles_m - 1;
-    for (int t = t0; t <= t1; ++t) {
-      const int slot = f - (int)(((long long)t * tile_rows) / cs_rows);
-      if (slot < 0 || slot >= slots) continue;
-      const float2 v = *reinterpret_cast<const float2*>(parts + (((long long)t * slots + slot) * N + n) * 2);
-      s += (double)v.x; q += (double)v.y;
+  if (n < N) {
+    for (int t = t0 + ln; t <= t1; t += 8) {
+      const int first = (int)(((long long)t * tile_rows) / cs_rows);
+      for (int sl = 0; sl < slots; ++sl) {
+        const int f = first + sl;
+        if (f < o * group || f >= (o + 1) * group || f >= nsamp) continue;
+        const float2 v = *reinterpret_cast<const float2*>(parts + (((long long)t * slots + sl) * N + n) * 2);
+        s += (double)v.x; q += (double)v.y;
+      }
     }
   }
-  double* dst = cs + ((long long)o * N + n) * 2;
-  dst[0] = s; dst[1] = q;
+  red[0][ln][c] = s; red[1][ln][c] = q;
+  __syncthreads();
+  if (ln == 0 && n < N) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { s += red[0][i][c]; q += red[1][i][c]; }
+    double* dst = cs + ((long long)o * N + n) * 2;
+    dst[0] = s; dst[1] = q;
+  }
 }
 
 // ---- GroupNorm apply from per-(sample, channel) sums (+SiLU), optional channel concat of two sources ---------------------
@@ -357,8 +369,9 @@ extern "C" int fyc_chan_stats_reduce(const fyc_chan_stats_reduce_args* a, void* 
   const int out_rows = a->out_rows > 0 ? a->out_rows : a->cs_rows;
   FYC_REQUIRE(out_rows % a->cs_rows == 0 && a->rows % out_rows == 0, "fyc_chan_stats_reduce: out_rows=%d must be a multiple of cs_rows=%d dividing rows=%d", out_rows, a->cs_rows, a->rows);
   const int tiles_m = (a->rows + a->tile_rows - 1) / a->tile_rows;
-  dim3 grid((a->N + 255) / 256, a->rows / out_rows);
-  hipLaunchKernelGGL(chan_stats_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, a->parts, a->cs, a->N, tiles_m, a->tile_rows, a->slots, a->cs_rows, out_rows / a->cs_rows);
+  dim3 grid((a->N + 31) / 32, a->rows / out_rows);
+  hipLaunchKernelGGL(chan_stats_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, a->parts, a->cs, a->N, tiles_m, a->tile_rows, a->slots, a->cs_rows,
+                     out_rows / a->cs_rows, a->rows / a->cs_rows);
   FYC_CHECK_LAUNCH("fyc_chan_stats_reduce");
   return 0;
 }
