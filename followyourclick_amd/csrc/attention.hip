@@ -18,13 +18,13 @@ extern "C" int fyc_attention(const fyc_attn_args* a, void* stream) {
   p.sl2e = a->scale * 1.44269504088896340736f; p.o_scale = a->o_scale;
   p.nqb = 0; p.zero = (const char*)g_fyc_zero_page;
   hipStream_t st = (hipStream_t)stream;
-  // 64 queries per wave (QT=4) amortises the K / V^T fragment reads over twice the MFMAs; it needs n_q large
-  // enough to still fill the chip.  tuning key 3 forces QT (A/B measurements).
-  const long long wg4 = (long long)a->batch * a->heads * ((a->n_q + 255) / 256);
-  bool qt4 = a->n_q >= 1024 && wg4 >= 512 && a->d <= 80;
-  if (g_fyc_tuning[3] == 2) qt4 = false;
-  if (g_fyc_tuning[3] == 4 && a->d <= 80) qt4 = true;
-  if (a->d <= 48) return fyca::run_small(p, qt4, st);
-  if (a->d <= 96) return fyca::run_medium(p, qt4, st);
+  // Queries per wave = 16 * QT.  More queries amortise the K / V^T fragment reads over more MFMAs but cost registers: at d = 40
+  // QT = 4 needs 170 VGPRs (2 waves / SIMD), QT = 3 needs 140 (3 waves / SIMD).  Large problems take QT = 3 (measured,
+  // profiles/r02_attention_variants.txt); small ones QT = 2 so that the grid still fills the chip.  tuning key 3 forces QT.
+  const long long wg3 = (long long)a->batch * a->heads * ((a->n_q + 191) / 192);
+  int qt = (a->n_q >= 1024 && wg3 >= 512 && a->d <= 80) ? 3 : 2;
+  if (g_fyc_tuning[3] >= 2 && g_fyc_tuning[3] <= 4 && (a->d <= 80 || g_fyc_tuning[3] == 2)) qt = g_fyc_tuning[3];
+  if (a->d <= 48) return fyca::run_small(p, qt, st);
+  if (a->d <= 96) return fyca::run_medium(p, qt, st);
   return fyca::run_large(p, st);
 }

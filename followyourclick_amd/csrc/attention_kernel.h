@@ -106,7 +106,83 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
   const int ntiles = (p.n_k + KB - 1) / KB;
   const int dchunks = p.d >> 3;
 
-  auto issue = [&](int tile, int stage) {
+  // ---- K / V^T tile loaders.  What a lane fetches is the same in every tile except for a wave-uniform base: lanes that carry
+  // data keep a 32-bit byte offset (global_load_lds with an SGPR base), lanes that carry constants (head-dim padding, the ones
+  // column / row, rows beyond the tile) are written ONCE per ring stage by `issue_const` and masked off afterwards - the
+  // per-tile issue block is 4 DMAs + their exec masks instead of ~100 VALU compares / selects / 64-bit adds.  Only a ragged
+  // last tile takes the general, fully predicated path (`issue_general`).
+  // Per-thread byte offsets of the data lanes (0xffffffff = this lane carries a constant).  With <= 4 DMA instructions per
+  // tile they live in LDS behind the ring (one ds_read_b128 per tile) instead of in 4 VGPRs + masks: at 64 queries per wave
+  // and d = 40 the kernel sits exactly at the 168-register limit of 3 waves per SIMD.
+  constexpr bool OFFS_IN_LDS = (K_IT + V_IT) <= 4;
+  constexpr unsigned NODATA = 0xffffffffu;
+  unsigned k_off[K_IT], v_off[V_IT];
+  int my_loads = 0;            // DMA instructions this WAVE issues per full tile (instructions with no data lane are skipped)
+#pragma unroll
+  for (int it = 0; it < K_IT; ++it) {
+    const int L = it * 256 + tid, row = L / PC, cc = L - row * PC;
+    const int c = KXOR ? (cc ^ (row & 7)) : cc;
+    k_off[it] = (row < KB && c < dchunks) ? (unsigned)(row * p.d + c * 8) * 2u : NODATA;
+    my_loads += __builtin_amdgcn_ballot_w64(k_off[it] != NODATA) != 0 ? 1 : 0;
+  }
+#pragma unroll
+  for (int it = 0; it < V_IT; ++it) {
+    const int L = it * 256 + tid, row = L >> 3, cc = L & 7;
+    const int c = cc ^ (row & 7);
+    v_off[it] = (row < p.d) ? (unsigned)(row * p.ldvt + c * 8) * 2u : NODATA;
+    my_loads += __builtin_amdgcn_ballot_w64(v_off[it] != NODATA) != 0 ? 1 : 0;
+  }
+  my_loads = __builtin_amdgcn_readfirstlane(my_loads);
+  char* const offs_lds = smem + NS * STAGE + tid * 16;
+  if (OFFS_IN_LDS) {
+    u32x4 o4 = {NODATA, NODATA, NODATA, NODATA};
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it) o4[it] = k_off[it];
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) o4[K_IT + it] = v_off[it];
+    *reinterpret_cast<u32x4*>(offs_lds) = o4;      // only this thread reads it back: no barrier needed
+  }
+  auto issue_const = [&](int stage) {
+    char* sK = smem + stage * STAGE;
+    char* sV = sK + K_BYTES;
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it) {
+      const int L = it * 256 + tid, row = L / PC, cc = L - row * PC;
+      const int c = KXOR ? (cc ^ (row & 7)) : cc;
+      if (k_off[it] == NODATA) glds16((MSUB && row < KB && c == dchunks) ? (const void*)(fyc_ones + 64) : (const void*)zero, sK + (it * 256 + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) {
+      const int row = (it * 256 + tid) >> 3;
+      if (v_off[it] == NODATA) glds16(row == p.d ? (const void*)fyc_ones : (const void*)zero, sV + (it * 256 + wave * 64) * 16);
+    }
+  };
+  auto issue_full = [&](int tile, int stage) {          // all KB keys of the tile exist
+    char* sK = smem + stage * STAGE;
+    char* sV = sK + K_BYTES;
+    const char* kb = reinterpret_cast<const char*>(K) + (long long)tile * (KB * 2) * p.d;
+    const char* vb = reinterpret_cast<const char*>(VT) + (long long)tile * (KB * 2);
+    unsigned ko[K_IT], vo[V_IT];
+    if (OFFS_IN_LDS) {
+      const u32x4 o4 = *reinterpret_cast<const u32x4*>(offs_lds);
+#pragma unroll
+      for (int it = 0; it < K_IT; ++it) ko[it] = o4[it];
+#pragma unroll
+      for (int it = 0; it < V_IT; ++it) vo[it] = o4[K_IT + it];
+    } else {
+#pragma unroll
+      for (int it = 0; it < K_IT; ++it) ko[it] = k_off[it];
+#pragma unroll
+      for (int it = 0; it < V_IT; ++it) vo[it] = v_off[it];
+    }
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it)
+      if (ko[it] != NODATA) glds16(kb + ko[it], sK + (it * 256 + wave * 64) * 16);
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it)
+      if (vo[it] != NODATA) glds16(vb + vo[it], sV + (it * 256 + wave * 64) * 16);
+  };
+  auto issue_general = [&](int tile, int stage) {       // ragged last tile: every lane predicated, every lane issues
     char* sK = smem + stage * STAGE;
     char* sV = sK + K_BYTES;
     const int key0 = tile * KB;
@@ -132,6 +208,21 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
       glds16(src, sV + (it * 256 + wave * 64) * 16);
     }
   };
+  const int nfull = p.n_k / KB;                          // tiles 0 .. nfull-1 are full
+  auto issue = [&](int tile, int stage) { if (tile < nfull) issue_full(tile, stage); else issue_general(tile, stage); };
+  // DMA instructions of tile t still allowed in flight when tile t-1 is awaited
+  auto loads_of = [&](int tile) { return tile < nfull ? my_loads : LOADS; };
+  auto wait_dyn = [&](int n) {
+    switch (n) {
+      case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;   case 3: wait_vmcnt<3>(); break;
+      case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;   case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;
+      case 8: wait_vmcnt<8>(); break;   case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+      default: wait_vmcnt<12>(); break;
+    }
+  };
+  static_assert(LOADS <= 12, "wait_dyn covers up to 12 DMA instructions per tile");
+#pragma unroll
+  for (int st = 0; st < NS; ++st) issue_const(st);
   issue(0, 0);
   if (ntiles > 1) issue(1, 1);
 
@@ -189,7 +280,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
 
   int st_c = 0, st_i = (ntiles > 1) ? 2 : 1;
   for (int tile = 0; tile < ntiles; ++tile) {
-    if (tile + 1 < ntiles) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+    wait_dyn(tile + 1 < ntiles ? loads_of(tile + 1) : 0);      // tile landed; the next one may stay in flight
     __builtin_amdgcn_s_barrier();
     if (tile + 2 < ntiles) { issue(tile + 2, st_i); st_i = (st_i + 1 == NS) ? 0 : st_i + 1; }
     const char* sK = smem + st_c * STAGE;
@@ -239,7 +330,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
           for (int ks = 0; ks < KS; ++ks) s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[qt][ks], s[t][qt], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       // ---- online softmax; lane holds keys kb*32 + 8g + 4t + r of query r16.  MSUB: s already is score - m_run.
-      float mx[QT];
+      float mx[QT];        // this LANE's maximum over its 8 keys (the other three quads of the query column hold the other 24)
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         if (tail) {
@@ -251,8 +342,10 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
         }
         const float m0 = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), s[0][qt][2]);
         const float m1 = fmaxf(fmaxf(s[0][qt][3], s[1][qt][0]), s[1][qt][1]);
-        mx[qt] = quad_max(fmaxf(fmaxf(m0, m1), fmaxf(s[1][qt][2], s[1][qt][3])));
+        mx[qt] = fmaxf(fmaxf(m0, m1), fmaxf(s[1][qt][2], s[1][qt][3]));
       }
+      // does ANY lane of the wave see a score above its running max + THR?  (the per-lane maxima suffice for the decision;
+      // the cross-quad reduction that makes the four quads of a query column agree on the new max runs on the rare path only)
       bool move = !started;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) move = move || (MSUB ? mx[qt] > RESCALE_THR : mx[qt] > m_run[qt] + RESCALE_THR);
@@ -260,6 +353,8 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) shift[qt] = MSUB ? 0.f : m_run[qt];
       if (__builtin_amdgcn_ballot_w64(move) != 0) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mx[qt] = quad_max(mx[qt]);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
           const bool mv = !started || (MSUB ? mx[qt] > RESCALE_THR : mx[qt] > m_run[qt] + RESCALE_THR);
@@ -353,7 +448,7 @@ int launch_attn(const AttnP& p0, hipStream_t st) {
   constexpr int PC = (DC == 8) ? 8 : DC + 1;
   constexpr int K_BYTES = ((64 * PC + 255) / 256) * 256 * 16;
   constexpr int V_BYTES = ((DVT * 16 * 8 + 255) / 256) * 256 * 16;
-  constexpr int smem = 3 * (K_BYTES + V_BYTES);
+  constexpr int smem = 3 * (K_BYTES + V_BYTES) + 256 * 16;      // ring + per-thread loader offsets
   static_assert(smem <= 160 * 1024, "LDS budget");
   auto kern = fyc_attn_kernel<DP16, DVT, QT>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);   // per call: cheap, and correct on every device
@@ -366,8 +461,8 @@ int launch_attn(const AttnP& p0, hipStream_t st) {
 }
 
 // one translation unit per group of head dims keeps the build parallel
-int run_small(const AttnP& p, bool qt4, hipStream_t st);    // d <= 48
-int run_medium(const AttnP& p, bool qt4, hipStream_t st);   // 48 < d <= 96
+int run_small(const AttnP& p, int qt, hipStream_t st);     // d <= 48; qt = 16-query tiles per wave (2, 3, 4)
+int run_medium(const AttnP& p, int qt, hipStream_t st);    // 48 < d <= 96
 int run_large(const AttnP& p, hipStream_t st);              // 96 < d <= 160
 
 // d -> (DP16, DVT) = (ceil(d/16), d/16 + 1), d a multiple of 8

@@ -11,7 +11,9 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // LDS ring, not the MFMA rate, bounds this kernel, so the widest tile that still fills the chip wins.
   ns = 2;
   if (p.N % 320 == 0) {
-    if (p.M >= 16384) cfg = (p.N == 320 && p.K <= 320 && p.mode == FYC_GEMM_PLAIN) ? 6 : 5;   // one column tile, 5 K tiles: epilogue-bound, two row tiles per 256 rows overlap better
+    // N = 320, K <= 320 (one column tile, 5 K tiles, HBM-bound with its residual): two independent 4-wave blocks per CU (config 8,
+    // 64-byte K tiles) overlap one block's epilogue with the other's loads - 432 vs 372 (6) / 348 (5) TFLOP/s, profiles/r02_gemm_sweep_stagger.txt
+    if (p.M >= 16384) cfg = (p.N == 320 && p.K <= 320 && p.mode == FYC_GEMM_PLAIN) ? 8 : 5;
     else if (p.M >= 4096) cfg = (p.N >= 5120) ? 5 : 6;
     else cfg = 2;
   } else if (p.N % 256 == 0 && p.M >= 16384) {
@@ -39,19 +41,23 @@ int stat_slots(int bm, int cs_rows) {
   if (bm % cs_rows == 0) return bm / cs_rows;
   return (bm - 1) / cs_rows + 2;
 }
-void pick(const fyc_gemm_args* a, int& cfg, int& ns) {
+// `stats`: the epilogue also writes output statistics - not built for the 64-byte K-tile configs (their ring stage is too small
+// for the accumulators), which fall back to the 128-byte ones
+void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
   if (a->dtype == FYC_F32) { cfg = (a->N % 128 == 0) ? 1 : 2; ns = 2; return; }
   GemmP q;
   memset(&q, 0, sizeof(q));
   q.M = a->M; q.N = a->N; q.K = a->K; q.mode = a->mode;
   choose(q, a->batch > 0 ? a->batch : 1, a->tile, cfg, ns);
+  if (stats && cfg == 8) cfg = 6;
+  if (stats && cfg == 10) cfg = 1;
 }
 }  // namespace
 
 extern "C" int fyc_gemm_row_parts(const fyc_gemm_args* a) {
   if (a == nullptr || a->N <= 0) return 0;
   int cfg = 1, ns = 2;
-  pick(a, cfg, ns);
+  pick(a, cfg, ns, true);
   const int bn = tile_bn(cfg);
   return (a->N + bn - 1) / bn;
 }
@@ -59,7 +65,7 @@ extern "C" int fyc_gemm_row_parts(const fyc_gemm_args* a) {
 extern "C" int fyc_gemm_stat_layout(const fyc_gemm_args* a, int32_t* tile_rows, int32_t* slots) {
   if (a == nullptr || a->M <= 0 || a->cs_rows <= 0) return 0;
   int cfg = 1, ns = 2;
-  pick(a, cfg, ns);
+  pick(a, cfg, ns, true);
   const int bm = tile_bm(cfg);
   if (tile_rows) *tile_rows = bm;
   if (slots) *slots = stat_slots(bm, a->cs_rows);
@@ -175,8 +181,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   p.rb_tile = 0;
   hipStream_t st = (hipStream_t)stream;
   int cfg = 1, ns = 2;
-  pick(a, cfg, ns);
-  FYC_REQUIRE((a->chan_parts == nullptr && a->row_parts == nullptr) || (cfg != 8 && cfg != 10), "fyc_gemm: output statistics are not built for the 64-byte K-tile configs");
+  pick(a, cfg, ns, a->chan_parts != nullptr || a->row_parts != nullptr);
   FYC_REQUIRE(a->chan_parts == nullptr || a->dtype == FYC_F32 || p.wide || cfg == 1 || cfg == 2, "fyc_gemm: chan_parts in bf16 needs the 16-byte aligned layout or tile config 1 / 2");
   FYC_REQUIRE(a->row_parts == nullptr || a->dtype == FYC_F32 || p.wide, "fyc_gemm: row_parts in bf16 needs the 16-byte aligned layout (N, ldo, ldr multiples of 8; aligned pointers)");
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, cfg, st);

@@ -226,7 +226,7 @@ def test_attention_every_head_dim(hip, emu, d):
     vt = torch.zeros(B * H, d, ldvt, dtype=T)
     vt[..., :nk] = rnd((B * H, d, nk), T, 13)
     kw = dict(batch=B, heads=H, n_q=nq, n_k=nk, d=d, ldo=H * d, ldvt=ldvt, scale=d ** -0.5)
-    for qt in (2, 4):
+    for qt in (2, 3, 4):
         hip.set_tuning(3, qt)
         try:
             o_h = torch.full((B * nq, H * d), float("nan"), dtype=T, device="cuda")

@@ -12,7 +12,7 @@ for (B, H, n, nk, d) in [(32, 8, 4096, 4096, 40), (32, 8, 1024, 1024, 80), (32, 
     o = torch.empty(B * n, H * d, dtype=T, device=dev)
     kw = dict(batch=B, heads=H, n_q=n, n_k=nk, d=d, ldo=H * d, ldvt=ld, scale=d ** -0.5)
     res = []
-    for var in (2, 4):
+    for var in (2, 3, 4):
         h.set_tuning(3, var)
         for _ in range(2): h.attention(q, k, vt, o, **kw)
         torch.cuda.synchronize()
@@ -23,4 +23,4 @@ for (B, H, n, nk, d) in [(32, 8, 4096, 4096, 40), (32, 8, 1024, 1024, 80), (32, 
         res.append(s.elapsed_time(e) / 5 * 1e3)
     h.set_tuning(3, 0)
     fl = 4.0 * B * H * n * nk * d
-    print(f"B={B} H={H} nq={n} nk={nk} d={d}: QT2 {res[0]:.0f}us ({fl/res[0]/1e6:.0f} TF) | QT4 {res[1]:.0f}us ({fl/res[1]/1e6:.0f} TF)")
+    print(f"B={B} H={H} nq={n} nk={nk} d={d}: " + " | ".join(f"QT{v} {r:.0f}us ({fl/r/1e6:.0f} TF)" for v, r in zip((2, 3, 4), res)))
