@@ -22,7 +22,7 @@ extern "C" int fyc_attention(const fyc_attn_args* a, void* stream) {
   // QT = 4 needs 170 VGPRs (2 waves / SIMD), QT = 3 needs 140 (3 waves / SIMD).  Large problems take QT = 3 (measured,
   // profiles/r02_attention_variants.txt); small ones QT = 2 so that the grid still fills the chip.  tuning key 3 forces QT.
   const long long wg3 = (long long)a->batch * a->heads * ((a->n_q + 191) / 192);
-  int qt = (a->n_q >= 1024 && wg3 >= 512 && a->d <= 80) ? 3 : 2;
+  int qt = (a->n_q >= 1024 && wg3 >= 512 && a->d <= 48) ? 3 : 2;      // larger head dims: 3 tiles no longer fit 2 waves / SIMD
   if (g_fyc_tuning[3] >= 2 && g_fyc_tuning[3] <= 4 && (a->d <= 80 || g_fyc_tuning[3] == 2)) qt = g_fyc_tuning[3];
   if (a->d <= 48) return fyca::run_small(p, qt, st);
   if (a->d <= 96) return fyca::run_medium(p, qt, st);

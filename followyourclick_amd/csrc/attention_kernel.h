@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
   constexpr int KS = DP16 / 2;           // full 32-wide k-steps
   constexpr bool TAIL = (DP16 & 1) != 0; // plus one 16-wide k-step
   constexpr bool MSUB = (DVT == DP16);
+  constexpr bool PIPE = DP16 <= 3;       // d <= 48: both 32-key blocks of a tile are software-pipelined (see the tile loop)
   constexpr int DC = DP16 * 2;           // 16-B chunks per K row
   constexpr bool KXOR = (DC == 8);       // 128-B rows: XOR swizzle; otherwise one pad chunk per row (odd pitch)
   constexpr int PC = KXOR ? 8 : DC + 1;  // K row pitch in chunks
@@ -287,33 +288,30 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
     const char* sV = sK + K_BYTES;
     st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     const bool tail = (tile * KB + KB > p.n_k);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      if (tile * KB + kb * 32 >= p.n_k) break;  // whole 32-key block out of range (uniform)
-      // ---- S^T tiles: tile t row i <-> key kb*32 + 8*(i>>2) + 4t + (i&3)
-      f32x4 s[2][QT];
-      bf16x8 kf[2][KS > 0 ? KS : 1];
-      s16x4 kt4[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int krow = kb * 32 + 8 * (r16 >> 2) + 4 * t + (r16 & 3);
-        const char* kr = sK + krow * (PC * 16);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int chunk = 4 * ks + g;
-          kf[t][ks] = *reinterpret_cast<const bf16x8*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16);
-        }
-        if (TAIL) {
-          const int chunk = 4 * KS + (g >> 1);
-          kt4[t] = *reinterpret_cast<const s16x4*>(kr + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16 + (g & 1) * 8);
-        }
-      }
-      __builtin_amdgcn_s_setprio(1);
+    // Two 32-key blocks per tile, software-pipelined inside the wave: both blocks' QK^T MFMAs are issued before the first
+    // block's softmax, so the matrix pipe works on block 1's scores while the VALU does block 0's exponentials, and block 0's
+    // PV MFMAs run under block 1's softmax (a wave issues in order: without this its MFMA and VALU phases simply add up -
+    // measured: matrix pipe 43 % busy, VALU 21 %, the rest dependency stalls).
+    auto qk = [&](int kb, f32x4 (&s)[2][QT]) {
+      // S^T tiles: tile t row i <-> key kb*32 + 8*(i>>2) + 4t + (i&3).
       // The 16-wide steps of all 2*QT score tiles first (onto zero), then the 32-wide chains on top, with the two groups pinned:
       // hipcc 7.2 puts no wait state between a v_mfma_f32_16x16x32_bf16 and a v_mfma_f32_16x16x16_bf16 that accumulates onto its
       // result (or vice versa), and the consumer then reads a stale accumulator (measured: head dims with full steps + a tail
       // came out wrong whenever the two were adjacent).  This order puts 2*QT-1 independent MFMAs (>= 24 cycles) behind each
       // 4-pass producer before its accumulator is read again; the 32-wide chains are same-opcode back-to-back (interlocked).
+      const char* kr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) kr[t] = sK + (kb * 32 + 8 * (r16 >> 2) + 4 * t + (r16 & 3)) * (PC * 16);
+      s16x4 kt4[2];
+      if (TAIL) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int krow = kb * 32 + 8 * (r16 >> 2) + 4 * t + (r16 & 3);
+          const int chunk = 4 * KS + (g >> 1);
+          kt4[t] = *reinterpret_cast<const s16x4*>(kr[t] + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16 + (g & 1) * 8);
+        }
+      }
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -323,12 +321,22 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
         }
       if (TAIL && KS > 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        const int krow = kb * 32 + 8 * (r16 >> 2) + 4 * t + (r16 & 3);
+        bf16x8 kf[KS > 0 ? KS : 1];        // one key tile's fragments at a time: large head dims would not fit both
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int chunk = 4 * ks + g;
+          kf[ks] = *reinterpret_cast<const bf16x8*>(kr[t] + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16);
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[qt][ks], s[t][qt], 0, 0, 0);
+          for (int ks = 0; ks < KS; ++ks) s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[qt][ks], s[t][qt], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
+    };
+    auto softmax_pv = [&](int kb, f32x4 (&s)[2][QT], f32x4 (&sn)[2][QT], bool has_next) {
       // ---- online softmax; lane holds keys kb*32 + 8g + 4t + r of query r16.  MSUB: s already is score - m_run.
       float mx[QT];        // this LANE's maximum over its 8 keys (the other three quads of the query column hold the other 24)
 #pragma unroll
@@ -366,6 +374,12 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
             m_run[qt] = m_new;
             shift[qt] = delta;
             set_neg_max(qt, m_new);
+            if (has_next) {      // the next block's scores were computed against the old max as well
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sn[t][qt][r] -= delta;
+            }
 #pragma unroll
             for (int dv = 0; dv < DVT; ++dv) { o[qt][dv][0] *= alpha; o[qt][dv][1] *= alpha; o[qt][dv][2] *= alpha; o[qt][dv][3] *= alpha; }
           } else {
@@ -414,6 +428,18 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
         for (int qt = 0; qt < QT; ++qt) o[qt][dv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][dv], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
+    };
+    const int nb = (tile * KB + 32 < p.n_k) ? 2 : 1;      // 32-key blocks of this tile that hold keys (uniform)
+    f32x4 s0[2][QT], s1[2][QT];
+    if constexpr (PIPE) {
+      qk(0, s0);
+      if (nb > 1) { qk(1, s1); __builtin_amdgcn_sched_barrier(0); }
+      softmax_pv(0, s0, s1, nb > 1);
+      if (nb > 1) softmax_pv(1, s1, s0, false);
+    } else {            // larger head dims: two blocks of scores in flight do not fit the register file
+      qk(0, s0);
+      softmax_pv(0, s0, s1, false);
+      if (nb > 1) { qk(1, s0); softmax_pv(1, s0, s1, false); }
     }
   }
 
