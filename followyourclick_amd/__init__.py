@@ -17,8 +17,11 @@ DROPIN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
 def install_dropin(force: bool = False) -> str:
     """Put the drop-in `animatediff` / `diffusers` / `ip_adapter` packages first on sys.path so that the
     reference's scripts import this engine instead of the reference's torch modules."""
-    loaded = [m for m in ("animatediff", "diffusers", "ip_adapter") if m in sys.modules
-              and not getattr(sys.modules[m], "__file__", "").startswith(DROPIN_DIR)]
+    def foreign(mod) -> bool:     # the reference's `animatediff` has no __init__.py: a namespace package, __file__ is None
+        paths = [getattr(mod, "__file__", None) or ""] + [str(p) for p in (getattr(mod, "__path__", None) or [])]
+        return not any(p.startswith(DROPIN_DIR) for p in paths if p)
+
+    loaded = [m for m in ("animatediff", "diffusers", "ip_adapter") if m in sys.modules and foreign(sys.modules[m])]
     if loaded and not force:
         raise RuntimeError(f"{loaded} already imported from elsewhere; call install_dropin() before importing them "
                            "(or pass force=True to evict them)")

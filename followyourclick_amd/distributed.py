@@ -93,6 +93,33 @@ def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> 
     return total
 
 
+_share = os.environ.get("FYC_BROADCAST_WEIGHTS", "1") != "0"
+
+
+def enable_weight_broadcast(on: bool = True) -> None:
+    """Whether the drop-in modules (UNet3DConditionModel, UNet2DConditionModel, AutoencoderKL) broadcast their packed weights
+    from rank 0 when torch.distributed is initialised (default on; FYC_BROADCAST_WEIGHTS=0 turns it off)."""
+    global _share
+    _share = bool(on)
+
+
+def share_packed(P: Packed, src: int = 0) -> int:
+    """The drop-in path's one collective: every rank packs what its module holds, then receives rank `src`'s packed tree, so
+    only rank `src` needs the real checkpoint (`load_on_rank0`).  The reference makes every rank read every checkpoint from disk
+    (scripts/inference.py:44-51, 152-181).  Returns bytes moved (0 without a process group)."""
+    if not _share:
+        return 0
+    return broadcast_packed(P, src=src)
+
+
+def load_on_rank0(loader, *args, **kwargs):
+    """run a checkpoint loader (e.g. `unet.load_state_dict(torch.load(path))`) on rank 0 only; the other ranks keep their
+    initial parameters, which `share_packed` overwrites in the packed engine tree at first use"""
+    if not dist.is_initialized() or dist.get_rank() == 0 or not _share:
+        return loader(*args, **kwargs)
+    return None
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -20,6 +20,8 @@ from typing import Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
+from followyourclick_amd import distributed as D
+from followyourclick_amd import ops as ops_mod
 from followyourclick_amd.engine import UNet3DConfig
 from followyourclick_amd.engine.schema import unet_schema
 from followyourclick_amd.engine.unet3d import UNet3DEngine
@@ -121,6 +123,7 @@ class UNet3DConditionModel(nn.Module):
         self._engine: Optional[UNet3DEngine] = None
         self._engine_key = None
         self._ctx_key = None
+        self._ctx_cache_obj = None
         self._reset_parameters()
 
     # ---- nn.Module plumbing -------------------------------------------------------------------
@@ -170,10 +173,12 @@ class UNet3DConditionModel(nn.Module):
     def _get_engine(self) -> UNet3DEngine:
         key = self._weights_key()
         if self._engine is None or key != self._engine_key:
-            if self.device.type != "cuda":
+            if self.device.type != "cuda" and ops_mod.get().name == "hip":
                 raise RuntimeError("UNet3DConditionModel runs on an MI355X HIP device only (call .to('cuda')); no CPU fallback")
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith("image_proj_model")}
-            self._engine = UNet3DEngine(pack_unet(sd, self.engine_config, self.compute_dtype, self.device))
+            packed = pack_unet(sd, self.engine_config, self.compute_dtype, self.device)
+            D.share_packed(packed)          # torch.distributed initialised: rank 0's weights, one RCCL broadcast
+            self._engine = UNet3DEngine(packed)
             self._engine_key, self._ctx_key = key, None
         return self._engine
 
@@ -207,13 +212,19 @@ class UNet3DConditionModel(nn.Module):
             if self.image_proj_model is None:
                 raise ValueError("set unet.image_proj_model (ip_adapter.init_proj()) before using IP cross-attention")
             ip_tokens = self.image_proj_model(reference_images_clip_feat)
-        ckey = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
-                None if ip_tokens is None else (reference_images_clip_feat.data_ptr(), reference_images_clip_feat._version))
-        if ckey != self._ctx_key:
+        # The cached K / V^T are valid only for the very tensors they were projected from: compare by identity + version and
+        # keep the tensors alive (an address can be recycled by a new prompt's embeddings), and make sure the engine's cache is
+        # still ours (AnimationPipeline / DDIMSampler.prepare re-project it for their own runs).
+        cur = (encoder_hidden_states, encoder_hidden_states._version,
+               reference_images_clip_feat if ip_tokens is not None else None,
+               reference_images_clip_feat._version if ip_tokens is not None else None)
+        hit = (self._ctx_key is not None and self._ctx_key[0] is cur[0] and self._ctx_key[1] == cur[1]
+               and self._ctx_key[2] is cur[2] and self._ctx_key[3] == cur[3] and eng.ctx_cache is self._ctx_cache_obj)
+        if not hit:
             if encoder_hidden_states.shape[0] != B:
                 raise ValueError("encoder_hidden_states batch does not match sample batch")
             eng.prepare_context(encoder_hidden_states.float(), None if ip_tokens is None else ip_tokens.float())
-            self._ctx_key = ckey
+            self._ctx_key, self._ctx_cache_obj = cur, eng.ctx_cache
 
         def vec(v, n):
             if v is None:

@@ -13,6 +13,8 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
+from followyourclick_amd import distributed as D
+from followyourclick_amd import ops as ops_mod
 from followyourclick_amd.engine import VAEDecoderConfig
 from followyourclick_amd.engine.schema import vae_decoder_schema, vae_encoder_schema
 from followyourclick_amd.engine.vae import VAEDecoderEngine, VAEEncoderEngine
@@ -106,10 +108,12 @@ class AutoencoderKL(nn.Module):
     def _get_engine(self) -> VAEDecoderEngine:
         key = (self.device, self.compute_dtype) + tuple(p._version for p in self.parameters())
         if self._engine is None or key != self._engine_key:
-            if self.device.type != "cuda":
+            if self.device.type != "cuda" and ops_mod.get().name == "hip":
                 raise RuntimeError("AutoencoderKL.decode runs on an MI355X HIP device only (call .to('cuda')); no CPU fallback")
             sd = {k: v for k, v in self.state_dict().items() if k.startswith(("decoder.", "post_quant_conv."))}
-            self._engine = VAEDecoderEngine(pack_vae_decoder(sd, self.engine_config, self.compute_dtype, self.device))
+            packed = pack_vae_decoder(sd, self.engine_config, self.compute_dtype, self.device)
+            D.share_packed(packed)          # torch.distributed initialised: rank 0's weights, one RCCL broadcast
+            self._engine = VAEDecoderEngine(packed)
             self._engine_key = key
         return self._engine
 
@@ -134,8 +138,7 @@ class AutoencoderKL(nn.Module):
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         """z: (N, 4, h, w) latents already divided by 0.18215 -> DecoderOutput(sample (N,3,8h,8w) in [-1, 1]-ish)"""
         eng = self._get_engine()
-        img01 = eng.decode(z.float() * self.engine_config.scaling_factor)        # engine returns clamp(x/2+0.5, 0, 1)
-        sample = (img01 * 2.0 - 1.0).to(z.dtype)
+        sample = eng.decode(z.float() * self.engine_config.scaling_factor, raw=True).to(z.dtype)   # unclamped, like the reference
         if not return_dict:
             return (sample,)
         return DecoderOutput(sample=sample)

@@ -125,6 +125,14 @@ class UNet3DEngine(EngineBase):
                    heads=dict(seg_cols=C, heads=H, tokens=n_tok, outs=[k, vt], transposed=[0, 1], ld=[0, ld]))
             return k, vt, ld
 
+        if cfg.use_ip_cross_attention and ip_tokens is None:
+            # IPCrossAttention.forward always treats the LAST num_tokens tokens of encoder_hidden_states as image tokens
+            # (reference animatediff/models/attention.py:52-53, 104-120) - also when the caller passed plain text states
+            n = cfg.ip_num_tokens
+            if Nk <= n:
+                raise ValueError(f"encoder_hidden_states has {Nk} tokens, the IP cross-attention splits off the last {n}")
+            ctx, ip_tokens = ctx[:, :Nk - n], ctx[:, Nk - n:]
+            Nk -= n
         xt = to_T(ctx)
         xi = to_T(ip_tokens) if (cfg.use_ip_cross_attention and ip_tokens is not None) else None
         cache = []

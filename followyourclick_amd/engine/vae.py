@@ -56,9 +56,10 @@ class VAEDecoderEngine(EngineBase):
         o.gemm(S, vt, att, M=N, N=C, K=ld, lda=ld, ldw=ld, ldo=C, batch=frames, stride_a=N * ld, stride_w=C * ld, stride_o=N * C)
         return self.lin(att, a.o_w, rows, bias=a.o_b, residual=x)
 
-    def decode(self, z: Tensor) -> Tensor:
+    def decode(self, z: Tensor, raw: bool = False) -> Tensor:
         """z: (N, 4, h, w) f32 latents *already in model space* (not yet divided by the scaling factor);
-        returns (N, 3, 8h, 8w) f32 = clamp(decode(z / 0.18215) / 2 + 0.5, 0, 1)."""
+        returns (N, 3, 8h, 8w) f32 = clamp(decode(z / 0.18215) / 2 + 0.5, 0, 1), or with raw=True the decoder's own
+        unclamped sample (what AutoencoderKL.decode returns, reference diffusers/models/vae.py:575-589)."""
         P, cfg, o = self.P, self.cfg, self.ops
         N, Cz, H, W = z.shape
         z = z.to(device=self.device, dtype=torch.float32).contiguous()
@@ -86,7 +87,10 @@ class VAEDecoderEngine(EngineBase):
         o.gemm(h, P.conv_out_w, img, M=N * H * W, N=Co, K=Kc, lda=Kc // 9, ldw=Kc, ldo=ldo, bias=P.conv_out_b, mode=L.GEMM_CONV3X3,
                conv=dict(Hout=H, Wout=W, Hin=H, Win=W, Cin=Kc // 9, stride=1))
         out = self.new(N, Co, H, W, dtype=torch.float32)
-        o.nhwc_to_nchw(img, out, N=N, C_=Co, HW=H * W, ld=ldo, mul=0.5, add=0.5, lo=0.0, hi=1.0)
+        if raw:
+            o.nhwc_to_nchw(img, out, N=N, C_=Co, HW=H * W, ld=ldo)
+        else:
+            o.nhwc_to_nchw(img, out, N=N, C_=Co, HW=H * W, ld=ldo, mul=0.5, add=0.5, lo=0.0, hi=1.0)
         return out
 
     def decode_video(self, latents: Tensor, chunk: int = 16) -> Tensor:

@@ -54,13 +54,19 @@ class HipOps:
 
     # -- library ---------------------------------------------------------------------------
     def ensure_init(self, device: torch.device) -> None:
-        if self._inited_dev == device:
-            return
+        """One GPU per process (the library's zero page and tuning table are process-wide; the multi-GPU path is one process
+        per GPU): the first device used is bound, any other raises."""
         if not torch.cuda.is_available():
             raise L.FycError("no HIP device visible: followyourclick_amd has no CPU fallback")
-        self._zero = torch.zeros(4096, dtype=torch.uint8, device=device)
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._inited_dev == idx:
+            return
+        if self._inited_dev is not None:
+            raise L.FycError(f"followyourclick_amd is bound to cuda:{self._inited_dev}; use one process per GPU (asked for cuda:{idx})")
+        self._zero = torch.zeros(4096, dtype=torch.uint8, device=torch.device("cuda", idx))
         L.check(self.lib.fyc_init(self._zero.data_ptr()), "fyc_init")
-        self._inited_dev = device
+        self._inited_dev = idx
         for kv in filter(None, os.environ.get("FYC_TUNING", "").split(",")):   # A/B runs: FYC_TUNING="5=1,4=8" (fyc_set_tuning keys)
             k, v = kv.split("=")
             self.set_tuning(int(k), int(v))

@@ -73,3 +73,43 @@ def test_shard_indices():
     from followyourclick_amd.distributed import shard_indices
     assert [shard_indices(8, r, 8) for r in range(8)] == [[r] for r in range(8)]
     assert shard_indices(5, 1, 2) == [1, 3] and shard_indices(1, 3, 8) == []
+
+
+def _dropin_worker(rank, world, port, tmp):
+    """the drop-in classes themselves: only rank 0 holds the real checkpoint, the others receive the packed tree"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import followyourclick_amd
+    from emu_ops import EmuOps
+    from followyourclick_amd import distributed as D
+    from followyourclick_amd import ops as ops_mod
+    ops_mod.impl = EmuOps()                     # CPU test: host orchestration on the op emulator
+    followyourclick_amd.install_dropin(force=True)
+    from animatediff.models.unet import UNet3DConditionModel
+    from test_dropin_api import TINY
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(1234 + rank)              # every rank starts from DIFFERENT random parameters
+    unet = UNet3DConditionModel(**TINY)
+    ckpt = os.path.join(tmp, "unet.pt")
+    if rank == 0:
+        torch.save(unet.state_dict(), ckpt)
+    D.barrier()
+    loaded = D.load_on_rank0(lambda: unet.load_state_dict(torch.load(ckpt), strict=False))
+    assert (loaded is not None) == (rank == 0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 9, 2, 8, 8, generator=g)
+    text = torch.randn(2, 77, 64, generator=g)
+    out = unet(x, torch.tensor(500), text, use_fps_condition=True, fps_tensor=torch.tensor([2, 2]), flow_control=torch.tensor([4, 4])).sample
+    torch.save({"out": out, "w": unet._engine.P.conv_in_w.clone()}, os.path.join(tmp, f"dropin{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_dropin_unet_receives_rank0_weights(tmp_path):
+    """scripts/inference.py --ddp equivalent: with a process group the drop-in UNet broadcasts rank 0's packed weights, so the
+    ranks that never read the checkpoint produce rank 0's outputs"""
+    world, port = 2, 29743
+    mp.spawn(_dropin_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"dropin{r}.pt")) for r in (0, 1))
+    assert torch.equal(a["w"], b["w"])
+    assert torch.equal(a["out"], b["out"])

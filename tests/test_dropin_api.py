@@ -308,3 +308,31 @@ def test_prepare_latents_vs_reference_golden(dropin, golden_dir):
             continue
         out = pipe.prepare_latents(1, 4, 6, 64, 64, torch.float32, torch.device("cpu"), gen, **kw)
         assert torch.equal(out, torch.from_numpy(g[name])), name
+
+
+def test_install_dropin_evicts_a_namespace_package(tmp_path):
+    """the reference's `animatediff` has no __init__.py (a namespace package: __file__ is None): install_dropin must report it
+    as foreign, refuse without force and evict it with force=True"""
+    import importlib
+    ref = tmp_path / "refroot"
+    (ref / "animatediff" / "models").mkdir(parents=True)
+    (ref / "animatediff" / "models" / "__init__.py").write_text("")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")]:
+        del sys.modules[k]
+    if followyourclick_amd.DROPIN_DIR in sys.path:
+        sys.path.remove(followyourclick_amd.DROPIN_DIR)
+    sys.path.insert(0, str(ref))
+    try:
+        mod = importlib.import_module("animatediff")
+        assert getattr(mod, "__file__", None) is None
+        with pytest.raises(RuntimeError, match="already imported"):
+            followyourclick_amd.install_dropin()
+        followyourclick_amd.install_dropin(force=True)
+        mod = importlib.import_module("animatediff")
+        assert any(str(p).startswith(followyourclick_amd.DROPIN_DIR) for p in list(getattr(mod, "__path__", [])) + [mod.__file__ or ""])
+    finally:
+        sys.path.remove(str(ref))
+        for k in [k for k in sys.modules if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")]:
+            del sys.modules[k]
+        if followyourclick_amd.DROPIN_DIR in sys.path:
+            sys.path.remove(followyourclick_amd.DROPIN_DIR)

@@ -233,3 +233,23 @@ def test_sampler_first_frame_condition_matches_reference_pipeline(golden_dir):
     traj, ref = torch.stack(traj), g["trajectory_first_frame"]
     err = (traj - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
     assert err.max().item() < 5e-4, err
+
+
+def test_ip_model_without_ip_tokens_splits_the_text_states():
+    """On a model built with IP cross-attention the reference always treats the LAST num_tokens tokens of
+    encoder_hidden_states as image tokens (animatediff/models/attention.py:52-53, 104-120), also when the caller passed plain
+    text states: prepare_context(ctx) must equal prepare_context(ctx[:, :-n], ctx[:, -n:])."""
+    cfg = tiny_cfg(use_ip_cross_attention=True, ip_scale=0.7)
+    ocfg = Fn.tiny_unet_config(use_ip_cross_attention=True, ip_scale=0.7)
+    sd = W.make_weights(W.unet_state_shapes(ocfg), 0)
+    eng = UNet3DEngine(pack_unet(sd, cfg, torch.float32, "cpu"), ops=EmuOps())
+    ctx = torch.randn(2, 77, 64, generator=torch.Generator().manual_seed(1))
+    n = cfg.ip_num_tokens
+    eng.prepare_context(ctx)
+    a = eng.ctx_cache
+    eng.prepare_context(ctx[:, :-n], ctx[:, -n:])
+    b = eng.ctx_cache
+    assert a[0]["n_text"] == 77 - n and a[0]["n_ip"] == n
+    for ea, eb in zip(a, b):
+        for ta, tb in zip(ea["text"][:2] + ea["ip"][:2], eb["text"][:2] + eb["ip"][:2]):
+            assert torch.equal(ta, tb)
