@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
                 ("Hout", i32), ("Wout", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("conv_stride", i32), ("conv_pad", i32),
                 ("rows_per_batch", i32), ("seg_cols", i32), ("heads", i32), ("tokens", i32),
                 ("out_scale", f32), ("dtype", i32), ("tile", i32), ("act", i32), ("ln_stats", vp), ("ln_colsum", vp),
-                ("ln_nparts", i32), ("ln_eps", f32), ("chan_parts", vp), ("cs_rows", i32), ("row_parts", vp), ("row_nparts", i32)]
+                ("ln_nparts", i32), ("ln_eps", f32), ("chan_parts", vp), ("cs_rows", i32), ("row_parts", vp), ("row_nparts", i32), ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class AttnArgs(C.Structure):
@@ -128,7 +128,7 @@ OPS = {
     "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs, "fyc_row_stats": RowStatsArgs,
     "fyc_gn_apply_cs": GnApplyCsArgs, "fyc_chan_stats_reduce": ChanStatsReduceArgs,
 }
-MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout"]
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes"]
 
 _lib = None
 
@@ -157,6 +157,8 @@ def load() -> C.CDLL:
         lib.fyc_gemm_row_parts.restype = C.c_int
         lib.fyc_gemm_stat_layout.argtypes = [C.POINTER(GemmArgs), C.POINTER(i32), C.POINTER(i32)]
         lib.fyc_gemm_stat_layout.restype = C.c_int
+        lib.fyc_gemm_workspace_bytes.argtypes = [C.POINTER(GemmArgs)]
+        lib.fyc_gemm_workspace_bytes.restype = i64
     for name, st in OPS.items():
         if ab_build and not hasattr(lib, name):
             continue

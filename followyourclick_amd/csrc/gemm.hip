@@ -5,6 +5,47 @@
 using fycg::GemmP;
 
 namespace {
+// ---- split-K: small M with a long K (the 8x8-latent level: M = 2048, K up to 23040) -----------------------------------------
+// A 128x64 tile grid (320 tiles) re-fetches 3.4x the operand bytes per FLOP of the 320-wide tiles, and 128x320 tiles alone
+// leave 3/4 of the CUs idle (64 tiles).  Each output tile is therefore cut into `splitk` K slices (one work item each, raw f32
+// partials to the caller's workspace) and this kernel adds the slices and applies the LINEAR epilogue.
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                            const float* __restrict__ rowbias, int rows_per_batch, int ldrb,
+                                                            const bf16_t* __restrict__ residual, int ldr, bf16_t* __restrict__ out, int ldo,
+                                                            int M, int N, float out_scale) {
+  const int n8 = N >> 3;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < (long long)M * n8; idx += gridDim.x * 256ll) {
+    const int m = (int)(idx / n8), n = (int)(idx - (long long)m * n8) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* src = ws + ((long long)s * M + m) * N + n;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    }
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
+    }
+    if (rowbias) {
+      const float* rb = rowbias + (long long)(m / rows_per_batch) * ldrb + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rb[e];
+    }
+    if (residual) {
+      float r[8];
+      load8<bf16_t>(residual + (long long)m * ldr + n, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= out_scale;
+    store8<bf16_t>(out + (long long)m * ldo + n, v);
+  }
+}
+
 // Tile / ring-depth choice.  g_fyc_tuning[1] / [2] force a config / depth (bench sweeps, tests).
 void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tile_sweep.txt): the DMA fill rate of the
@@ -52,7 +93,30 @@ void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
   if (stats && cfg == 8) cfg = 6;
   if (stats && cfg == 10) cfg = 1;
 }
+// K slices per output tile (1 = no split) and the tile config a split problem uses
+int split_of(const fyc_gemm_args* a, int& cfg) {
+  if (a->dtype != FYC_BF16 || a->epilogue != FYC_EPI_LINEAR || a->act != FYC_ACT_NONE || a->batch > 1 || a->tile != 0 || g_fyc_tuning[1] > 0 || g_fyc_tuning[0] == 1) return 1;
+  if (a->ln_stats != nullptr || a->chan_parts != nullptr || a->row_parts != nullptr || a->a2 != nullptr) return 1;
+  if (a->M > 4096 || a->K < 2048 || a->N % 8 != 0 || a->N < 256) return 1;
+  const int c = (a->N % 320 == 0) ? 6 : 1;                     // 128x320 or 128x128 tiles
+  const int bn = (c == 6) ? 320 : 128;
+  const long long tiles = (long long)((a->M + 127) / 128) * ((a->N + bn - 1) / bn);
+  const int kt = (a->K + 63) / 64;
+  int s = (int)(256 / tiles);
+  if (s > 8) s = 8;
+  while (s > 1 && kt / s < 16) --s;                            // keep >= 16 K tiles per slice
+  if (s < 2) return 1;
+  cfg = c;
+  return s;
+}
 }  // namespace
+
+extern "C" int64_t fyc_gemm_workspace_bytes(const fyc_gemm_args* a) {
+  if (a == nullptr) return 0;
+  int cfg = 0;
+  const int s = split_of(a, cfg);
+  return s > 1 ? (int64_t)s * a->M * a->N * 4 : 0;
+}
 
 extern "C" int fyc_gemm_row_parts(const fyc_gemm_args* a) {
   if (a == nullptr || a->N <= 0) return 0;
@@ -182,6 +246,22 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int cfg = 1, ns = 2;
   pick(a, cfg, ns, a->chan_parts != nullptr || a->row_parts != nullptr);
+  {
+    int scfg = 0;
+    const int sk = split_of(a, scfg);
+    if (sk > 1 && p.wide && a->workspace != nullptr && a->workspace_bytes >= (int64_t)sk * a->M * a->N * 4 && ((uintptr_t)a->workspace % 16) == 0) {
+      GemmP q = p;
+      q.splitk = sk; q.ws = (float*)a->workspace;
+      const int rc = (a->mode == FYC_GEMM_PLAIN) ? fycg::run_bf16_plain(q, batch, scfg, 2, st) : fycg::run_bf16_conv(q, batch, scfg, 2, st);
+      if (rc != 0) return rc;
+      const long long items = (long long)a->M * (a->N / 8);
+      const int blocks = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+      hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->workspace, sk, a->bias, a->rowbias, p.rows_per_batch, p.ldrb,
+                         (const bf16_t*)a->residual, a->ldr, (bf16_t*)a->out, a->ldo, a->M, a->N, a->out_scale);
+      FYC_CHECK_LAUNCH("fyc_gemm split-K finish");
+      return 0;
+    }
+  }
   FYC_REQUIRE(a->chan_parts == nullptr || a->dtype == FYC_F32 || p.wide || cfg == 1 || cfg == 2, "fyc_gemm: chan_parts in bf16 needs the 16-byte aligned layout or tile config 1 / 2");
   FYC_REQUIRE(a->row_parts == nullptr || a->dtype == FYC_F32 || p.wide, "fyc_gemm: row_parts in bf16 needs the 16-byte aligned layout (N, ldo, ldr multiples of 8; aligned pointers)");
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, cfg, st);

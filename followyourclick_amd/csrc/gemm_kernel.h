@@ -52,6 +52,7 @@ struct GemmP {
   int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
   int colc;   // bias / colsum / tile-uniform rowbias may be fetched 16 B at a time and staged through LDS once per tile
   int rb_tile; // rowbias row is the same for every row of a tile (rows_per_batch % BM == 0): folded into the staged bias
+  int splitk; float* ws;   // split-K (small M, long K): `splitk` work items per output tile, raw f32 partials to ws[splitk][M][N]
   int stagger; // 8-wave tiles: the upper half of the waves issues its DMAs between its two MFMA k-steps (fyc_set_tuning key 5 = 1: off)
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
@@ -632,10 +633,17 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   int a_pos[C3 ? A_IT : 1], a_msk[C3 ? A_IT : 1];
   int a_pix[MODE == FYC_GEMM_CONV3X3_UP2 ? A_IT : 1], a_yx[MODE == FYC_GEMM_CONV3X3_UP2 ? A_IT : 1];   // upsampled conv: frame pixel base (-1: row outside M), (iy0 << 16) | (ix0 & 0xffff)
   int tap = 0, c0 = 0;  // conv: filter tap and channel offset of the K tile being issued
-  auto setup_issue = [&](int tile) {
-    const int t = remap(tile);
+  // split-K: work item w = (output tile w / S, K slice w % S); K slice s covers K tiles [s*KT/S, (s+1)*KT/S)
+  const int KT = (p.K + BK - 1) / BK;
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  auto kt_begin = [&](int work) { return (int)(((long long)(work % S) * KT) / S); };
+  auto kt_end = [&](int work) { return (int)(((long long)(work % S + 1) * KT) / S); };
+  auto setup_issue = [&](int work) {
+    const int t = remap(work / S);
     tile_coords(p, t, i_tm, i_tn);
-    tap = 0; c0 = 0;
+    const int kt0 = kt_begin(work);
+    tap = kt0 % 9; c0 = (kt0 / 9) * BK;      // conv K order (slab, tap, channel): K tile kt = tap kt%9 of slab kt/9 (RB = 128; host keeps split-K off the 64-byte tiles)
+    if (MODE == FYC_GEMM_PLAIN || S == 1) { tap = 0; c0 = 0; }
     b_base = (long long)(i_tn * BN + lrow) * p.ldw + koff;
     if (MODE == FYC_GEMM_PLAIN) {
       a_base = (long long)(i_tm * BM + lrow) * p.lda + koff;
@@ -663,8 +671,6 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       }
     }
   };
-
-  const int KT = (p.K + BK - 1) / BK;
 
   auto src_a = [&](int it, int k0) -> const T* {
     if (MODE == FYC_GEMM_PLAIN) {
@@ -736,30 +742,32 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   };
 
   // ---- main loop: NS-deep ring over the continuous K-tile stream, counted waits -------------------
-  int i_tile = blockIdx.x, i_kt = 0;      // issue side of the stream
+  const int nwork = ntiles * S;
+  int i_tile = blockIdx.x, i_kt = 0, i_kt_end = 0;   // issue side of the stream (i_tile: work item being issued)
   int st_c = 0, st_i = 0;                 // stage being computed / issued
   int n_ahead = 0;                        // stream elements issued and not yet consumed
+  auto begin_issue = [&]() { setup_issue(i_tile); i_kt = kt_begin(i_tile); i_kt_end = kt_end(i_tile); };
   auto issue_next = [&]() {
     issue(i_kt, st_i);
     st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
     ++n_ahead;
-    if (++i_kt == KT) {
-      i_kt = 0;
+    if (++i_kt == i_kt_end) {
       i_tile += gridDim.x;
-      if (i_tile < ntiles) setup_issue(i_tile);
+      if (i_tile < nwork) begin_issue();
     }
   };
-  if (i_tile < ntiles) setup_issue(i_tile);
+  if (i_tile < nwork) begin_issue();
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (i_tile < ntiles) issue_next();
+    if (i_tile < nwork) issue_next();
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < nwork; tile += gridDim.x) {
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < KT; ++kt) {
+    const int kt_hi = kt_end(tile);
+    for (int kt = kt_begin(tile); kt < kt_hi; ++kt) {
       // the oldest in-flight element must have landed; up to NS-2 younger ones may stay in flight
       const int ahead = min(NS - 2, n_ahead - 1);
       if (NS >= 4 && ahead == 2) wait_vmcnt<2 * LOADS>();
@@ -774,15 +782,29 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       // every wave before this barrier, and the late DMAs still have a k-step of both waves to land.)
       // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
       const bool late = STAGGER && p.stagger && wave >= (WGM * WGN) / 2;
-      if (!late && i_tile < ntiles) issue_next();
+      if (!late && i_tile < nwork) issue_next();
       compute(st_c, 0, 1);
-      if (late && i_tile < ntiles) issue_next();
+      if (late && i_tile < nwork) issue_next();
       compute(st_c, 1, KSTEPS);
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     }
-    const int t = remap(tile);
+    const int t = remap(tile / S);
     int tile_m, tile_n;
     tile_coords(p, t, tile_m, tile_n);
+    if (S > 1) {      // split-K: raw f32 partial sums; fyc_gemm's finish kernel adds the slices and applies the epilogue
+      float* Wp = p.ws + (long long)(tile % S) * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+          const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
+          if (n < p.N) *reinterpret_cast<f32x4*>(Wp + (long long)m * p.N + n) = acc[i][j];
+        }
+      }
+      continue;
+    }
 
     gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE, WIDE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
   }  // tile stream
@@ -825,7 +847,7 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   if (occ < 1) occ = 1;
   long long resident = (long long)n_cu * occ / (batch > 0 ? batch : 1);
   if (resident < n_cu) resident = n_cu;
-  const long long ntiles = (long long)q.tiles_m * q.tiles_n;
+  const long long ntiles = (long long)q.tiles_m * q.tiles_n * (q.splitk > 1 ? q.splitk : 1);
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident), 1, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), smem, st, q);
   FYC_CHECK_LAUNCH("fyc_gemm");

@@ -50,6 +50,7 @@ class HipOps:
     def __init__(self):
         self.lib = L.load()
         self._zero = None
+        self._ws = None              # scratch for split-K GEMMs: one buffer, grown on demand (all work is on one stream)
         self._inited_dev = None
 
     # -- library ---------------------------------------------------------------------------
@@ -101,6 +102,12 @@ class HipOps:
                             stride_a=stride_a, stride_w=stride_w, stride_o=stride_o, heads=heads, tile=tile, a2=a2, k_split=k_split,
                             lda2=lda2, act=act, ln_stats=ln_stats, ln_colsum=ln_colsum, ln_nparts=ln_nparts, ln_eps=ln_eps,
                             chan_parts=chan_parts, cs_rows=cs_rows, row_parts=row_parts, row_nparts=row_nparts)
+        if hasattr(self.lib, "fyc_gemm_workspace_bytes"):
+            need = int(self.lib.fyc_gemm_workspace_bytes(C.byref(g)))     # split-K scratch (small M, long K)
+            if need > 0:
+                if self._ws is None or self._ws.numel() < need or self._ws.device != a.device:
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+                g.workspace, g.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
         self._call("fyc_gemm", g)
 
     def gemm_row_parts(self, dtype: torch.dtype, *, M: int, N: int, K: int, mode: int = L.GEMM_PLAIN, batch: int = 1, tile: int = 0) -> int:
@@ -109,6 +116,13 @@ class HipOps:
         g.M, g.N, g.K, g.mode, g.batch, g.tile = M, N, K, mode, batch, tile
         g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
         return int(self.lib.fyc_gemm_row_parts(C.byref(g)))
+
+    def gemm_split_bytes(self, dtype: torch.dtype, *, M: int, N: int, K: int, mode: int = L.GEMM_PLAIN) -> int:
+        """scratch bytes a plain LINEAR-epilogue problem of this shape would use for split-K (0: it runs unsplit)"""
+        g = L.GemmArgs()
+        g.M, g.N, g.K, g.mode, g.batch, g.epilogue = M, N, K, mode, 1, L.EPI_LINEAR
+        g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+        return int(self.lib.fyc_gemm_workspace_bytes(C.byref(g)))
 
     def gemm_stat_layout(self, dtype: torch.dtype, *, M: int, N: int, K: int, cs_rows: int, mode: int = L.GEMM_PLAIN, batch: int = 1,
                          tile: int = 0):

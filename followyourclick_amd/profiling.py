@@ -92,6 +92,9 @@ class TimedOps:
     def gemm_stat_layout(self, dtype, **kw):
         return self.inner.gemm_stat_layout(dtype, **kw)
 
+    def gemm_split_bytes(self, dtype, **kw):
+        return self.inner.gemm_split_bytes(dtype, **kw)
+
     def chan_stats_reduce(self, parts, cs, **kw):
         return self._timed("gn_stats", 0.0, 0.0, self.inner.chan_stats_reduce, parts, cs, **kw)
 

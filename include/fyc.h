@@ -38,7 +38,7 @@ const char* fyc_last_error(void);
 int fyc_init(const void* zero_page);
 /* fills caps[0..7]: CU count, LDS bytes/CU, wave size, gfx arch number (950), clock kHz, L2 bytes, 0, 0 */
 int fyc_device_caps(int64_t* caps);
-/* tuning knobs for A/B measurements (0 = automatic): key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
+/* tuning knobs for A/B measurements (0 = automatic): key 0 = 1 disables split-K, key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
  * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
  * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one */
 int fyc_set_tuning(int key, int value);
@@ -105,8 +105,14 @@ typedef struct {
    *    fyc_gemm_row_parts(args).  Consumed through ln_stats / ln_nparts of the next GEMM. */
   float* chan_parts; int32_t cs_rows;
   float* row_parts; int32_t row_nparts;
+  /* Optional scratch for split-K (small M, long K: the 8x8-latent level).  fyc_gemm_workspace_bytes(args) says how much the
+   * problem would like (0: no split); with less, or NULL, the GEMM runs unsplit.  16-byte aligned device memory, contents
+   * undefined before and after the call. */
+  void* workspace; int64_t workspace_bytes;
 } fyc_gemm_args;
 int fyc_gemm(const fyc_gemm_args* a, void* stream);
+/* scratch bytes fyc_gemm can use for these arguments (split-K partial sums); 0 = none needed */
+int64_t fyc_gemm_workspace_bytes(const fyc_gemm_args* a);
 /* number of column tiles fyc_gemm will use for these arguments (M, N, K, mode, dtype, batch, tile are read) = row_nparts */
 int fyc_gemm_row_parts(const fyc_gemm_args* a);
 /* layout of chan_parts for these arguments (also cs_rows is read): returns the number of row tiles, *tile_rows = rows per tile,

@@ -40,7 +40,7 @@ class EmuOps:
     def gemm(self, a, w, out, *, M, N, K, lda, ldw, ldo=0, bias=None, rowbias=None, rows_per_batch=1, residual=None,
              ldr=0, ldrb=0, out_scale=1.0, epilogue=LINEAR, mode=PLAIN, conv=None, batch=1, stride_a=0, stride_w=0, stride_o=0,
              heads=None, tile=0, a2=None, k_split=0, lda2=0, act=0, ln_stats=None, ln_colsum=None, ln_nparts=0, ln_eps=1e-5,
-             chan_parts=None, cs_rows=0, row_parts=None, row_nparts=0):
+             chan_parts=None, cs_rows=0, row_parts=None, row_nparts=0, workspace=None):
         acc_t = self.acc
         if chan_parts is not None or row_parts is not None:
             assert epilogue == LINEAR and batch == 1
@@ -137,6 +137,9 @@ class EmuOps:
                         ld = ld if ld > 0 else T
                         v = _strided(_flat(t), (Bn, H, d, T), (H * d * ld, d * ld, ld, 1), 0)
                         v.copy_(seg.permute(0, 2, 3, 1).to(t.dtype))
+
+    def gemm_split_bytes(self, dtype, *, M, N, K, mode=PLAIN):
+        return 0
 
     def gemm_stat_layout(self, dtype, *, M, N, K, cs_rows, mode=PLAIN, batch=1, tile=0):
         """row tiles of 96 rows: neither a divisor nor a multiple of the usual sample sizes, so samples straddle tiles"""
