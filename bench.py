@@ -50,24 +50,28 @@ def synthetic_inputs(cfg, frames, h, w, seed, device):
     return dict(latents=lat.to(device), first=first.to(device), mask=mask.to(device), text=text.to(device))
 
 
-def cpu_baseline(sd, frames, h, w, ddim_steps):
-    """The oracle (CPU port of the reference math, fp32) on the host cores: ONE of the `ddim_steps`
-    CFG-pair UNet3D forwards at the benchmark shape, extrapolated x ddim_steps."""
+def cpu_baseline(sd, frames, h, w, ddim_steps, sample_frames=2, timed=2):
+    """The oracle (CPU port of the reference math, fp32) on all host cores, per BASELINE.md 3: 1 warm-up + `timed` timed CFG-pair
+    UNet3D forwards (= DDIM steps) at the benchmark resolution, on a BOUNDED sample of `sample_frames` of the clip's frames (the
+    cost is linear in the frame count; a full 16-frame step takes minutes), extrapolated x frames x ddim_steps."""
     from oracle import functional as Fn  # test infrastructure: used only as the reported CPU baseline
     cfg = Fn.UNetConfig()
     g = torch.Generator().manual_seed(1)
-    total_frames, frames = frames, min(frames, 2)   # bounded sample: 2 of the clip's frames (cost is linear in frames)
+    total_frames, frames = frames, min(frames, sample_frames)
     x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g)
     text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
     cores = torch.get_num_threads()
-    t0 = time.time()
+    times = []
     with torch.no_grad():
-        Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961), text, fps, flow)
-    dt = time.time() - t0
+        for i in range(1 + timed):
+            t0 = time.time()
+            Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961 - 40 * i), text, fps, flow)
+            times.append(time.time() - t0)
+    dt = sum(times[1:]) / timed
     return dict(value=frames / (ddim_steps * dt), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 of {ddim_steps} DDIM steps on {frames} of the {total_frames} frames (one CFG-pair UNet3D forward at {h * 8}x{w * 8}, "
-                       f"fp32 oracle, {dt:.1f}s measured); frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
+                sample=f"1 warm-up ({times[0]:.1f}s) + {timed} timed DDIM steps (mean {dt:.1f}s) on {frames} of the {total_frames} frames: CFG-pair "
+                       f"UNet3D forward at {h * 8}x{w * 8}, fp32 oracle, {cores} threads; frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
 
 
 def main():
@@ -81,6 +85,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ip-tokens", type=int, default=0, help="configs[4]: IP-Adapter decoupled cross-attention with this many image tokens")
     ap.add_argument("--vae", action="store_true", help="also time the VAE decode of the final latents (outside the metric)")
+    ap.add_argument("--graph", action="store_true", help="replay DDIM steps 1..n-1 from one captured hipGraph (A/B vs eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -117,7 +122,8 @@ def main():
         ip = torch.randn(2, args.ip_tokens, cfg.cross_attention_dim, generator=torch.Generator().manual_seed(4000)).to(device)
 
     def run(c):
-        return sampler.sample(c["latents"], c["text"], args.ddim_steps, 8.0, c["first"], c["mask"], fps=[2], flow=[4], ip_tokens=ip)
+        return sampler.sample(c["latents"], c["text"], args.ddim_steps, 8.0, c["first"], c["mask"], fps=[2], flow=[4], ip_tokens=ip,
+                              use_graph=True if args.graph else None)
 
     for c in clips[: args.warmup]:
         run(c)
@@ -154,10 +160,16 @@ def main():
         st = sampler.prepare(c["text"], args.ddim_steps, 1, 8.0, [2], [4], ip)
         lat = c["latents"].clone()
         first, mask = c["first"].reshape(1, cfg.in_channels, h * w).contiguous(), c["mask"][:, :, 0].reshape(1, 1, h * w).contiguous()
+        # one untimed instrumented step first (lazy host-side state), then n_inst timed ones.  Each timed step is queued behind
+        # a ~50 ms device-side spin so that the host runs ahead of the GPU: the event pairs then bracket kernel execution only,
+        # not the host's launch gaps (with ~900 ctypes launches per step the host is otherwise the slower side of this pass).
+        sampler.step(st, 0, lat, first, mask)
+        torch.cuda.synchronize()
         timed.reset()
-        n_inst = 2
+        n_inst = 3
         for i in range(n_inst):
-            sampler.step(st, i, lat, first, mask)
+            torch.cuda._sleep(100_000_000)
+            sampler.step(st, 1 + i, lat, first, mask)
         torch.cuda.synchronize()
         summ = timed.summary()
         eng.ops = timed.inner
@@ -171,7 +183,7 @@ def main():
         launches = sum(v["launches"] for v in mm.values())
         ach = fl / (ms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from PMC counters (collected offline with rocprofv3 --pmc, see profiles/)
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tpath) and args.frames == 16 and args.size == 512 and args.dtype == "bf16":
             try:
                 traffic = round(json.load(open(tpath))["families"]["gemm"]["hbm_bytes_per_launch"])
@@ -181,7 +193,7 @@ def main():
         result["roofline"] = {"kernel": "fyc_gemm_kernel (MFMA GEMM + implicit-GEMM conv3x3)", "bound": "mfma",
                               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                               "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": traffic,
-                              "traffic_note": "avg HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r01_hbm_traffic.json",
+                              "traffic_note": "avg HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r02_hbm_traffic.json",
                               "algorithmic_bytes_per_launch": round(alg_bytes),
                               "launches_per_ddim_step": launches // n_inst, "avg_launch_us": round(1e3 * ms / launches, 2),
                               "algorithmic_tflop_per_ddim_step": round(fl / n_inst / 1e12, 3)}

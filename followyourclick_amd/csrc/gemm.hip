@@ -96,7 +96,7 @@ void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
 // K slices per output tile (1 = no split) and the tile config a split problem uses
 int split_of(const fyc_gemm_args* a, int& cfg) {
   if (a->dtype != FYC_BF16 || a->epilogue != FYC_EPI_LINEAR || a->act != FYC_ACT_NONE || a->batch > 1 || a->tile != 0 || g_fyc_tuning[1] > 0 || g_fyc_tuning[0] == 1) return 1;
-  if (a->ln_stats != nullptr || a->chan_parts != nullptr || a->row_parts != nullptr || a->a2 != nullptr) return 1;
+  if (a->ln_stats != nullptr || a->chan_parts != nullptr || a->row_parts != nullptr) return 1;
   if (a->M > 4096 || a->K < 2048 || a->N % 8 != 0 || a->N < 256) return 1;
   const int c = (a->N % 320 == 0) ? 6 : 1;                     // 128x320 or 128x128 tiles
   const int bn = (c == 6) ? 320 : 128;

@@ -1,10 +1,10 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) into per-kernel-family HBM bytes per
-launch -> profiles/r01_hbm_traffic.json, which bench.py reports as roofline.traffic.
+launch -> profiles/r02_hbm_traffic.json, which bench.py reports as roofline.traffic.
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT/pmc_fetch -o f -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-roofline
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT/pmc_write -o w -- python bench.py ... (same)
-    python tools/hbm_traffic.py OUT/pmc_fetch OUT/pmc_write profiles/r01_hbm_traffic.json
+    python tools/hbm_traffic.py OUT/pmc_fetch OUT/pmc_write profiles/r02_hbm_traffic.json
 
 Units (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
 reads, so it is doubled; WRITE_SIZE is uncalibrated (taken as is)."""
@@ -15,7 +15,8 @@ import os
 import sys
 
 FAMILIES = (("fyc_gemm_kernel", "gemm"), ("fyc_attn_kernel", "attention"), ("tattn", "attn_temporal"), ("gn_stats", "gn_stats"),
-            ("gn_apply", "gn_apply"), ("layernorm", "row_stats"), ("concat", "concat"))
+            ("chan_stats_reduce", "gn_stats"), ("gn_apply", "gn_apply"), ("layernorm", "row_stats"), ("concat", "concat"),
+            ("splitk_finish", "gemm_splitk_finish"))
 
 
 def family(name: str) -> str:
