@@ -328,11 +328,41 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
 #pragma unroll
       for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
       int cur_slot = -1;
-      auto flush_cols = [&]() {
+      // Same-address LDS float atomics serialise at the latency of the add (measured: 16 atomics per lane with rpp lanes per
+      // address cost the N = 320 layers +60 us per launch).  A tile inside ONE sample (the common case: cs_rows % BM == 0)
+      // keeps its sums in registers for the whole pass and adds the rpp lanes that hold one chunk through the wave's staging
+      // slice (flush_tree); a shuffle tree did the same but its 16 live values pushed loader state of the K loop into scratch.  Tiles that span samples (8x8 frames) flush per sample
+      // with the plain per-lane atomics: few, small launches, and the code stays compact (it is inlined per 16-row block).
+      const bool one_slot = p.cs_slots == 1;
+      const int rows_live = rpp < 16 ? rpp : 16;        // lanes with lrow >= 16 never store
+      auto flush_cols = [&]() {                         // spanning tiles
         if (do_cs && lact && cur_slot >= 0) {
           float* dst = cacc + ((cur_slot * BN) + nl_w0 + j0 * 16 + lch * 8) * 2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { lds_add(dst + 2 * e, cs8[e]); lds_add(dst + 2 * e + 1, cq8[e]); cs8[e] = cq8[e] = 0.f; }
+        }
+      };
+      auto flush_tree = [&]() {                         // once per pass; every lane of the wave gets here
+        // the wave's staging slice is idle here: lanes park their 8 sums in it ([lrow][lch][8] = lane * 8 floats), then one
+        // lane per column adds the rows_live entries of its column - no same-address atomics, a handful of registers
+        float* red = reinterpret_cast<float*>(stg);
+        const int ncol = cpr * 8;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          if (lact && lrow < rows_live) {
+            const float* src = ph ? cq8 : cs8;
+            *reinterpret_cast<f32x4*>(red + lane * 8) = (f32x4){src[0], src[1], src[2], src[3]};
+            *reinterpret_cast<f32x4*>(red + lane * 8 + 4) = (f32x4){src[4], src[5], src[6], src[7]};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+          for (int c = lane; c < ncol; c += 64) {
+            float t = 0.f;
+#pragma unroll 1
+            for (int r = 0; r < rows_live; ++r) t += red[r * ncol + c];
+            lds_add(cacc + (nl_w0 + j0 * 16 + c) * 2 + ph, t);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
       };
       // residual rows of a 16-row block are fetched one block ahead (the kernel has one workgroup per CU: nothing else would
@@ -394,7 +424,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (do_cs) {                                     // sample slot of this 16-row block (wave-uniform)
+        if (do_cs && !one_slot) {                        // sample slot of this 16-row block (wave-uniform)
           const int slot = (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample;
           if (slot != cur_slot) { flush_cols(); cur_slot = slot; }
         }
@@ -405,6 +435,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           const int row = r0 + lrow, ch = lch;
           const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
           const int n = o_w0 + j0 * 16 + ch * 8;
+          float rs = 0.f, rq = 0.f;                      // this lane's share of row `row` (row statistics)
           if (lact && row < 16 && m < p.M && n < n_out) {
             float v[8];
             *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
@@ -432,20 +463,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
               }
             }
             if (do_rp) {
-              float rs = 0.f, rq = 0.f;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float x0 = __uint_as_float(pk[e] << 16), x1 = __uint_as_float(pk[e] & 0xffff0000u);
                 rs += x0 + x1; rq = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, rq));
               }
-              float* dst = racc + ((wm * WTM + i) * 16 + row) * 2;
-              lds_add(dst, rs); lds_add(dst + 1, rq);
             }
+          }
+          if (do_rp && lact && row < 16 && m < p.M && n < n_out) {
+            float* dst = racc + ((wm * WTM + i) * 16 + row) * 2;
+            lds_add(dst, rs); lds_add(dst + 1, rq);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      flush_cols();
+      if (do_cs) {
+        if (one_slot) flush_tree(); else flush_cols();
+      }
     }
     if (do_cs || do_rp) stats_flush<BM, BN, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
     return;

@@ -1,0 +1,78 @@
+"""Where do the small-K linears lose time inside the pipeline?  Times the engine's K=320 / 640 GEMM calls as the UNet issues
+them (LayerNorm fold, per-frame row bias, fused output statistics, residual) against the bare GEMM, with the operands either
+re-used every launch (Infinity-Cache hot, what tools/gemm_bench.py measures) or rotated over enough buffers to come from HBM.
+usage (GPU box): python tools/gemm_probe.py > gpurun_out/gemm_probe.txt"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from followyourclick_amd import ops
+
+T = torch.bfloat16
+DEV = torch.device("cuda:0")
+
+
+def run(h, M, N, K, *, epi=0, res=False, ln=False, rowbias=False, stats=False, nb=1, tile=0, reps=6):
+    ocols = N // 2 if epi == 1 else N
+    sets = []
+    for _ in range(nb):
+        a = torch.randn(M, K, device=DEV).to(T)
+        out = torch.empty(M, ocols, dtype=T, device=DEV)
+        r = torch.randn(M, N, device=DEV).to(T) if res else None
+        sets.append((a, out, r))
+    w = (torch.randn(N, K, device=DEV) / K ** 0.5).to(T)
+    bias = torch.randn(N, device=DEV)
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=ocols, ldr=N, epilogue=epi, bias=bias, tile=tile)
+    if ln:
+        kw["ln_stats"] = torch.rand(M, 2, device=DEV) + 0.5
+        kw["ln_colsum"] = torch.randn(N, device=DEV)
+    if rowbias:
+        kw["rowbias"] = torch.randn(32, N, device=DEV)
+        kw["rows_per_batch"] = M // 32
+    if stats:
+        n, tr, sl = h.gemm_stat_layout(T, M=M, N=N, K=K, cs_rows=M // 32)
+        kw["chan_parts"] = torch.empty(n * sl * N * 2, device=DEV)
+        kw["cs_rows"] = M // 32
+    for i in range(2 * nb):
+        a, out, r = sets[i % nb]
+        h.gemm(a, w, out, residual=r, **kw)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(reps * nb):
+        a, out, r = sets[i % nb]
+        h.gemm(a, w, out, residual=r, **kw)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) / (reps * nb) * 1e3
+    return us, 2.0 * M * N * K / us / 1e6
+
+
+def main():
+    h = ops.get()
+    h.ensure_init(DEV)
+    cases = [
+        ("temporal QKV L0", 131072, 960, 320, dict(), [dict(), dict(ln=True), dict(ln=True, rowbias=True)]),
+        ("FF1 GEGLU L0", 131072, 2560, 320, dict(epi=1), [dict(), dict(ln=True)]),
+        ("to_out L0", 131072, 320, 320, dict(res=True), [dict(), dict(stats=True)]),
+        ("attn2 Q L0", 131072, 320, 320, dict(), [dict(), dict(ln=True)]),
+        ("temporal QKV L1", 32768, 1920, 640, dict(), [dict(), dict(ln=True, rowbias=True)]),
+        ("FF1 GEGLU L1", 32768, 5120, 640, dict(epi=1), [dict(), dict(ln=True)]),
+        ("to_out L1", 32768, 640, 640, dict(res=True), [dict()]),
+        ("FF1 GEGLU L2", 8192, 10240, 1280, dict(epi=1), [dict(), dict(ln=True)]),
+    ]
+    tiles = [int(t) for t in os.environ.get("PROBE_TILES", "0").split(",")]
+    for name, M, N, K, base, variants in cases:
+        for v in variants:
+            for tile in tiles:
+                row = []
+                for nb in (1, 8):
+                    us, tf = run(h, M, N, K, nb=nb, tile=tile, **base, **v)
+                    row.append(f"{'hot' if nb == 1 else 'cold'} {us:7.1f} us {tf:6.0f} TF")
+                tag = ",".join(k for k in v) or "bare"
+                print(f"{name:18s} M={M} N={N} K={K} tile={tile} [{tag:12s}]  " + "   ".join(row), flush=True)
+                torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
