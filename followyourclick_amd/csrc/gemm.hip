@@ -52,9 +52,13 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // LDS ring, not the MFMA rate, bounds this kernel, so the widest tile that still fills the chip wins.
   ns = 2;
   if (p.N % 320 == 0) {
-    // N = 320, K <= 320 (one column tile, 5 K tiles, HBM-bound with its residual): two independent 4-wave blocks per CU (config 8,
-    // 64-byte K tiles) overlap one block's epilogue with the other's loads - 432 vs 372 (6) / 348 (5) TFLOP/s, profiles/r02_gemm_sweep_stagger.txt
-    if (p.M >= 16384) cfg = (p.N == 320 && p.K <= 320 && p.mode == FYC_GEMM_PLAIN) ? 8 : 5;
+    // One or two column tiles per row and a short K loop (N = 320, K <= 320; N = 640, K <= 640): the epilogue is most of the
+    // tile, and 128-row tiles give every CU twice as many epilogues to overlap with the next tile's fill.  Measured with the
+    // operands coming from HBM and the epilogue features the UNet uses (tools/gemm_probe.py, profiles/r02_gemm_probe_cold_sweep.txt):
+    // 95 (config 6) vs 111 (8) / 122 (5) us at M = 131072, N = K = 320 + residual, 67 vs 75 (5) at M = 32768, N = K = 640; the
+    // Infinity-Cache-hot sweep had ranked 8 first.  (Shape-only rule: fyc_gemm_stat_layout must predict the tile from M, N, K.)
+    const bool short_k = p.mode == FYC_GEMM_PLAIN && (p.N == 320 || p.N == 640) && p.K <= p.N;
+    if (p.M >= 16384) cfg = short_k ? 6 : 5;
     else if (p.M >= 4096) cfg = (p.N >= 5120) ? 5 : 6;
     else cfg = 2;
   } else if (p.N % 256 == 0 && p.M >= 16384) {
