@@ -401,8 +401,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
             const f32x4 bh = *reinterpret_cast<const f32x4*>(colc + nl), bg = *reinterpret_cast<const f32x4*>(colc + nl + 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { hv[r] += bh[r]; gv[r] += bg[r]; }
-            v[0] = hv[0] * gelu_erf_f(gv[0]); v[1] = hv[1] * gelu_erf_f(gv[1]);
-            v[2] = hv[2] * gelu_erf_f(gv[2]); v[3] = hv[3] * gelu_erf_f(gv[3]);
+            if constexpr (sizeof(T) == 2) {              // bf16 outputs: polynomial gate (fyc_common.h::geglu_pair)
+              const f32x2 lo = geglu_pair((f32x2){hv[0], hv[1]}, (f32x2){gv[0], gv[1]}), hi = geglu_pair((f32x2){hv[2], hv[3]}, (f32x2){gv[2], gv[3]});
+              v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+            } else {
+              v[0] = hv[0] * gelu_erf_f(gv[0]); v[1] = hv[1] * gelu_erf_f(gv[1]);
+              v[2] = hv[2] * gelu_erf_f(gv[2]); v[3] = hv[3] * gelu_erf_f(gv[3]);
+            }
           } else {
             const int n = n_w0 + jo * 16 + g * 4;
             v = acc[i][jo];
