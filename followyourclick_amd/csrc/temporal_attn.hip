@@ -49,7 +49,24 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
       kf[ft][ks] = *reinterpret_cast<const bf16x8*>(ok ? base + fr * fstride + C + dd : zero);
     }
   }
-  // V^T fragments: lane (dv = 16*t + r16, quad g): k-slot j<4 <-> frame 4g+j, j>=4 <-> frame 16+4g+(j-4)
+  // V^T fragments: lane (dv = 16*t + r16, quad g): k-slot j<4 <-> frame 4g+j, j>=4 <-> frame 16+4g+(j-4).  The operand wants
+  // the FRAMES of one channel in a lane while memory has the channels of one frame contiguous: V rows are fetched like Q / K
+  // (16 B per lane) and transposed through a wave-private LDS tile (2-byte gathers straight from global memory were 12-24
+  // narrow requests per lane and held the kernel at 3.0 TB/s).  Row pitch DP + 8 elements: the four frame groups of a read
+  // land 16 banks apart.
+  __shared__ __attribute__((aligned(16))) unsigned short vsh[4][NFT * 16][DP + 8];
+  unsigned short (*vt)[DP + 8] = vsh[threadIdx.x >> 6];
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft) {
+    const int fr = ft * 16 + r16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int dd = 32 * ks + 8 * g;
+      const bool ok = fr < F && dd < p.d;
+      *reinterpret_cast<bf16x8*>(&vt[fr][dd]) = *reinterpret_cast<const bf16x8*>(ok ? base + fr * fstride + 2 * C + dd : zero);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // same wave wrote and reads: LDS ops of a wave complete in order
   bf16x8 vf[DVT];
 #pragma unroll
   for (int t = 0; t < DVT; ++t) {
@@ -58,8 +75,8 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int fr = (j < 4) ? 4 * g + j : 16 + 4 * g + (j - 4);
-      const bool ok = dv < p.d && fr < F && (j < 4 || NFT > 1);
-      e[j] = ok ? *reinterpret_cast<const unsigned short*>(base + fr * fstride + 2 * C + dv) : (unsigned short)0;
+      const bool ok = dv < DP && (j < 4 || NFT > 1);     // rows >= F and channels >= d hold zeros
+      e[j] = ok ? vt[fr][dv] : (unsigned short)0;
     }
     u32x4 pk;
 #pragma unroll
