@@ -118,6 +118,14 @@ class PatchifyArgs(C.Structure):
     _fields_ = [("image", vp), ("out", vp), ("B", i32), ("Cin", i32), ("H", i32), ("W", i32), ("P", i32), ("ld", i32), ("dtype", i32)]
 
 
+class PackConv3x3Args(C.Structure):
+    _fields_ = [("w", vp), ("out", vp), ("O", i32), ("I", i32), ("dtype", i32)]
+
+
+class PackGegluArgs(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("w_out", vp), ("b_out", vp), ("O", i32), ("I", i32), ("dtype", i32)]
+
+
 # name -> args struct for every `int fyc_<op>(const args*, void* stream)` entry point
 OPS = {
     "fyc_gemm": GemmArgs, "fyc_attention": AttnArgs, "fyc_temporal_attention": TAttnArgs,
@@ -127,6 +135,7 @@ OPS = {
     "fyc_cfg_ddim_step": CfgDdimArgs, "fyc_nchw_to_nhwc": NchwInArgs, "fyc_nhwc_to_nchw": NhwcOutArgs,
     "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs, "fyc_row_stats": RowStatsArgs,
     "fyc_gn_apply_cs": GnApplyCsArgs, "fyc_chan_stats_reduce": ChanStatsReduceArgs,
+    "fyc_pack_conv3x3": PackConv3x3Args, "fyc_pack_geglu": PackGegluArgs,
 }
 MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes"]
 

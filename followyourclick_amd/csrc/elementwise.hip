@@ -128,6 +128,33 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__
   }
 }
 
+// (O, I, 3, 3) f32 -> [O][slab][tap][c in slab] (see include/fyc.h): one thread per output element
+template <typename T>
+__global__ void __launch_bounds__(256) pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int I, int Ip, int slab) {
+  const long long total = (long long)O * 9 * Ip;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % (9 * Ip));
+    const long long o = i / (9 * Ip);
+    const int sl = k / (9 * slab), r = k - sl * 9 * slab, tap = r / slab, c = sl * slab + (r - tap * slab);
+    ElemIO<T>::st(out + i, c < I ? w[(o * I + c) * 9 + tap] : 0.f);
+  }
+}
+
+// value rows [0, O/2) and gate rows [O/2, O) interleaved in blocks of 16 (weight and bias)
+template <typename T>
+__global__ void __launch_bounds__(256) pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ wo,
+                                                         float* __restrict__ bo, int O, int I) {
+  const long long total = (long long)O * I;
+  const int half = O / 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int col = (int)(i % I), row = (int)(i / I);
+    const int blk = row >> 5, in = row & 31;
+    const int src = (in < 16) ? blk * 16 + in : half + blk * 16 + (in - 16);
+    ElemIO<T>::st(wo + i, w[(long long)src * I + col]);
+    if (col == 0 && b != nullptr) bo[row] = b[src];
+  }
+}
+
 inline int grid_for(long long n) {
   long long b = ceil_div64(n, 256);
   return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -298,5 +325,30 @@ extern "C" int fyc_patchify(const fyc_patchify_args* a, void* stream) {
          hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->image, (bf16_t*)a->out, a->B, a->Cin, a->H, a->W, a->P, a->ld),
          hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->image, (float*)a->out, a->B, a->Cin, a->H, a->W, a->P, a->ld));
   FYC_CHECK_LAUNCH("fyc_patchify");
+  return 0;
+}
+
+extern "C" int fyc_pack_conv3x3(const fyc_pack_conv3x3_args* a, void* stream) {
+  FYC_REQUIRE(a && a->w && a->out && a->O > 0 && a->I > 0, "fyc_pack_conv3x3: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int Ip = (a->I + 63) / 64 * 64;
+  const long long n = (long long)a->O * 9 * Ip;
+  FYC_DT(a,
+         hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->w, (bf16_t*)a->out, a->O, a->I, Ip, 64),
+         hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->w, (float*)a->out, a->O, a->I, Ip, 32));
+  FYC_CHECK_LAUNCH("fyc_pack_conv3x3");
+  return 0;
+}
+
+extern "C" int fyc_pack_geglu(const fyc_pack_geglu_args* a, void* stream) {
+  FYC_REQUIRE(a && a->w && a->w_out && a->O > 0 && a->I > 0, "fyc_pack_geglu: bad args");
+  FYC_REQUIRE(a->O % 32 == 0, "fyc_pack_geglu: O=%d must be a multiple of 32 (16 value + 16 gate rows per block)", a->O);
+  FYC_REQUIRE((a->b == nullptr) == (a->b_out == nullptr), "fyc_pack_geglu: bias in and out must both be given or both be null");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)a->O * a->I;
+  FYC_DT(a,
+         hipLaunchKernelGGL(pack_geglu_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->w, a->b, (bf16_t*)a->w_out, a->b_out, a->O, a->I),
+         hipLaunchKernelGGL(pack_geglu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->w, a->b, (float*)a->w_out, a->b_out, a->O, a->I));
+  FYC_CHECK_LAUNCH("fyc_pack_geglu");
   return 0;
 }

@@ -256,6 +256,19 @@ class HipOps:
         a.image, a.out, a.B, a.Cin, a.H, a.W, a.P, a.ld, a.dtype = _p(image), _p(out), B, Cin, H, W, P, ld, _dt(out)
         self._call("fyc_patchify", a)
 
+    def pack_conv3x3(self, w: Tensor, out: Tensor) -> None:
+        """(O, I, 3, 3) f32 on the device -> the K order of the implicit-GEMM conv (engine/weights.py::pack_conv3x3)"""
+        a = L.PackConv3x3Args()
+        a.w, a.out, a.O, a.I, a.dtype = _f32(w, "w"), _p(out), w.shape[0], w.shape[1], _dt(out)
+        self._call("fyc_pack_conv3x3", a)
+
+    def pack_geglu(self, w: Tensor, b: Optional[Tensor], w_out: Tensor, b_out: Optional[Tensor]) -> None:
+        """ff.net.0.proj rows -> 16 value rows, their 16 gate rows, ... (engine/weights.py::pack_geglu)"""
+        a = L.PackGegluArgs()
+        a.w, a.b, a.w_out, a.b_out = _f32(w, "w"), _f32(b, "b"), _p(w_out), _f32(b_out, "b_out")
+        a.O, a.I, a.dtype = w.shape[0], w.shape[1], _dt(w_out)
+        self._call("fyc_pack_geglu", a)
+
     def silu_f32(self, x: Tensor, y: Tensor) -> None:
         a = L.SiluArgs()
         a.x, a.y, a.n = _f32(x, "x"), _f32(y, "y"), x.numel()

@@ -281,6 +281,18 @@ int fyc_embed_tokens(const fyc_embed_args* a, void* stream);
 typedef struct { const float* image; void* out; int32_t B, Cin, H, W, P, ld; int32_t dtype; } fyc_patchify_args;
 int fyc_patchify(const fyc_patchify_args* a, void* stream);
 
+/* ---- weight layouts fyc_gemm expects (one-time, at load): the state-dict tensors of the reference, f32 on the device --------
+ * fyc_pack_conv3x3: Conv2d / InflatedConv3d weight (O, I, 3, 3) (animatediff/models/resnet.py:20-27; diffusers resnet.py Conv2d)
+ *   -> [O][slab][ky][kx][c in slab], one slab = 128 bytes of input channels (64 bf16 / 32 f32), I zero-padded to a multiple
+ *   of 64: the K order of FYC_GEMM_CONV3X3 (ldw = 9 * pad64(I)).
+ * fyc_pack_geglu: GEGLU projection ff.net.0.proj (diffusers/models/attention.py:819-821: rows [0, O/2) value, [O/2, O) gate)
+ *   -> blocks of 16 value rows followed by their 16 gate rows (weight, cast to `dtype`) and the same order for the f32 bias:
+ *   the column order FYC_EPI_GEGLU consumes.  O % 32 == 0. */
+typedef struct { const float* w; void* out; int32_t O, I; int32_t dtype; } fyc_pack_conv3x3_args;
+int fyc_pack_conv3x3(const fyc_pack_conv3x3_args* a, void* stream);
+typedef struct { const float* w; const float* b; void* w_out; float* b_out; int32_t O, I; int32_t dtype; } fyc_pack_geglu_args;
+int fyc_pack_geglu(const fyc_pack_geglu_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

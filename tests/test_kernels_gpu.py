@@ -468,6 +468,27 @@ def test_embed_tokens_and_patchify(hip, emu, dt):
         hip.patchify(img.cuda(), p_h, B=B, Cin=3, H=28, W=42, P=16, ld=1024)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_weight_packers_match_the_host_packers(hip, dt):
+    """fyc_pack_conv3x3 / fyc_pack_geglu (the layouts fyc_gemm expects, for hosts without torch) == engine/weights.py, bit for bit"""
+    from followyourclick_amd.engine import weights as Wt
+    T = DT[dt]
+    for O, I in ((32, 4), (64, 320), (16, 100)):                     # I = 4: the latent conv_in; 100: padding inside a slab
+        w = rnd((O, I, 3, 3), torch.float32, O + I)
+        ref = Wt.pack_conv3x3(w, T, "cpu")
+        out = torch.full(ref.shape, float("nan"), dtype=T, device="cuda")
+        hip.pack_conv3x3(w.cuda(), out)
+        assert torch.equal(out.cpu(), ref), (O, I)
+    for O, I in ((64, 40), (2560, 320)):
+        w, b = rnd((O, I), torch.float32, 7), rnd((O,), torch.float32, 8)
+        rw, rb = Wt.pack_geglu(w, b, T, "cpu")
+        ow, ob = torch.empty(O, I, dtype=T, device="cuda"), torch.empty(O, device="cuda")
+        hip.pack_geglu(w.cuda(), b.cuda(), ow, ob)
+        assert torch.equal(ow.cpu(), rw) and torch.equal(ob.cpu(), rb), (O, I)
+    with pytest.raises(Exception, match="multiple of 32"):
+        hip.pack_geglu(torch.zeros(48, 8, device="cuda"), None, torch.empty(48, 8, dtype=T, device="cuda"), None)
+
+
 # ---- LayerNorm folded into the consuming GEMM ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("rows,C", [(300, 320), (64, 64), (1000, 1280), (33, 640)])
