@@ -2,6 +2,7 @@
 production precision, by executing the REAL reference (container only; TEST INFRASTRUCTURE).
 
     python -m oracle.make_golden_full small      # F=4, 16x16 latent, one forward            (~1 min)
+    python -m oracle.make_golden_full ip         # the same forward with the IP-Adapter branch (16 image tokens)
     python -m oracle.make_golden_full vae        # AutoencoderKL.decode, (128,256,512,512), 16x16 latent
     python -m oracle.make_golden_full p2         # AnimationPipeline.prepare_latents (init-latents blend / interpolate noise)
     python -m oracle.make_golden_full cfg1       # BASELINE configs[0]: 8 frames 256x256, 5 DDIM steps, full pipeline
@@ -66,6 +67,35 @@ def small():
     np.savez_compressed(os.path.join(OUT, "unet_full_small_fwd.npz"), out_f32=y32.numpy(), out_bf16=y16.numpy(), drift=np.float64(d),
                         timestep=np.int64(961), fps=fps.numpy(), flow=flow.numpy(), weight_seed=np.int64(0), input_seed=np.int64(31),
                         frames=np.int64(4), h=np.int64(16), w=np.int64(16))
+
+
+def ip():
+    """full-width UNet3D forward WITH the IP-Adapter branch (BASELINE configs[4]: 16 image tokens).  The reference's CPU code path
+    (no xformers) runs attn2 with softmax temperature = the IP weight (IPCrossAttention.__init__ overwrites `scale`, SURVEY.md
+    headline 6): the golden pins oracle.functional with `ip_reference_cpu_scale_quirk=True`; the engine implements the deployed
+    (xformers) semantics and is held to the oracle without the quirk (tests/test_fullwidth_gpu.py)."""
+    cfg = Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7, ip_reference_cpu_scale_quirk=True)
+    unet = ref_unet(cfg).eval()
+    sd = W.make_weights(W.unet_state_shapes(cfg), seed=0)
+    unet.load_state_dict(sd, strict=True)
+
+    class Proj(torch.nn.Module):
+        def forward(self, feat):
+            return feat
+    unet.image_proj_model = Proj()
+    inp = W.seeded_inputs(cfg, 1, 4, 16, 16, seed=33)
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    kw = dict(use_fps_condition=True, fps_tensor=fps, flow_control=flow, use_ip_cross_attention=True, reference_images_clip_feat=inp["ip_tokens"])
+    with torch.no_grad():
+        y32 = unet(x9, torch.tensor(961), inp["text"], **kw).sample
+        with CudaAutocastOnCpu(torch.bfloat16):
+            y16 = unet(x9, torch.tensor(961), inp["text"], **kw).sample.float()
+    d = rel(y16, y32)
+    log(f"ip: drift bf16-autocast vs f32 = {d:.3e}")
+    np.savez_compressed(os.path.join(OUT, "unet_full_ip_fwd.npz"), out_f32=y32.numpy(), out_bf16=y16.numpy(), drift=np.float64(d),
+                        timestep=np.int64(961), fps=fps.numpy(), flow=flow.numpy(), weight_seed=np.int64(0), input_seed=np.int64(33),
+                        frames=np.int64(4), h=np.int64(16), w=np.int64(16), ip_scale=np.float64(0.7), ip_num_tokens=np.int64(16))
 
 
 def vae():
@@ -189,6 +219,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     for part in sys.argv[1:]:
         log("==", part)
-        dict(small=small, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2)[part]()
+        dict(small=small, ip=ip, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2)[part]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

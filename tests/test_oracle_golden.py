@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import functional as Fn
@@ -72,6 +73,22 @@ def test_unet_forward_tiny_ip(golden_dir):
     with torch.no_grad():
         y = Fn.unet3d_forward(sd, cfg, g["sample"], torch.tensor(961), g["text"], g["fps"], g["flow"], g["ip_tokens"])
     assert (y - g["out"]).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("ip", [False, True])
+def test_unet_forward_full_width(golden_dir, ip):
+    """SD-1.5 widths (320/640/1280/1280, ctx 768, head dims 40/80/160), F=4, 16x16 latent, the real reference's f32 output
+    (oracle/make_golden_full.py small / ip).  The IP golden is of the reference's CPU code path (attn2 temperature quirk)."""
+    g = _load(golden_dir, "unet_full_ip_fwd.npz" if ip else "unet_full_small_fwd.npz")
+    cfg = Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7, ip_reference_cpu_scale_quirk=True) if ip else Fn.UNetConfig()
+    sd = W.make_weights(W.unet_state_shapes(cfg), int(g["weight_seed"]))
+    inp = W.seeded_inputs(cfg, 1, int(g["frames"]), int(g["h"]), int(g["w"]), seed=int(g["input_seed"]))
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    with torch.no_grad():
+        y = Fn.unet3d_forward(sd, cfg, x9, torch.tensor(int(g["timestep"])), inp["text"], g["fps"], g["flow"], inp["ip_tokens"] if ip else None)
+    ref = g["out_f32"]
+    assert (torch.linalg.norm(y - ref) / torch.linalg.norm(ref)).item() < 2e-5
+    assert (y - ref).abs().max().item() < 1e-4
 
 
 def test_vae_decode_tiny(golden_dir):
