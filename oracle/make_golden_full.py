@@ -25,7 +25,7 @@ from . import functional as Fn
 from . import refshim, stubs
 from . import weights as W
 from .autocast_emul import CudaAutocastOnCpu
-from .make_golden import MM_KW, OUT, ref_unet, ref_vae
+from .make_golden import OUT, ref_unet, ref_vae
 
 SKW = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
            clip_sample=False, prediction_type="v_prediction", rescale_betas_zero_snr=True)
