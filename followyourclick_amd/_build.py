@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libfyc_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "temporal_block.hip", "norm.hip", "elementwise.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file and every
 # kernel here fits in 256 registers), which removes the v_accvgpr_read/write traffic around the
 # softmax rescale and the epilogues (312 -> 0 such moves in the attention main loop).

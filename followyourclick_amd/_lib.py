@@ -118,6 +118,12 @@ class PatchifyArgs(C.Structure):
     _fields_ = [("image", vp), ("out", vp), ("B", i32), ("Cin", i32), ("H", i32), ("W", i32), ("P", i32), ("ld", i32), ("dtype", i32)]
 
 
+class TemporalBlockArgs(C.Structure):
+    _fields_ = [("x", vp), ("out", vp), ("w_qkv", vp), ("colsum", vp), ("bias", vp), ("pe_bias", vp), ("w_out", vp), ("b_out", vp),
+                ("clips", i32), ("frames", i32), ("pixels", i32), ("heads", i32), ("d", i32), ("C", i32),
+                ("scale", C.c_float), ("eps", C.c_float), ("dtype", i32)]
+
+
 class PackConv3x3Args(C.Structure):
     _fields_ = [("w", vp), ("out", vp), ("O", i32), ("I", i32), ("dtype", i32)]
 
@@ -135,9 +141,9 @@ OPS = {
     "fyc_cfg_ddim_step": CfgDdimArgs, "fyc_nchw_to_nhwc": NchwInArgs, "fyc_nhwc_to_nchw": NhwcOutArgs,
     "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs, "fyc_row_stats": RowStatsArgs,
     "fyc_gn_apply_cs": GnApplyCsArgs, "fyc_chan_stats_reduce": ChanStatsReduceArgs,
-    "fyc_pack_conv3x3": PackConv3x3Args, "fyc_pack_geglu": PackGegluArgs,
+    "fyc_pack_conv3x3": PackConv3x3Args, "fyc_pack_geglu": PackGegluArgs, "fyc_temporal_block": TemporalBlockArgs,
 }
-MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes"]
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_temporal_block_supported"]
 
 _lib = None
 
@@ -168,6 +174,9 @@ def load() -> C.CDLL:
         lib.fyc_gemm_stat_layout.restype = C.c_int
         lib.fyc_gemm_workspace_bytes.argtypes = [C.POINTER(GemmArgs)]
         lib.fyc_gemm_workspace_bytes.restype = i64
+    if not ab_build or hasattr(lib, "fyc_temporal_block_supported"):
+        lib.fyc_temporal_block_supported.argtypes = [C.POINTER(TemporalBlockArgs)]
+        lib.fyc_temporal_block_supported.restype = C.c_int
     for name, st in OPS.items():
         if ab_build and not hasattr(lib, name):
             continue

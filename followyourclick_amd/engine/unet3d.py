@@ -26,13 +26,14 @@ from .. import _lib as L
 from .. import ops as ops_mod
 from .base import EngineBase
 from .config import UNet3DConfig
-from .weights import Packed
+from .weights import Packed, pack_temporal_block
 
 Tensor = torch.Tensor
 
 # Statistics of an activation are accumulated by the epilogue of the GEMM / conv that writes it (fyc_gemm chan_stats / row_parts)
 # instead of by a read pass per GroupNorm / LayerNorm.  FYC_FUSE_STATS=0 restores the separate passes (A/B measurements).
 FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
+FUSE_TEMPORAL = os.environ.get("FYC_FUSE_TEMPORAL", "1") != "0"   # fyc_temporal_block: one kernel per temporal attention sub-block (C = 320 level)
 FUSE_ROWS = os.environ.get("FYC_FUSE_ROWS", "0") != "0"      # the LayerNorm half (row_parts): measured slower than the separate fyc_row_stats pass (profiles/r02_stats_fusion_ab.txt), off by default
 
 
@@ -369,6 +370,14 @@ class UNet3DEngine(EngineBase):
         tok = self._lin_rp(h, m.pin_w, rows, bias=m.pin_b)
         for bi, blk in enumerate(m.blocks):
             for a in blk.attns:
+                if FUSE_TEMPORAL and a.qkv_f is not None and o.temporal_block_supported(self.dtype, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d):
+                    cache = a.setdefault("_tblock", {})      # per-head operands, packed once per clip length
+                    if g["F"] not in cache:
+                        cache[g["F"]] = pack_temporal_block(a, Hm, g["F"])
+                    out = self.new(rows, C)
+                    o.temporal_block(tok.t, out, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5, **cache[g["F"]])
+                    tok = Act(out, C)
+                    continue
                 if a.qkv_f is not None:     # LayerNorm folded into the QKV projection, positional table as a per-frame row bias
                     w, b, cs = a.qkv_f
                     qkv = self.new(rows, 3 * C)

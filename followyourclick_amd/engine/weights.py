@@ -190,6 +190,31 @@ def _motion(sd, p: str, cfg: UNet3DConfig, dtype, device) -> Packed:
                   blocks=blocks)
 
 
+def pack_temporal_block(att: Packed, heads: int, frames: int) -> dict:
+    """per-head operands of fyc_temporal_block (csrc/temporal_block.hip) from a packed temporal attention block with the
+    LayerNorm folded in (`qkv_f`): w_qkv [H][128][C] (q | k | v rows of the head, zero padded), colsum / bias [H][128],
+    pe_bias [F][H][128], w_out [H][C][48] (Wo[:, head's 40 columns], zero padded), b_out [C]"""
+    w, b, cs = att.qkv_f
+    C = w.shape[1]
+    d = C // heads
+    assert 3 * d <= 128 and d <= 48
+
+    def per_head(t: Tensor) -> Tensor:          # leading axis 3C = [q | k | v] x (head, d)  ->  [H][128][...]
+        out = torch.zeros(heads, 128, *t.shape[1:], dtype=t.dtype, device=t.device)
+        for i in range(3):
+            out[:, i * d:(i + 1) * d] = t[i * C:(i + 1) * C].reshape(heads, d, *t.shape[1:])
+        return out.contiguous()
+
+    pe = None
+    if att.pe_w is not None:
+        if frames > att.pe_w.shape[0]:
+            raise ValueError(f"video_length {frames} exceeds the positional table ({att.pe_w.shape[0]})")
+        pe = per_head(att.pe_w[:frames].t().contiguous()).permute(2, 0, 1).contiguous()       # [F][H][128]
+    wo = torch.zeros(heads, C, 48, dtype=att.o_w.dtype, device=att.o_w.device)
+    wo[:, :, :d] = att.o_w.reshape(C, heads, d).permute(1, 0, 2)
+    return dict(w_qkv=per_head(w), colsum=per_head(cs), bias=per_head(b), pe_bias=pe, w_out=wo.contiguous(), b_out=att.o_b)
+
+
 def sinusoidal_pe(channels: int, length: int) -> Tensor:
     """pe[p, 2i] = sin(p * exp(-2i ln(1e4)/C)), pe[p, 2i+1] = cos(...) (reference motion_module.py:295-301)."""
     import math

@@ -190,6 +190,31 @@ class HipOps:
                                                                                   heads, d, scale, _dt(qkv))
         self._call("fyc_temporal_attention", a)
 
+    def _tblock_args(self, x, out, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels, heads, d, scale, eps):
+        a = L.TemporalBlockArgs()
+        a.x, a.out, a.w_qkv, a.w_out = _p(x), _p(out), _p(w_qkv), _p(w_out)
+        a.colsum, a.bias, a.pe_bias, a.b_out = _f32(colsum, "colsum"), _f32(bias, "bias"), _f32(pe_bias, "pe_bias"), _f32(b_out, "b_out")
+        a.clips, a.frames, a.pixels, a.heads, a.d, a.C = clips, frames, pixels, heads, d, heads * d
+        a.scale, a.eps, a.dtype = scale, eps, _dt(x)
+        return a
+
+    def temporal_block_supported(self, dtype: torch.dtype, *, clips: int, frames: int, pixels: int, heads: int, d: int) -> bool:
+        """does fyc_temporal_block (the fused temporal sub-block) cover this shape?  (no launch)"""
+        if not hasattr(self.lib, "fyc_temporal_block_supported"):
+            return False
+        a = L.TemporalBlockArgs()
+        a.clips, a.frames, a.pixels, a.heads, a.d, a.C = clips, frames, pixels, heads, d, heads * d
+        a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+        return bool(self.lib.fyc_temporal_block_supported(C.byref(a)))
+
+    def temporal_block(self, x: Tensor, out: Tensor, *, w_qkv: Tensor, colsum: Tensor, bias: Tensor, pe_bias: Optional[Tensor],
+                       w_out: Tensor, b_out: Tensor, clips: int, frames: int, pixels: int, heads: int, d: int, scale: float,
+                       eps: float = 1e-5) -> None:
+        """out = x + Attn_F(LayerNorm(x) + pe) Wo^T + bo in one kernel (csrc/temporal_block.hip)"""
+        self.ensure_init(x.device)
+        self._call("fyc_temporal_block", self._tblock_args(x, out, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels,
+                                                           heads, d, scale, eps))
+
     # -- normalisation -----------------------------------------------------------------------
     def gn_stats(self, x: Tensor, stats: Tensor, *, rows: int, C_: int, groups: int, rows_per_sample: int) -> None:
         a = L.GnStatsArgs()

@@ -95,6 +95,14 @@ class TimedOps:
     def gemm_split_bytes(self, dtype, **kw):
         return self.inner.gemm_split_bytes(dtype, **kw)
 
+    def temporal_block_supported(self, dtype, **kw):
+        return self.inner.temporal_block_supported(dtype, **kw)
+
+    def temporal_block(self, x, out, **kw):
+        rows, C = kw["clips"] * kw["frames"] * kw["pixels"], kw["heads"] * kw["d"]
+        return self._timed("temporal_block", 2.0 * rows * C * 4 * C + 4.0 * rows * kw["frames"] * C, 2.0 * rows * C * _esize(x),
+                           self.inner.temporal_block, x, out, **kw)
+
     def chan_stats_reduce(self, parts, cs, **kw):
         return self._timed("gn_stats", 0.0, 0.0, self.inner.chan_stats_reduce, parts, cs, **kw)
 

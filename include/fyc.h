@@ -281,6 +281,26 @@ int fyc_embed_tokens(const fyc_embed_args* a, void* stream);
 typedef struct { const float* image; void* out; int32_t B, Cin, H, W, P, ld; int32_t dtype; } fyc_patchify_args;
 int fyc_patchify(const fyc_patchify_args* a, void* stream);
 
+/* ---- fused temporal self-attention sub-block (motion_module.py:270-283, 371-464) -------------------------------------------
+ * out = x + Attn_F(LayerNorm(x) + pe) Wo^T + bo for token rows x [(clip, frame, pixel)][C], attention over the frame axis at
+ * every pixel: replaces fyc_row_stats + fyc_gemm(to_q|k|v, LayerNorm folded) + fyc_temporal_attention + fyc_gemm(to_out, +x)
+ * with one read and one write of x.  Weights are per head:
+ *   w_qkv [heads][128][C]  rows 0..d-1 = gamma-scaled to_q rows of the head, d..2d-1 to_k, 2d..3d-1 to_v, rest zero
+ *   colsum, bias [heads][128] f32 (sum_k gamma_k W[n][k];  beta W^T + b),  pe_bias [frames][heads][128] f32 = pe_f W^T or NULL
+ *   w_out [heads][C][48]   Wo[n][head*d + k] for k < d, zero for k >= d;  b_out [C] f32
+ * Built for dtype bf16, C = 320, 8 heads of 40, 16 frames, pixels % 8 == 0 (fyc_temporal_block_supported says so without
+ * launching); x and out must not alias. */
+typedef struct {
+  const void* x; void* out;
+  const void* w_qkv; const float* colsum; const float* bias; const float* pe_bias;
+  const void* w_out; const float* b_out;
+  int32_t clips, frames, pixels, heads, d, C;
+  float scale, eps;
+  int32_t dtype;
+} fyc_temporal_block_args;
+int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream);
+int fyc_temporal_block_supported(const fyc_temporal_block_args* a);
+
 /* ---- weight layouts fyc_gemm expects (one-time, at load): the state-dict tensors of the reference, f32 on the device --------
  * fyc_pack_conv3x3: Conv2d / InflatedConv3d weight (O, I, 3, 3) (animatediff/models/resnet.py:20-27; diffusers resnet.py Conv2d)
  *   -> [O][slab][ky][kx][c in slab], one slab = 128 bytes of input channels (64 bf16 / 32 f32), I zero-padded to a multiple

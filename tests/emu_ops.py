@@ -195,6 +195,32 @@ class EmuOps:
         O = torch.matmul(P, v).permute(0, 3, 1, 2, 4).reshape(clips * frames * pixels, Cc)
         _flat(o)[: O.numel()].reshape(O.shape).copy_(O.to(o.dtype))
 
+    def temporal_block_supported(self, dtype, *, clips, frames, pixels, heads, d):
+        """the shapes libfyc_hip.so's kernel is built for (csrc/temporal_block.hip); `temporal_block` itself is a
+        specification for any head layout that fits the operand packing (3 d <= 128, d <= 48)"""
+        return dtype == torch.bfloat16 and heads == 8 and d == 40 and frames == 16 and pixels % 8 == 0
+
+    def temporal_block(self, x, out, *, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels, heads, d, scale, eps=1e-5):
+        """out = x + Attn_F(LayerNorm(x) + pe) Wo^T + bo from the per-head operands of engine/weights.py::pack_temporal_block
+        (LayerNorm folded: rstd (x W'^T - mean colsum) + bias); q|k|v, the probabilities and the attention output are rounded to
+        the storage dtype where the kernel stores them"""
+        acc_t, T = self.acc, x.dtype
+        Cc = heads * d
+        X = _flat(x)[: clips * frames * pixels * Cc].reshape(clips, frames, pixels, Cc).to(acc_t)
+        mean = X.mean(-1, keepdim=True)
+        rstd = (X.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+        a = torch.einsum("bfpc,hnc->bfphn", X, w_qkv.to(acc_t))
+        qkv = rstd[..., None] * (a - mean[..., None] * colsum.to(acc_t)) + bias.to(acc_t)
+        if pe_bias is not None:
+            qkv = qkv + pe_bias.to(acc_t)[None, :, None]
+        qkv = qkv.to(T).to(acc_t)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:3 * d]                  # b f p h d
+        S = torch.einsum("bfphd,bgphd->bphfg", q, k) * scale
+        P = S.softmax(dim=-1).to(T).to(acc_t)
+        O = torch.einsum("bphfg,bgphd->bfphd", P, v).to(T).to(acc_t)
+        y = X + torch.einsum("bfphk,hnk->bfpn", O, w_out.to(acc_t)[:, :, :d]) + b_out.to(acc_t)
+        _flat(out)[: y.numel()].reshape(y.shape).copy_(y.to(out.dtype))
+
     # ------------------------------------------------------------------------------------
     def gn_stats(self, x, stats, *, rows, C_, groups, rows_per_sample):
         xs = _flat(x)[: rows * C_].reshape(rows // rows_per_sample, rows_per_sample, groups, C_ // groups).double()

@@ -44,6 +44,39 @@ def test_unet_forward_matches_golden(golden_dir, dtype, tol):
     assert rel < tol, rel
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_unet_forward_with_fused_temporal_blocks(golden_dir, dtype, tol, monkeypatch):
+    """FYC_FUSE_TEMPORAL: every temporal attention sub-block goes through `temporal_block` with the per-head operands of
+    weights.pack_temporal_block (q|k|v gather per head, positional bias per frame, output projection slices) - same golden"""
+    from followyourclick_amd.engine import unet3d
+    monkeypatch.setattr(unet3d, "FUSE_TEMPORAL", True)
+    calls = []
+
+    class Spy(EmuOps):
+        def temporal_block_supported(self, dtype, **kw):      # the tiny widths are outside the kernel's shapes: force the path
+            return True
+
+        def temporal_block(self, *a, **kw):
+            calls.append(kw["pixels"])
+            return super().temporal_block(*a, **kw)
+
+        def temporal_attention(self, *a, **kw):
+            raise AssertionError("the unfused temporal attention must not run")
+    g = _load(golden_dir, "unet_tiny_fwd.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), dtype, "cpu"), ops=Spy())
+    x9 = g["sample"]
+    B, C9, F, H, Wd = x9.shape
+    x = torch.zeros(B * F * H * Wd, 64)
+    x[:, :C9] = x9.permute(0, 2, 3, 4, 1).reshape(-1, C9)
+    eng.prepare_context(g["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), B)
+    out = eng.forward(x.to(dtype), temb, B, F, H, Wd).float().reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    rel = ((out - g["out"]).norm() / g["out"].norm()).item()
+    assert rel < tol, rel
+    assert len(calls) >= 2 * 9                         # two attention blocks per motion module
+
+
 def test_unet_forward_odd_size(golden_dir):
     g = _load(golden_dir, "unet_tiny_odd_fwd.npz")
     sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"]))

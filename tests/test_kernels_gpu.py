@@ -286,6 +286,43 @@ def test_temporal_attention(hip, emu, dt, clips, F, P, H, d):
     close(o_h, o_e, f"tattn {dt} F{F} P{P} d{d}", 6e-3 if dt == "bf16" else 2e-5)
 
 
+@pytest.mark.parametrize("with_pe", [True, False])
+@pytest.mark.parametrize("clips,P", [(2, 64), (1, 8), (3, 4096)])
+def test_temporal_block_fused(hip, emu, clips, P, with_pe):
+    """fyc_temporal_block (row statistics + LayerNorm-folded QKV + attention over frames + output projection + residual in
+    one kernel) against the torch specification on the per-head operands of engine/weights.py::pack_temporal_block"""
+    from followyourclick_amd.engine.weights import Packed, pack_temporal_block
+    T, H, d, F = torch.bfloat16, 8, 40, 16
+    C = H * d
+    att = Packed(qkv_f=((rnd((3 * C, C), torch.float32, 1) * C ** -0.5).to(T), rnd((3 * C,), torch.float32, 2) * 0.1, None),
+                 pe_w=rnd((24, 3 * C), torch.float32, 3) * 0.5 if with_pe else None,
+                 o_w=(rnd((C, C), torch.float32, 4) * C ** -0.5).to(T), o_b=rnd((C,), torch.float32, 5) * 0.1)
+    att["qkv_f"] = (att.qkv_f[0], att.qkv_f[1], att.qkv_f[0].float().sum(dim=1))
+    ops_e = pack_temporal_block(att, H, F)
+    ops_h = {k: (v.cuda() if v is not None else None) for k, v in ops_e.items()}
+    x = (rnd((clips * F * P, C), torch.float32, 6) * 1.5 + 0.3).to(T)
+    kw = dict(clips=clips, frames=F, pixels=P, heads=H, d=d, scale=d ** -0.5)
+    shape = dict(clips=clips, frames=F, pixels=P, heads=H, d=d)
+    assert hip.temporal_block_supported(T, **shape)
+    assert not hip.temporal_block_supported(T, **dict(shape, pixels=P + 1)) and not hip.temporal_block_supported(torch.float32, **shape)
+    o_h = torch.full((clips * F * P, C), float("nan"), dtype=T, device="cuda")
+    hip.temporal_block(x.cuda(), o_h, **ops_h, **kw)
+    torch.cuda.synchronize()
+    if P > 64:                                           # the specification on a slice of the pixels (tiles are independent)
+        sel = torch.arange(0, P, 61)[:8]
+        xs = x.reshape(clips, F, P, C)[:, :, sel].reshape(-1, C)
+        o_e = torch.zeros(clips * F * len(sel), C, dtype=T)
+        emu.temporal_block(xs, o_e, **ops_e, **dict(kw, pixels=len(sel)))
+        o_h = o_h.reshape(clips, F, P, C)[:, :, sel.cuda()].reshape(-1, C)
+    else:
+        o_e = torch.zeros(clips * F * P, C, dtype=T)
+        emu.temporal_block(x, o_e, **ops_e, **kw)
+    close(o_h, o_e, f"temporal block clips{clips} P{P} pe{with_pe}", 6e-3)
+    with pytest.raises(Exception, match="in-place"):
+        xc = x.cuda()
+        hip.temporal_block(xc, xc, **ops_h, **kw)
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("samples,rps,C", [(2, 4 * 64, 320), (8, 64, 64), (2, 16 * 16, 2560), (6, 1, 128), (3, 1000, 960), (2, 37, 1920)])
