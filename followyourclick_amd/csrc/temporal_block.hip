@@ -13,6 +13,8 @@
 // per-frame bias pe_f W^T.  Row order inside the tile: row = pixel * 16 + frame, so a 16-row MFMA block is one pixel.
 //
 // Built for the level where it pays (C = 320, 8 heads of 40, 16 frames, bf16); other shapes keep the unfused schedule.
+#include <mutex>
+
 #include "fyc_common.h"
 
 namespace {
@@ -293,13 +295,17 @@ extern "C" int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream
   p.x = (const bf16_t*)a->x; p.out = (bf16_t*)a->out; p.w_qkv = (const bf16_t*)a->w_qkv; p.colsum = a->colsum; p.bias = a->bias;
   p.pe_bias = a->pe_bias; p.w_out = (const bf16_t*)a->w_out; p.b_out = a->b_out; p.clips = a->clips; p.pixels = a->pixels;
   p.scale_log2e = a->scale * 1.44269504088896340736f; p.eps = a->eps;
-  constexpr int kMaxDev = 64;
-  static bool attr_done[kMaxDev] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
+  {  // dynamic LDS above 64 KB needs the function attribute once per device; one process may drive several GPUs from several threads
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static bool attr_done[kMaxDev] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
+    }
   }
   hipLaunchKernelGGL(temporal_block_kernel, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_temporal_block");
