@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-FAMILIES = (("fyc_gemm_kernel", "gemm"), ("fyc_attn_kernel", "attention"), ("tattn", "attn_temporal"), ("gn_stats", "gn_stats"),
+FAMILIES = (("fyc_gemm_kernel", "gemm"), ("fyc_attn_kernel", "attention"), ("temporal_block", "temporal_block"), ("tattn", "attn_temporal"), ("gn_stats", "gn_stats"),
             ("chan_stats_reduce", "gn_stats"), ("gn_apply", "gn_apply"), ("layernorm", "row_stats"), ("concat", "concat"),
             ("splitk_finish", "gemm_splitk_finish"))
 
