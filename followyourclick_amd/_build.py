@@ -13,12 +13,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libfyc_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "temporal_block.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "temporal_block.hip", "ff_block.hip", "norm.hip", "elementwise.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file and every
 # kernel here fits in 256 registers), which removes the v_accvgpr_read/write traffic around the
 # softmax rescale and the epilogues (312 -> 0 such moves in the attention main loop).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# ff_block.hip runs one wave per SIMD with the whole 512-register file: its 192 accumulator registers must be AGPRs
+AGPR_SOURCES = {"ff_block.hip"}
+
+
+def _flags(src: str):
+    if src in AGPR_SOURCES:
+        return [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form=1")]
+    return FLAGS
 
 
 def _hipcc() -> str:
@@ -33,7 +41,7 @@ def _digest(path: str) -> str:
     for dep in [path, os.path.join(CSRC, "fyc_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "attention_kernel.h"), os.path.join(HERE, "..", "include", "fyc.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(_flags(os.path.basename(path))).encode())
     return h.hexdigest()
 
 
@@ -44,7 +52,7 @@ def _compile(src: str) -> str:
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", path, "-o", obj]
+    cmd = [_hipcc(), *_flags(src), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -124,6 +124,11 @@ class TemporalBlockArgs(C.Structure):
                 ("scale", C.c_float), ("eps", C.c_float), ("dtype", i32)]
 
 
+class FFBlockArgs(C.Structure):
+    _fields_ = [("x", vp), ("residual", vp), ("out", vp), ("wstream", vp), ("b_out", vp), ("chan_parts", vp), ("cs_rows", i32),
+                ("rows", i32), ("C", i32), ("hidden", i32), ("eps", C.c_float), ("dtype", i32)]
+
+
 class PackConv3x3Args(C.Structure):
     _fields_ = [("w", vp), ("out", vp), ("O", i32), ("I", i32), ("dtype", i32)]
 
@@ -142,8 +147,10 @@ OPS = {
     "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs, "fyc_row_stats": RowStatsArgs,
     "fyc_gn_apply_cs": GnApplyCsArgs, "fyc_chan_stats_reduce": ChanStatsReduceArgs,
     "fyc_pack_conv3x3": PackConv3x3Args, "fyc_pack_geglu": PackGegluArgs, "fyc_temporal_block": TemporalBlockArgs,
+    "fyc_ff_block": FFBlockArgs,
 }
-MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_temporal_block_supported"]
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_temporal_block_supported",
+        "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes"]
 
 _lib = None
 
@@ -177,6 +184,11 @@ def load() -> C.CDLL:
     if not ab_build or hasattr(lib, "fyc_temporal_block_supported"):
         lib.fyc_temporal_block_supported.argtypes = [C.POINTER(TemporalBlockArgs)]
         lib.fyc_temporal_block_supported.restype = C.c_int
+    if not ab_build or hasattr(lib, "fyc_ff_block_supported"):
+        lib.fyc_ff_block_supported.argtypes = [C.POINTER(FFBlockArgs)]
+        lib.fyc_ff_block_supported.restype = C.c_int
+        lib.fyc_ff_block_wstream_bytes.argtypes = []
+        lib.fyc_ff_block_wstream_bytes.restype = i64
     for name, st in OPS.items():
         if ab_build and not hasattr(lib, name):
             continue

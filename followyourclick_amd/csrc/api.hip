@@ -3,7 +3,7 @@
 
 thread_local char g_fyc_err[512] = {0};
 const void* g_fyc_zero_page = nullptr;
-int g_fyc_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int g_fyc_tuning[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" int fyc_version(void) { return FYC_VERSION; }
 
@@ -17,7 +17,7 @@ extern "C" int fyc_init(const void* zero_page) {
 }
 
 extern "C" int fyc_set_tuning(int key, int value) {
-  FYC_REQUIRE(key >= 0 && key < 8, "fyc_set_tuning: key %d", key);
+  FYC_REQUIRE(key >= 0 && key < 16, "fyc_set_tuning: key %d", key);
   g_fyc_tuning[key] = value;
   return 0;
 }

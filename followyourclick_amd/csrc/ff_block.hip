@@ -1,0 +1,329 @@
+// One GEGLU feed-forward block of a transformer in ONE kernel (reference diffusers/models/attention.py:772-775 FeedForward,
+// 819-821 GEGLU; called from animatediff/models/attention.py:489-564 BasicTransformerBlock and motion_module.py:270-283
+// TemporalTransformerBlock), merged with the output projection that follows it as engine/weights.py::_ff does:
+//
+//   h   = GEGLU( LN(tok) W1^T + b1 )                       [rows][4C]       (LayerNorm folded: rstd (tok W1'^T - mean colsum) + b1')
+//   out = residual + b_out + [tok | h] [Wp | Wp W2]^T      [rows][C]
+//
+// The unfused schedule (fyc_row_stats, fyc_gemm GEGLU, fyc_gemm dual-K) writes and re-reads the 4C-wide hidden tensor (335 MB
+// each way at the 64x64 level) and runs a K = C GEMM whose epilogue is as long as its MFMA work.  Here the hidden activation never
+// leaves the registers and there is no per-tile epilogue in the main loop:
+//
+//   * a workgroup = 4 wave64 (one per SIMD, the whole 512-register file each) owns 128 token rows, a wave 32 of them for ALL
+//     columns.  Its 32 x C tokens live in registers as MFMA operands for the whole kernel (80 VGPRs): they are the operand of
+//     the projection phase and of all 40 FF1 chunks and the source of the LayerNorm statistics - no statistics pass, no LDS
+//     traffic for the activation side.  The 32 x C output accumulators (160) sit in the accumulator half of the file;
+//   * the weights arrive as one pre-packed stream (engine/weights.py::pack_ff_block): 46 stages of <= 61 KiB, every 1-KiB piece
+//     already in MFMA fragment order (lane l holds W[16 j + (l & 15)][32 s + 8 (l >> 4) .. +8]), so a stage is ONE contiguous
+//     global -> LDS DMA (global_load_lds, 16 B / lane, lane-linear image = conflict-free ds_read_b128 at base + lane * 16) into a
+//     2-deep ring: stages 0-4 = the tok Wp^T projection (2 k-steps each), stage 5 + c = {W1 rows of hidden chunk c (32 units =
+//     2 x (16 value + 16 gate) rows), their colsum / bias, the W2' columns of chunk c - 1};
+//   * per chunk a wave runs 80 MFMAs of FF1 (K = C from registers), the GEGLU gate on its 32 x 32 results - which ARE the MFMA
+//     operand of FF2 as they stand (the k-slots of the W2' fragments are packed in the order the gate outputs sit in the lanes:
+//     no shuffle, no LDS round trip) - and 40 MFMAs of FF2 for the PREVIOUS chunk, so that the gate's VALU work has independent
+//     matrix work beside it.  One barrier per stage;
+//   * epilogue: residual tile by DMA into the (now idle) ring, + bias + accumulators in f32, one rounding to bf16 in LDS, the
+//     tile leaves as a flat 80-KiB copy (16 B / lane); per-(row tile, channel) {sum, sum sq} of the stored values for the
+//     GroupNorm that consumes the block (fyc_gemm's chan_parts layout with tile_rows = 128, one slot).
+//
+// Built for the level where it pays (C = 320, hidden 1280, bf16, rows % 128 == 0); other shapes keep the unfused schedule.
+// Compiled WITHOUT -amdgpu-mfma-vgpr-form (see _build.py): the accumulators must live in AGPRs for the 512-register budget.
+#include <mutex>
+
+#include "fyc_common.h"
+
+namespace {
+
+constexpr int C_ = 320, HID = 1280, ROWS = 128, NT = 256;
+constexpr int KS = C_ / 32;                    // 10 MFMA k-steps over C
+constexpr int NB = C_ / 16;                    // 20 column blocks of the output
+constexpr int CHUNKS = HID / 32;               // 40 hidden chunks of 32 units
+constexpr int PROJ_ST = KS / 2;                // 5 projection stages of 2 k-steps
+constexpr int NSTAGE = PROJ_ST + CHUNKS + 1;   // 46
+constexpr int PIECE = 1024;                    // one MFMA fragment for all 64 lanes
+constexpr int P_CONST = 40, P_W2 = 41, NPIECE = 61, NPIECE_PROJ = 40;
+constexpr int STAGE_BYTES = NPIECE * PIECE;    // 62464
+constexpr int TILE_BYTES = ROWS * C_ * 2;      // 81920: the residual / output tile of the epilogue (overlays the ring)
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+static_assert(TILE_BYTES + 160 * 16 <= LDS_BYTES, "epilogue tile + statistics scratch overlay the ring");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+struct FFP {
+  const bf16_t* x; const bf16_t* res; bf16_t* out;
+  const char* ws;            // packed weight stream, NSTAGE * STAGE_BYTES
+  const float* b_out;        // [C]
+  float* parts;              // [rows / 128][C][2] or null
+  float eps;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
+
+// VAR: 0 = the compiler's own schedule of a chunk; 1 = FF1 fragment reads pinned one k-step ahead of the MFMAs that consume them
+// (the compiler already deals the GEGLU gate's VALU work out between the FF2 MFMAs: a wave alone on its SIMD overlaps VALU with
+// the matrix pipe only where they alternate in program order)
+template <int VAR>
+__global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const long long row0 = (long long)blockIdx.x * ROWS;
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  auto issue = [&](int t) {                                   // DMA of stage t into slot t & 1: piece q by wave q % 4
+    const int np = t < PROJ_ST ? NPIECE_PROJ : NPIECE;
+    const char* src = p.ws + (long long)t * STAGE_BYTES;     // wave-uniform base + one 32-bit lane offset: no per-piece address registers
+    char* dst = smem + (t & 1) * STAGE_BYTES;
+#pragma unroll 1
+    for (int q = wave; q < np; q += 4) glds16(src + q * PIECE + lane16, dst + q * PIECE);
+  };
+
+  // ---- the wave's 32 token rows as MFMA operands: lane (row r16, quad g) holds x[row][32 s + 8 g .. +8] ---------------------
+  bf16x8 xa[2][KS];
+  {
+    const bf16_t* xr = p.x + (row0 + wave * 32 + r16) * C_ + g * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const bf16x8*>(xr + i * 16 * C_ + s * 32);
+  }
+  issue(0);
+
+  // LayerNorm statistics of the lane's two rows (two-pass, in registers; the four quads of a row meet through xor 16 / 32)
+  float mu[2], rs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += __uint_as_float(t[e] << 16) + __uint_as_float(t[e] & 0xffff0000u);
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float m = s * (1.0f / C_);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = __uint_as_float(t[e] << 16) - m, b = __uint_as_float(t[e] & 0xffff0000u) - m;
+        q = __builtin_fmaf(a, a, q);
+        q = __builtin_fmaf(b, b, q);
+      }
+    }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    mu[i] = m;
+    rs[i] = rsqrtf(q * (1.0f / C_) + p.eps);
+  }
+
+  f32x4 oacc[2][NB];                                          // out rows 16 i + r16, columns 16 j + 4 g .. +4
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) oacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- projection: out = tok Wp^T, stage t = k-steps 2t, 2t + 1 of all 20 column blocks ---------------------------------------
+#pragma unroll
+  for (int t = 0; t < PROJ_ST; ++t) {
+    __syncthreads();                                          // stage t landed (the barrier drains the DMA queue); slot (t+1)&1 is free
+    issue(t + 1);
+    const char* sl = smem + (t & 1) * STAGE_BYTES + lane16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const bf16x8 wf = frag(sl, s * NB + j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, xa[i][2 * t + s], oacc[i][j]);
+      }
+  }
+
+  // ---- hidden chunks -----------------------------------------------------------------------------------------------------------
+  // FF1 of chunk c: pre-activations of the chunk's 64 W1 rows (q = 2 * half + {value, gate}) for the wave's 32 rows
+  auto ff1 = [&](const char* sl, f32x4 (&ha)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ha[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (VAR == 1) {
+      // the four fragments of k-step s + 1 are requested before the eight MFMAs of k-step s are issued (pinned: left alone the
+      // compiler reads two fragments, waits, issues four MFMAs - the LDS round trip then sits on the matrix pipe's critical path)
+      bf16x8 w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = frag(sl, q);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 n[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) n[q] = (s + 1 < KS) ? frag(sl, (s + 1) * 4 + q) : w[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) ha[i][q] = mfma(w[q], xa[i][s], ha[i][q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = n[q];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bf16x8 wf = frag(sl, s * 4 + q);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) ha[i][q] = mfma(wf, xa[i][s], ha[i][q]);
+        }
+    }
+  };
+  // GEGLU on the pre-activations: k-slots 8 g + e of the FF2 operand = hidden unit 4 g + e of half 0 (e < 4), of half 1 (e >= 4)
+  auto gate = [&](const char* base, const f32x4 (&ha)[2][4], bf16x8 (&hb)[2]) {
+    const float* cst = reinterpret_cast<const float*>(base + P_CONST * PIECE);    // [colsum 64 | bias 64] of the chunk's 64 W1 rows
+    f32x4 cs[4], bi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cs[q] = *reinterpret_cast<const f32x4*>(cst + q * 16 + g * 4); bi[q] = *reinterpret_cast<const f32x4*>(cst + 64 + q * 16 + g * 4); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 v, gt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = rs[i] * (ha[i][2 * h][r] - mu[i] * cs[2 * h][r]) + bi[2 * h][r];
+          gt[r] = rs[i] * (ha[i][2 * h + 1][r] - mu[i] * cs[2 * h + 1][r]) + bi[2 * h + 1][r];
+        }
+        const f32x2 lo = geglu_pair((f32x2){v[0], v[1]}, (f32x2){gt[0], gt[1]}), hi = geglu_pair((f32x2){v[2], v[3]}, (f32x2){gt[2], gt[3]});
+        f[2 * h] = pack_bf16x2(lo.x, lo.y);
+        f[2 * h + 1] = pack_bf16x2(hi.x, hi.y);
+      }
+      hb[i] = __builtin_bit_cast(bf16x8, f);
+    }
+  };
+  auto ff2 = [&](const char* sl, const bf16x8 (&hb)[2]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bf16x8 wf = frag(sl, P_W2 + j);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, hb[i], oacc[i][j]);
+    }
+  };
+
+  f32x4 ha[2][4];
+  bf16x8 hb[2], hn[2];
+  __syncthreads();                                            // stage 5 (chunk 0) landed
+  issue(PROJ_ST + 1);
+  ff1(smem + (PROJ_ST & 1) * STAGE_BYTES + lane16, ha);
+  gate(smem + (PROJ_ST & 1) * STAGE_BYTES, ha, hb);
+  for (int c = 1; c < CHUNKS; ++c) {
+    const int t = PROJ_ST + c;
+    __syncthreads();                                          // stage t landed; slot (t+1)&1 free
+    issue(t + 1);
+    const char* base = smem + (t & 1) * STAGE_BYTES;
+    ff1(base + lane16, ha);                                   // 80 MFMAs
+    gate(base, ha, hn);                                       // VALU, beside ...
+    ff2(base + lane16, hb);                                   // ... the 40 MFMAs of the previous chunk's FF2
+    hb[0] = hn[0];
+    hb[1] = hn[1];
+  }
+  __syncthreads();                                            // last stage: W2' of chunk 39 only
+  ff2(smem + ((NSTAGE - 1) & 1) * STAGE_BYTES + lane16, hb);
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+  __syncthreads();                                            // every wave is done with the ring
+  if (p.res != nullptr) {                                     // the 128 residual rows are one contiguous 80 KiB: flat DMA
+    const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);
+#pragma unroll 1
+    for (int q = wave; q < TILE_BYTES / PIECE; q += 4) glds16(src + q * PIECE + lane16, smem + q * PIECE);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      bf16_t* a = reinterpret_cast<bf16_t*>(smem + (wave * 32 + i * 16 + r16) * (C_ * 2)) + j * 16 + g * 4;
+      const f32x4 bo = *reinterpret_cast<const f32x4*>(p.b_out + j * 16 + g * 4);
+      float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+      if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = oacc[i][j][r] + bo[r] + rr[r];
+      ElemIO<bf16_t>::st4(a, v);
+    }
+  __syncthreads();
+  {
+    char* dst = reinterpret_cast<char*>(p.out + row0 * C_);
+    for (int idx = tid; idx < TILE_BYTES / 16; idx += NT) *reinterpret_cast<u32x4*>(dst + idx * 16) = *reinterpret_cast<const u32x4*>(smem + idx * 16);
+  }
+  if (p.parts != nullptr && tid < 160) {                      // column statistics of the values as stored: one thread per column pair
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    const char* src = smem + tid * 4;
+#pragma unroll 8
+    for (int r = 0; r < ROWS; ++r) {
+      const unsigned u = *reinterpret_cast<const unsigned*>(src + r * (C_ * 2));
+      const float x0 = __uint_as_float(u << 16), x1 = __uint_as_float(u & 0xffff0000u);
+      s0 += x0; q0 = __builtin_fmaf(x0, x0, q0);
+      s1 += x1; q1 = __builtin_fmaf(x1, x1, q1);
+    }
+    *reinterpret_cast<f32x4*>(p.parts + ((long long)blockIdx.x * C_ + 2 * tid) * 2) = (f32x4){s0, q0, s1, q1};
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t fyc_ff_block_wstream_bytes(void) { return (int64_t)NSTAGE * STAGE_BYTES; }
+
+extern "C" int fyc_ff_block_supported(const fyc_ff_block_args* a) {
+  if (a == nullptr || a->dtype != FYC_BF16 || a->C != C_ || a->hidden != HID || a->rows <= 0 || a->rows % ROWS != 0) return 0;
+  if (a->chan_parts != nullptr && (a->cs_rows <= 0 || a->cs_rows % ROWS != 0 || a->rows % a->cs_rows != 0)) return 0;
+  static std::mutex mu;                            // LDS per CU of this process's device (one GPU per process), queried once
+  static int64_t lds_cap = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (lds_cap < 0) {
+      int64_t caps[8];
+      lds_cap = (fyc_device_caps(caps) == 0) ? caps[1] : 0;
+    }
+  }
+  if (lds_cap > 0 && lds_cap < LDS_BYTES) return 0;   // a device / partition mode with less LDS: the caller keeps the unfused schedule
+  return 1;
+}
+
+extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
+  FYC_REQUIRE(a && a->x && a->out && a->wstream && a->b_out, "fyc_ff_block: null pointer");
+  FYC_REQUIRE(fyc_ff_block_supported(a), "fyc_ff_block: built for bf16, C=320, hidden=1280, rows %% 128 == 0, cs_rows %% 128 == 0 and >= %d B of LDS (got C=%d hidden=%d rows=%d cs_rows=%d)",
+              LDS_BYTES, a->C, a->hidden, a->rows, a->cs_rows);
+  FYC_REQUIRE(a->x != a->out, "fyc_ff_block: out must not alias x");
+  FYC_REQUIRE(((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->out % 16) == 0 && ((uintptr_t)a->wstream % 16) == 0 && ((uintptr_t)a->b_out % 16) == 0 &&
+              ((uintptr_t)a->residual % 16) == 0 && ((uintptr_t)a->chan_parts % 16) == 0, "fyc_ff_block: operands must be 16-byte aligned");
+  FFP p;
+  p.x = (const bf16_t*)a->x; p.res = (const bf16_t*)a->residual; p.out = (bf16_t*)a->out; p.ws = (const char*)a->wstream;
+  p.b_out = a->b_out; p.parts = a->chan_parts; p.eps = a->eps;
+  {  // dynamic LDS above 64 KB needs the function attribute once per device; one process may drive several GPUs from several threads
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static bool attr_done[kMaxDev] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) FYC_FAIL(-3, "fyc_ff_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
+      if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
+    }
+  }
+  if (g_fyc_tuning[8] == 1) hipLaunchKernelGGL(ff_block_kernel<0>, dim3((unsigned)(a->rows / ROWS)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ff_block_kernel<1>, dim3((unsigned)(a->rows / ROWS)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  FYC_CHECK_LAUNCH("fyc_ff_block");
+  return 0;
+}

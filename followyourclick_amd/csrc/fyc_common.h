@@ -19,7 +19,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // ---- error plumbing (host) ----------------------------------------------------------------
 extern thread_local char g_fyc_err[512];
 extern const void* g_fyc_zero_page;
-extern int g_fyc_tuning[8];  // [1] forced GEMM tile config, [2] forced ring depth, [3] attention variant, [4] GEMM tile-order strip width (-1 = row-major)
+extern int g_fyc_tuning[16];  // [1] forced GEMM tile config, [2] forced ring depth, [3] attention variant, [4] GEMM tile-order strip width (-1 = row-major)
 
 #define FYC_FAIL(code, ...)                                   \
   do {                                                        \

@@ -26,7 +26,7 @@ from .. import _lib as L
 from .. import ops as ops_mod
 from .base import EngineBase
 from .config import UNet3DConfig
-from .weights import Packed, pack_temporal_block
+from .weights import Packed, pack_ff_block, pack_temporal_block
 
 Tensor = torch.Tensor
 
@@ -34,6 +34,7 @@ Tensor = torch.Tensor
 # instead of by a read pass per GroupNorm / LayerNorm.  FYC_FUSE_STATS=0 restores the separate passes (A/B measurements).
 FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
 FUSE_TEMPORAL = os.environ.get("FYC_FUSE_TEMPORAL", "1") != "0"   # fyc_temporal_block: one kernel per temporal attention sub-block (C = 320 level)
+FUSE_FF = os.environ.get("FYC_FUSE_FF", "1") != "0"               # fyc_ff_block: LayerNorm + FF1 + GEGLU + FF2 + output projection in one kernel (C = 320 level)
 FUSE_ROWS = os.environ.get("FYC_FUSE_ROWS", "0") != "0"      # the LayerNorm half (row_parts): measured slower than the separate fyc_row_stats pass (profiles/r02_stats_fusion_ab.txt), off by default
 
 
@@ -299,6 +300,21 @@ class UNet3DEngine(EngineBase):
     def feed_forward_out(self, ff: Packed, ln, tok: Act, residual: Optional[Tensor], rows: int, C: int, nxt=None) -> Act:
         """LN -> GEGLU FF -> (+tok) -> output projection (+residual) with FF2 and the projection merged into one GEMM
         over [tok | h] (see weights._ff): returns residual + Wp (tok + W2 h + b2) + bp."""
+        hidden = ff.w1.shape[0] // 2
+        cs_rows = nxt[0] if (nxt and self.fuse_stats) else 0
+        fused = FUSE_FF and ff.cs1 is not None
+        if fused and cs_rows and not self.ops.ff_block_supported(self.dtype, rows=rows, C_=C, hidden=hidden, cs_rows=cs_rows):
+            cs_rows = 0             # frames that are not whole 128-row tiles: the consuming GroupNorm runs its own statistics pass
+        if fused and self.ops.ff_block_supported(self.dtype, rows=rows, C_=C, hidden=hidden, cs_rows=cs_rows):
+            # one kernel: the 4C-wide hidden activation never reaches HBM, the LayerNorm statistics come from the token registers
+            if "_wstream" not in ff:
+                ff["_wstream"] = pack_ff_block(ff)
+            out = self.new(rows, C)
+            parts = torch.empty(rows // 128 * C * 2, dtype=torch.float32, device=self.device) if cs_rows else None
+            self.ops.ff_block(tok.t, residual, out, wstream=ff["_wstream"], b_out=ff.po_b, rows=rows, C_=C, hidden=hidden,
+                              chan_parts=parts, cs_rows=cs_rows)
+            cs = self._cs_finish((parts, 128, 1), rows, nxt[0], C, nxt[1]) if cs_rows else None
+            return Act(out, C, cs, nxt[1] if cs_rows else 0)
         if ff.cs1 is not None:      # LayerNorm folded into FF1: statistics from the producer of tok (or one statistics pass)
             N1 = ff.w1.shape[0]
             hmid = self.new(rows, N1 // 2)

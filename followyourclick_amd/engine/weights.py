@@ -215,6 +215,55 @@ def pack_temporal_block(att: Packed, heads: int, frames: int) -> dict:
     return dict(w_qkv=per_head(w), colsum=per_head(cs), bias=per_head(b), pe_bias=pe, w_out=wo.contiguous(), b_out=att.o_b)
 
 
+def ff_block_layout(C: int, hidden: int):
+    """(stages, pieces per stage, projection stages, index of the constants piece) of the fyc_ff_block weight stream;
+    (46, 61, 5, 40) at the one shape csrc/ff_block.hip is built for (C = 320, hidden = 1280)"""
+    nb, ks, chunks = C // 16, C // 32, hidden // 32
+    pst = (ks + 1) // 2
+    return pst + chunks + 1, max(2 * nb, 4 * ks + 1 + nb), pst, 4 * ks
+
+
+def _mfma_fragments(w: Tensor) -> Tensor:
+    """[..., 16, 32] weight blocks -> [..., 512]: the operand fragment of v_mfma_f32_16x16x32_bf16 in lane order - position
+    8 l + e = block[l & 15][8 (l >> 4) + e] (include/fyc.h, fyc_ff_block)"""
+    lead = w.shape[:-2]
+    return w.reshape(*lead, 16, 4, 8).transpose(-3, -2).reshape(*lead, 512)
+
+
+def pack_ff_block(ff: Packed) -> Tensor:
+    """weight stream of fyc_ff_block (csrc/ff_block.hip) from a packed feed-forward (`_ff`) whose LayerNorm is folded into FF1:
+    stages x pieces x 512 elements (layout: include/fyc.h; 46 x 61 x 1 KiB at C = 320).  The first stages hold the projection of
+    the token half of the merged [Wp | Wp W2] weight (two k-steps each); stage pst + c: W1 rows of hidden chunk c, their colsum /
+    bias (f32), and the W2' columns of chunk c - 1 in the k-slot order the kernel's GEGLU outputs have (slot 8 g + e = unit
+    4 g + e of the chunk's first 16 hidden units for e < 4, of its second 16 for e >= 4)."""
+    w1, b1, cs1, po = ff.w1, ff.b1, ff.cs1, ff.po_w
+    assert cs1 is not None, "fyc_ff_block needs the LayerNorm folded into FF1"
+    C = w1.shape[1]
+    hid = w1.shape[0] // 2
+    assert C % 32 == 0 and hid % 32 == 0 and tuple(po.shape) == (C, C + hid) and w1.dtype == po.dtype
+    nb, ks, chunks = C // 16, C // 32, hid // 32
+    nst, npc, pst, pc = ff_block_layout(C, hid)
+    st = torch.zeros(nst, npc, 512, dtype=w1.dtype, device=w1.device)
+    # projection: piece s_local * nb + j of stage t = Wp[16 j .. +16][32 (2 t + s_local) .. +32]
+    wp = _mfma_fragments(po[:, :C].reshape(nb, 16, ks, 32).permute(2, 0, 1, 3))             # [s][j][512]
+    for s_ in range(ks):
+        st[s_ // 2, (s_ % 2) * nb: (s_ % 2 + 1) * nb] = wp[s_]
+    # FF1: piece s * 4 + q of stage pst + c = W1[64 c + 16 q .. +16][32 s .. +32]
+    f1 = _mfma_fragments(w1.reshape(chunks, 4, 16, ks, 32).permute(0, 3, 1, 2, 4))          # [c][s][q][512]
+    st[pst: pst + chunks, : 4 * ks] = f1.reshape(chunks, 4 * ks, 512)
+    # constants piece: f32 colsum[64] | bias[64] of the chunk's 64 W1 rows (bit pattern of the floats inside a bf16 stream)
+    cst = torch.zeros(chunks, 512 * w1.element_size() // 4, dtype=torch.float32, device=w1.device)
+    cst[:, :64] = cs1.reshape(chunks, 64)
+    cst[:, 64:128] = b1.reshape(chunks, 64)
+    st[pst: pst + chunks, pc] = cst.view(w1.dtype)
+    # FF2: pieces pc + 1 + j of stage pst + c + 1 = W2'[16 j .. +16][k-slots of chunk c]
+    slot_unit = torch.tensor([(4 * (k // 8) + k % 8) if k % 8 < 4 else (16 + 4 * (k // 8) + k % 8 - 4) for k in range(32)], device=w1.device)
+    w2 = po[:, C:].reshape(nb, 16, chunks, 32)[..., slot_unit]                               # [j][16][c][k-slot]
+    f2 = _mfma_fragments(w2.permute(2, 0, 1, 3))                                             # [c][j][512]
+    st[pst + 1: pst + 1 + chunks, pc + 1: pc + 1 + nb] = f2
+    return st.reshape(-1).contiguous()
+
+
 def sinusoidal_pe(channels: int, length: int) -> Tensor:
     """pe[p, 2i] = sin(p * exp(-2i ln(1e4)/C)), pe[p, 2i+1] = cos(...) (reference motion_module.py:295-301)."""
     import math

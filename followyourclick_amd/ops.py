@@ -215,6 +215,33 @@ class HipOps:
         self._call("fyc_temporal_block", self._tblock_args(x, out, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels,
                                                            heads, d, scale, eps))
 
+    def ff_block_supported(self, dtype: torch.dtype, *, rows: int, C_: int, hidden: int, cs_rows: int = 0) -> bool:
+        """does fyc_ff_block (the fused GEGLU feed-forward block) cover this shape?  (no launch); cs_rows > 0: with the fused
+        output statistics for a GroupNorm whose statistics sample has cs_rows rows"""
+        if not hasattr(self.lib, "fyc_ff_block_supported"):
+            return False
+        a = L.FFBlockArgs()
+        a.rows, a.C, a.hidden, a.cs_rows = rows, C_, hidden, cs_rows
+        a.chan_parts = 16 if cs_rows > 0 else None         # only tested for null / alignment by the query
+        a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+        return bool(self.lib.fyc_ff_block_supported(C.byref(a)))
+
+    def ff_block_wstream_bytes(self) -> int:
+        return int(self.lib.fyc_ff_block_wstream_bytes())
+
+    def ff_block(self, x: Tensor, residual: Optional[Tensor], out: Tensor, *, wstream: Tensor, b_out: Tensor, rows: int, C_: int,
+                 hidden: int, eps: float = 1e-5, chan_parts: Optional[Tensor] = None, cs_rows: int = 0) -> None:
+        """out = residual + b_out + [x | GEGLU(LN(x) W1^T + b1)] [Wp | Wp W2]^T in one kernel (csrc/ff_block.hip); `wstream`
+        from engine/weights.py::pack_ff_block"""
+        self.ensure_init(x.device)
+        if wstream.numel() * wstream.element_size() != self.ff_block_wstream_bytes():
+            raise ValueError(f"ff_block: wstream has {wstream.numel() * wstream.element_size()} bytes, expected {self.ff_block_wstream_bytes()}")
+        a = L.FFBlockArgs()
+        a.x, a.residual, a.out, a.wstream, a.b_out = _p(x), _p(residual), _p(out), _p(wstream), _f32(b_out, "b_out")
+        a.chan_parts, a.cs_rows = _f32(chan_parts, "chan_parts"), cs_rows
+        a.rows, a.C, a.hidden, a.eps, a.dtype = rows, C_, hidden, eps, _dt(x)
+        self._call("fyc_ff_block", a)
+
     # -- normalisation -----------------------------------------------------------------------
     def gn_stats(self, x: Tensor, stats: Tensor, *, rows: int, C_: int, groups: int, rows_per_sample: int) -> None:
         a = L.GnStatsArgs()

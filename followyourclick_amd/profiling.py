@@ -103,6 +103,15 @@ class TimedOps:
         return self._timed("temporal_block", 2.0 * rows * C * 4 * C + 4.0 * rows * kw["frames"] * C, 2.0 * rows * C * _esize(x),
                            self.inner.temporal_block, x, out, **kw)
 
+    def ff_block_supported(self, dtype, **kw):
+        return self.inner.ff_block_supported(dtype, **kw)
+
+    def ff_block(self, x, residual, out, **kw):
+        rows, C, hid = kw["rows"], kw["C_"], kw["hidden"]
+        flops = 2.0 * rows * (C * 2 * hid + (C + hid) * C)
+        nbytes = (2 + (residual is not None)) * rows * C * _esize(x) + (C * 2 * hid + (C + hid) * C) * _esize(x)
+        return self._timed("ff_block", flops, nbytes, self.inner.ff_block, x, residual, out, **kw)
+
     def chan_stats_reduce(self, parts, cs, **kw):
         return self._timed("gn_stats", 0.0, 0.0, self.inner.chan_stats_reduce, parts, cs, **kw)
 

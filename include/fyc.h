@@ -40,7 +40,8 @@ int fyc_init(const void* zero_page);
 int fyc_device_caps(int64_t* caps);
 /* tuning knobs for A/B measurements (0 = automatic): key 0 = 1 disables split-K, key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
  * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
- * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one */
+ * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one,
+ * key 8 = 1: fyc_ff_block with the compiler's own instruction schedule (0: FF1 fragment reads pinned one k-step ahead); keys 9..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------
@@ -300,6 +301,37 @@ typedef struct {
 } fyc_temporal_block_args;
 int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream);
 int fyc_temporal_block_supported(const fyc_temporal_block_args* a);
+
+/* ---- fused GEGLU feed-forward block (diffusers/models/attention.py:772-775, 819-821; animatediff/models/attention.py:489-564;
+ *      motion_module.py:270-283) ------------------------------------------------------------------------------------------
+ *   h   = GEGLU( LayerNorm(x) W1^T + b1 )                      [rows][hidden]
+ *   out = residual + b_out + [x | h] [Wp | Wp W2]^T            [rows][C]        (FF2 merged with the block's output projection)
+ * replaces fyc_row_stats + fyc_gemm(FYC_EPI_GEGLU, LayerNorm folded) + fyc_gemm(a2 = h) - the hidden activation never leaves
+ * the CU, x is read once.  `wstream` is the pre-packed weight stream (fyc_ff_block_wstream_bytes() bytes, 16-byte aligned):
+ * 46 stages x 61 pieces x 1 KiB, a piece = one MFMA operand fragment of a 16 x 32 weight block B in lane order (byte 16 l of
+ * the piece = B[l & 15][8 (l >> 4) .. +8], bf16):
+ *   stage t < 5      pieces s * 20 + j (s = 0, 1; j < 20): Wp rows 16 j .. +16, columns 32 (2 t + s) .. +32  (Wp = merged weight [:, :C])
+ *   stage 5 + c      pieces s * 4 + q (s < 10; q < 4): rows 64 c + 16 q .. +16 of the LayerNorm-folded, GEGLU-packed W1
+ *                    (fyc_pack_geglu order: 16 value rows, their 16 gate rows, ...), columns 32 s .. +32;
+ *                    piece 40: f32 colsum[64] | bias[64] of those 64 rows (rest of the piece unused);
+ *                    pieces 41 + j (j < 20), for c >= 1: rows 16 j .. +16 of W2' = merged weight [:, C:], k-slot 8 g + e =
+ *                    hidden unit 32 (c - 1) + 4 g + e (e < 4) or 32 (c - 1) + 16 + 4 g + e - 4 (e >= 4)
+ *   stage 45         pieces 41 + j: the same for hidden chunk 39.
+ * (engine/weights.py::pack_ff_block builds it.)  chan_parts (optional): [rows / 128][C][2] f32 = per 128-row tile and channel
+ * {sum, sum of squares} of the values as stored - fyc_gemm's chan_parts layout with tile_rows = 128 and one slot, for
+ * fyc_chan_stats_reduce; needs cs_rows % 128 == 0.  Built for dtype bf16, C = 320, hidden = 1280, rows % 128 == 0
+ * (fyc_ff_block_supported says so without launching); out must not alias x. */
+typedef struct {
+  const void* x; const void* residual; void* out;
+  const void* wstream; const float* b_out;
+  float* chan_parts; int32_t cs_rows;
+  int32_t rows, C, hidden;
+  float eps;
+  int32_t dtype;
+} fyc_ff_block_args;
+int fyc_ff_block(const fyc_ff_block_args* a, void* stream);
+int fyc_ff_block_supported(const fyc_ff_block_args* a);
+int64_t fyc_ff_block_wstream_bytes(void);
 
 /* ---- weight layouts fyc_gemm expects (one-time, at load): the state-dict tensors of the reference, f32 on the device --------
  * fyc_pack_conv3x3: Conv2d / InflatedConv3d weight (O, I, 3, 3) (animatediff/models/resnet.py:20-27; diffusers resnet.py Conv2d)

@@ -221,6 +221,74 @@ class EmuOps:
         y = X + torch.einsum("bfphk,hnk->bfpn", O, w_out.to(acc_t)[:, :, :d]) + b_out.to(acc_t)
         _flat(out)[: y.numel()].reshape(y.shape).copy_(y.to(out.dtype))
 
+    def ff_block_supported(self, dtype, *, rows, C_, hidden, cs_rows=0):
+        """the shape libfyc_hip.so's kernel is built for (csrc/ff_block.hip); `ff_block` itself is a specification for any
+        C, hidden that are multiples of 32"""
+        return dtype == torch.bfloat16 and C_ == 320 and hidden == 1280 and rows % 128 == 0 and (cs_rows == 0 or (cs_rows % 128 == 0 and rows % cs_rows == 0))
+
+    @staticmethod
+    def _ff_unpack(wstream, C_, hidden):
+        """inverse of the fyc_ff_block weight stream (include/fyc.h), written from the layout description: returns
+        (Wp [C][C], W1 [2 hidden][C] GEGLU-packed, colsum, bias [2 hidden], W2' [C][hidden])"""
+        nb, ks, chunks = C_ // 16, C_ // 32, hidden // 32
+        pst, pc = (ks + 1) // 2, 4 * ks
+        npc = max(2 * nb, pc + 1 + nb)
+        S = _flat(wstream).reshape(pst + chunks + 1, npc, 64, 8)                  # [stage][piece][lane][e]
+        lane = torch.arange(64)
+        r, gq = lane & 15, lane >> 4
+
+        def block(piece):                                                          # [64][8] fragment -> [16][32] weight block
+            blk = torch.zeros(16, 32, dtype=piece.dtype)
+            for e in range(8):
+                blk[r, 8 * gq + e] = piece[:, e]
+            return blk
+        Wp = torch.zeros(C_, C_, dtype=wstream.dtype)
+        for s_ in range(ks):
+            for j in range(nb):
+                Wp[16 * j: 16 * j + 16, 32 * s_: 32 * s_ + 32] = block(S[s_ // 2, (s_ % 2) * nb + j])
+        W1 = torch.zeros(2 * hidden, C_, dtype=wstream.dtype)
+        cs, bi = torch.zeros(2 * hidden), torch.zeros(2 * hidden)
+        W2 = torch.zeros(C_, hidden, dtype=wstream.dtype)
+        for c in range(chunks):
+            for s_ in range(ks):
+                for q in range(4):
+                    W1[64 * c + 16 * q: 64 * c + 16 * q + 16, 32 * s_: 32 * s_ + 32] = block(S[pst + c, 4 * s_ + q])
+            cst = S[pst + c, pc].reshape(-1).view(torch.float32)
+            cs[64 * c: 64 * c + 64], bi[64 * c: 64 * c + 64] = cst[:64], cst[64:128]
+            for j in range(nb):
+                blk = block(S[pst + c + 1, pc + 1 + j])                          # columns = k-slots 8 g + e
+                for k in range(32):
+                    g_, e = k // 8, k % 8
+                    unit = 4 * g_ + e if e < 4 else 16 + 4 * g_ + e - 4
+                    W2[16 * j: 16 * j + 16, 32 * c + unit] = blk[:, k]
+        return Wp, W1, cs, bi, W2
+
+    def ff_block(self, x, residual, out, *, wstream, b_out, rows, C_, hidden, eps=1e-5, chan_parts=None, cs_rows=0):
+        """out = residual + b_out + [x | GEGLU(LN(x) W1^T + b1)] [Wp | W2']^T (LayerNorm folded: rstd (x W1'^T - mean colsum) + b1');
+        the hidden activation is rounded to the storage dtype where the kernel packs it into MFMA operands; chan_parts
+        [rows / 128][C][2] = per 128-row tile {sum, sum of squares} of the stored output"""
+        acc_t, T = self.acc, x.dtype
+        key = (wstream.data_ptr(), C_, hidden)
+        cache = self.__dict__.setdefault("_ff_cache", {})
+        if key not in cache:
+            cache[key] = self._ff_unpack(wstream, C_, hidden)
+        Wp, W1, cs, bi, W2 = cache[key]
+        X = _flat(x)[: rows * C_].reshape(rows, C_).to(acc_t)
+        mean = X.mean(-1, keepdim=True)
+        rstd = (X.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+        pre = rstd * (X @ W1.to(acc_t).t() - mean * cs.to(acc_t)) + bi.to(acc_t)
+        blk = pre.reshape(rows, hidden // 16, 2, 16)
+        h = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(rows, hidden).to(T).to(acc_t)
+        y = X @ Wp.to(acc_t).t() + h @ W2.to(acc_t).t() + b_out.to(acc_t)
+        if residual is not None:
+            y = y + _flat(residual)[: rows * C_].reshape(rows, C_).to(acc_t)
+        y = y.to(out.dtype)
+        _flat(out)[: rows * C_].reshape(rows, C_).copy_(y)
+        if chan_parts is not None:
+            assert cs_rows % 128 == 0 and rows % 128 == 0
+            t = y.double().reshape(rows // 128, 128, C_)
+            _flat(chan_parts)[: (rows // 128) * C_ * 2].reshape(rows // 128, C_, 2).copy_(torch.stack([t.sum(1), (t * t).sum(1)], dim=-1).float())
+
     # ------------------------------------------------------------------------------------
     def gn_stats(self, x, stats, *, rows, C_, groups, rows_per_sample):
         xs = _flat(x)[: rows * C_].reshape(rows // rows_per_sample, rows_per_sample, groups, C_ // groups).double()

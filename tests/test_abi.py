@@ -18,7 +18,7 @@ STRUCTS = {
     "fyc_cfg_ddim_args": "CfgDdimArgs", "fyc_nchw_in_args": "NchwInArgs", "fyc_nhwc_out_args": "NhwcOutArgs",
     "fyc_embed_args": "EmbedArgs", "fyc_patchify_args": "PatchifyArgs", "fyc_row_stats_args": "RowStatsArgs",
     "fyc_pack_conv3x3_args": "PackConv3x3Args", "fyc_pack_geglu_args": "PackGegluArgs",
-    "fyc_temporal_block_args": "TemporalBlockArgs",
+    "fyc_temporal_block_args": "TemporalBlockArgs", "fyc_ff_block_args": "FFBlockArgs",
 }
 
 

@@ -45,6 +45,54 @@ def test_unet_forward_matches_golden(golden_dir, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_unet_forward_with_fused_ff_blocks(golden_dir, dtype, tol, monkeypatch):
+    """FYC_FUSE_FF: every feed-forward (spatial and temporal transformer blocks) goes through `ff_block` with the weight stream of
+    weights.pack_ff_block (projection stages, FF1 chunks + constants, W2' in k-slot order) and its tile statistics feed the next
+    GroupNorm - same golden as the unfused schedule"""
+    from followyourclick_amd.engine import unet3d
+    monkeypatch.setattr(unet3d, "FUSE_FF", True)
+    calls = []
+
+    class Spy(EmuOps):
+        def ff_block_supported(self, dtype, *, rows, C_, hidden, cs_rows=0):      # the tiny widths are outside the kernel's shapes: force the path
+            return rows % 128 == 0 and (cs_rows == 0 or (cs_rows % 128 == 0 and rows % cs_rows == 0))
+
+        def ff_block(self, *a, **kw):
+            calls.append((kw["rows"], kw["C_"], kw["chan_parts"] is not None))
+            return super().ff_block(*a, **kw)
+    g = _load(golden_dir, "unet_tiny_fwd.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), dtype, "cpu"), ops=Spy())
+    x9 = g["sample"]
+    B, C9, F, H, Wd = x9.shape
+    x = torch.zeros(B * F * H * Wd, 64)
+    x[:, :C9] = x9.permute(0, 2, 3, 4, 1).reshape(-1, C9)
+    eng.prepare_context(g["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), B)
+    out = eng.forward(x.to(dtype), temb, B, F, H, Wd).float().reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    rel = ((out - g["out"]).norm() / g["out"].norm()).item()
+    assert rel < tol, rel
+    assert len(calls) >= 5, calls                      # the 64-channel level (rows = B*F*H*W is a multiple of 128 there)
+
+
+def test_ff_block_stream_round_trip():
+    """weights.pack_ff_block against the layout description of include/fyc.h (the emulator's independent unpacker), at the
+    kernel's widths and at a small one"""
+    from followyourclick_amd.engine.weights import Packed, ff_block_layout, pack_ff_block
+    assert ff_block_layout(320, 1280) == (46, 61, 5, 40)
+    for C, hid, T in [(320, 1280, torch.bfloat16), (64, 256, torch.float32), (96, 384, torch.bfloat16)]:
+        g = torch.Generator().manual_seed(C)
+        ff = Packed(w1=torch.randn(2 * hid, C, generator=g).to(T), b1=torch.randn(2 * hid, generator=g), cs1=torch.randn(2 * hid, generator=g),
+                    po_w=torch.randn(C, C + hid, generator=g).to(T), po_b=torch.randn(C, generator=g))
+        st = pack_ff_block(ff)
+        nst, npc, _, _ = ff_block_layout(C, hid)
+        assert st.numel() == nst * npc * 512
+        Wp, W1, cs, bi, W2 = EmuOps._ff_unpack(st, C, hid)
+        assert torch.equal(Wp, ff.po_w[:, :C]) and torch.equal(W1, ff.w1) and torch.equal(W2, ff.po_w[:, C:])
+        assert torch.equal(cs, ff.cs1) and torch.equal(bi, ff.b1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
 def test_unet_forward_with_fused_temporal_blocks(golden_dir, dtype, tol, monkeypatch):
     """FYC_FUSE_TEMPORAL: every temporal attention sub-block goes through `temporal_block` with the per-head operands of
     weights.pack_temporal_block (q|k|v gather per head, positional bias per frame, output projection slices) - same golden"""

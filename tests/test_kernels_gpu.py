@@ -323,6 +323,80 @@ def test_temporal_block_fused(hip, emu, clips, P, with_pe):
         hip.temporal_block(xc, xc, **ops_h, **kw)
 
 
+def _ff_operands(seed=0):
+    """a packed feed-forward (engine/weights.py::_ff layout) with the LayerNorm folded in, at the kernel's widths"""
+    from followyourclick_amd.engine.weights import Packed
+    T, C, hid = torch.bfloat16, 320, 1280
+    w1 = (rnd((2 * hid, C), torch.float32, seed + 1) * C ** -0.5).to(T)
+    return Packed(w1=w1, b1=rnd((2 * hid,), torch.float32, seed + 2) * 0.2, cs1=w1.float().sum(dim=1).contiguous(),
+                  po_w=(rnd((C, C + hid), torch.float32, seed + 3) * (C + hid) ** -0.5).to(T), po_b=rnd((C,), torch.float32, seed + 4) * 0.1)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("rows,with_res,with_stats", [(128, True, True), (512, False, False), (4096, True, True), (131072, True, True)])
+def test_ff_block_fused(hip, emu, rows, with_res, with_stats, variant):
+    """fyc_ff_block (LayerNorm statistics + FF1 + GEGLU + FF2 + merged output projection + residual + output statistics in one
+    kernel) against the torch specification on the weight stream of engine/weights.py::pack_ff_block; both instruction
+    schedules of the kernel (fyc_set_tuning key 8)"""
+    from followyourclick_amd.engine.weights import pack_ff_block
+    T, C, hid = torch.bfloat16, 320, 1280
+    ff = _ff_operands()
+    ws = pack_ff_block(ff)
+    assert ws.numel() * 2 == hip.ff_block_wstream_bytes()
+    x = (rnd((rows, C), torch.float32, 6) * 1.5 + 0.3).to(T)
+    x[5] = x[5] * 40 + 100                                       # a row with a large mean: the folded LayerNorm must not lose it
+    res = rnd((rows, C), T, 7) if with_res else None
+    assert hip.ff_block_supported(T, rows=rows, C_=C, hidden=hid, cs_rows=128 if with_stats else 0)
+    assert not hip.ff_block_supported(T, rows=rows + 64, C_=C, hidden=hid) and not hip.ff_block_supported(torch.float32, rows=rows, C_=C, hidden=hid)
+    assert not hip.ff_block_supported(T, rows=rows, C_=640, hidden=2560) and not hip.ff_block_supported(T, rows=rows, C_=C, hidden=hid, cs_rows=64)
+    o_h = torch.full((rows, C), float("nan"), dtype=T, device="cuda")
+    p_h = torch.full((rows // 128, C, 2), float("nan"), dtype=torch.float32, device="cuda") if with_stats else None
+    hip.set_tuning(8, 1 - variant)
+    try:
+        hip.ff_block(x.cuda(), res.cuda() if with_res else None, o_h, wstream=ws.cuda(), b_out=ff.po_b.cuda(), rows=rows, C_=C, hidden=hid,
+                     chan_parts=p_h, cs_rows=128 if with_stats else 0)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_tuning(8, 0)
+    sel = torch.arange(rows) if rows <= 4096 else torch.cat([torch.arange(0, 256), torch.arange(rows // 2 - 128, rows // 2 + 128), torch.arange(rows - 256, rows)])
+    n = len(sel)
+    o_e = torch.zeros(n, C, dtype=T)
+    p_e = torch.zeros(n // 128, C, 2) if with_stats else None
+    emu.ff_block(x[sel], res[sel] if with_res else None, o_e, wstream=ws, b_out=ff.po_b, rows=n, C_=C, hidden=hid, chan_parts=p_e, cs_rows=128 if with_stats else 0)
+    close(o_h[sel.cuda()], o_e, f"ff block rows{rows} res{with_res} v{variant}", 6e-3)
+    if with_stats:
+        # the statistics are of the values AS STORED by the kernel: compare with sums of its own output, tile by tile
+        t = o_h.double().reshape(rows // 128, 128, C)
+        own = torch.stack([t.sum(1), (t * t).sum(1)], dim=-1)
+        close(p_h, own.cpu(), f"ff block statistics rows{rows} v{variant}", 2e-5)
+    with pytest.raises(Exception, match="alias"):
+        xc = x.cuda()
+        hip.ff_block(xc, None, xc, wstream=ws.cuda(), b_out=ff.po_b.cuda(), rows=rows, C_=C, hidden=hid)
+
+
+def test_ff_block_matches_unfused_schedule(hip):
+    """the fused kernel against the three launches it replaces (row statistics, GEGLU GEMM with the folded LayerNorm, dual-K
+    output GEMM) on the device: same operands, same roundings up to the accumulation order"""
+    from followyourclick_amd.engine.weights import pack_ff_block
+    from followyourclick_amd import _lib as L
+    T, C, hid, rows = torch.bfloat16, 320, 1280, 8192
+    ff = _ff_operands(10)
+    ws = pack_ff_block(ff).cuda()
+    x = (rnd((rows, C), torch.float32, 6) * 1.2 - 0.2).to(T).cuda()
+    res = rnd((rows, C), T, 7).cuda()
+    w1, b1, cs1, po_w, po_b = (t.cuda() for t in (ff.w1, ff.b1, ff.cs1, ff.po_w, ff.po_b))
+    o_f = torch.empty(rows, C, dtype=T, device="cuda")
+    hip.ff_block(x, res, o_f, wstream=ws, b_out=po_b, rows=rows, C_=C, hidden=hid)
+    st = torch.empty(rows, 2, dtype=torch.float32, device="cuda")
+    hip.row_stats(x, st, rows=rows, C_=C)
+    hmid = torch.empty(rows, hid, dtype=T, device="cuda")
+    hip.gemm(x, w1, hmid, M=rows, N=2 * hid, K=C, lda=C, ldw=C, ldo=hid, bias=b1, epilogue=L.EPI_GEGLU, ln_colsum=cs1, ln_stats=st)
+    o_u = torch.empty(rows, C, dtype=T, device="cuda")
+    hip.gemm(x, po_w, o_u, M=rows, N=C, K=C + hid, lda=C, ldw=C + hid, ldo=C, bias=po_b, residual=res, ldr=C, a2=hmid, k_split=C, lda2=hid)
+    torch.cuda.synchronize()
+    close(o_f, o_u.cpu(), "ff block vs unfused launches", 4e-3)
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("samples,rps,C", [(2, 4 * 64, 320), (8, 64, 64), (2, 16 * 16, 2560), (6, 1, 128), (3, 1000, 960), (2, 37, 1920)])

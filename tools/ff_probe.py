@@ -1,0 +1,72 @@
+"""fyc_ff_block (one kernel) against the three launches it replaces (fyc_row_stats, fyc_gemm GEGLU with the folded LayerNorm,
+fyc_gemm dual-K + residual + statistics), cold operands (rotating buffer sets), both instruction schedules of the kernel.
+usage (GPU box): python tools/ff_probe.py > gpurun_out/ff_probe.txt"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from followyourclick_amd import _lib as L
+from followyourclick_amd import ops
+from followyourclick_amd.engine.weights import Packed, pack_ff_block
+
+T = torch.bfloat16
+DEV = torch.device("cuda:0")
+C, HID = 320, 1280
+
+
+def timed(fn, n):
+    fn(0)
+    fn(1)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(n):
+        fn(i)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+def main():
+    h = ops.get()
+    h.ensure_init(DEV)
+    w1 = (torch.randn(2 * HID, C, device=DEV) * C ** -0.5).to(T)
+    ff = Packed(w1=w1, b1=torch.randn(2 * HID, device=DEV) * 0.1, cs1=w1.float().sum(dim=1).contiguous(),
+                po_w=(torch.randn(C, C + HID, device=DEV) * (C + HID) ** -0.5).to(T), po_b=torch.randn(C, device=DEV) * 0.1)
+    ws = pack_ff_block(ff)
+    for rows in (131072, 32768, 8192):
+        nb = 8 if rows >= 32768 else 16
+        sets = [(torch.randn(rows, C, device=DEV).to(T), torch.randn(rows, C, device=DEV).to(T), torch.empty(rows, C, dtype=T, device=DEV),
+                 torch.empty(rows, HID, dtype=T, device=DEV)) for _ in range(nb)]
+        st = torch.empty(rows, 2, dtype=torch.float32, device=DEV)
+        parts = torch.empty(rows // 128 * C * 2, dtype=torch.float32, device=DEV)
+        cs_rows = 4096 if rows % 4096 == 0 else 128
+        n, tr, sl = h.gemm_stat_layout(T, M=rows, N=C, K=C + HID, cs_rows=cs_rows)
+        gparts = torch.empty(n * sl * C * 2, dtype=torch.float32, device=DEV)
+        flops = 2.0 * rows * (C * 2 * HID + (C + HID) * C)
+
+        def fused(i):
+            x, r, o, _ = sets[i % nb]
+            h.ff_block(x, r, o, wstream=ws, b_out=ff.po_b, rows=rows, C_=C, hidden=HID, chan_parts=parts, cs_rows=cs_rows)
+
+        def unfused(i):
+            x, r, o, hm = sets[i % nb]
+            h.row_stats(x, st, rows=rows, C_=C)
+            h.gemm(x, ff.w1, hm, M=rows, N=2 * HID, K=C, lda=C, ldw=C, ldo=HID, bias=ff.b1, epilogue=L.EPI_GEGLU, ln_colsum=ff.cs1, ln_stats=st)
+            h.gemm(x, ff.po_w, o, M=rows, N=C, K=C + HID, lda=C, ldw=C + HID, ldo=C, bias=ff.po_b, residual=r, ldr=C, a2=hm, k_split=C, lda2=HID,
+                   chan_parts=gparts, cs_rows=cs_rows)
+
+        res = {}
+        for rnd in range(3):                    # interleaved rounds: variants see the same clocks
+            for name, fn, key in (("unfused (3 launches)", unfused, None), ("ff_block pinned prefetch", fused, 0), ("ff_block compiler schedule", fused, 1)):
+                if key is not None:
+                    h.set_tuning(8, key)
+                res.setdefault(name, []).append(timed(fn, 2 * nb))
+        h.set_tuning(8, 0)
+        for name, v in res.items():
+            us = min(v)
+            print(f"rows={rows:7d}  {name:28s} {us:8.1f} us (min of {['%.1f' % t for t in v]})  {flops / us / 1e6:7.0f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
