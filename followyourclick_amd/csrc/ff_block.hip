@@ -29,6 +29,7 @@
 // Built for the level where it pays (C = 320, hidden 1280, bf16, rows % 128 == 0); other shapes keep the unfused schedule.
 // Compiled WITHOUT -amdgpu-mfma-vgpr-form (see _build.py): the accumulators must live in AGPRs for the 512-register budget.
 #include <mutex>
+#include <type_traits>
 
 #include "fyc_common.h"
 
@@ -44,8 +45,10 @@ constexpr int PIECE = 1024;                    // one MFMA fragment for all 64 l
 constexpr int P_CONST = 40, P_W2 = 41, NPIECE = 61, NPIECE_PROJ = 40;
 constexpr int STAGE_BYTES = NPIECE * PIECE;    // 62464
 constexpr int TILE_BYTES = ROWS * C_ * 2;      // 81920: the residual / output tile of the epilogue (overlays the ring)
+constexpr int SCR_BYTES = 6 * 40 * 16 * 4;       // statistics partials of the epilogue: [row slice][column group][8 sums | 8 sums of squares]
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-static_assert(TILE_BYTES + 160 * 16 <= LDS_BYTES, "epilogue tile + statistics scratch overlay the ring");
+static_assert(TILE_BYTES <= STAGE_BYTES + P_CONST * PIECE, "the residual tile lands while the last stage still reads its constants / W2' pieces");
+static_assert(TILE_BYTES + SCR_BYTES <= LDS_BYTES, "epilogue tile + statistics scratch overlay the ring");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 struct FFP {
@@ -53,7 +56,10 @@ struct FFP {
   const char* ws;            // packed weight stream, NSTAGE * STAGE_BYTES
   const float* b_out;        // [C]
   float* parts;              // [rows / 128][C][2] or null
+  int ntiles;                // rows / 128
   float eps;
+  int tune;                  // fyc_set_tuning key 9 (measurement only): 1 = every block walks a stage's pieces from its own start, 2 = no DMA
+                             // after the first stages, 4 = no MFMA / gate work (DMA + barriers only) - 2 and 4 give wrong results
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -71,29 +77,42 @@ __device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *rein
 template <int VAR>
 __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, r16 = lane & 15;
-  const long long row0 = (long long)blockIdx.x * ROWS;
-  const unsigned lane16 = (unsigned)lane * 16u;
+  const int rot = (p.tune & 1) ? (int)(((blockIdx.x >> 3) * 5u) % NPIECE_PROJ) : 0;
+  const bool work = !(p.tune & 4);
 
+  // One row tile per workgroup.  (A persistent loop over tiles was tried - with and without requesting the next tile's tokens
+  // during the last stage: inside an outer loop the register allocator spilled 85-95 registers of this 496-register kernel.)
+  {
+  const int tile = blockIdx.x;
+  const long long row0 = (long long)tile * ROWS;
+  const int lane = tid & 63;
+  const int g = lane >> 4, r16 = lane & 15;
+  const unsigned lane16 = (unsigned)lane * 16u;
   auto issue = [&](int t) {                                   // DMA of stage t into slot t & 1: piece q by wave q % 4
     const int np = t < PROJ_ST ? NPIECE_PROJ : NPIECE;
     const char* src = p.ws + (long long)t * STAGE_BYTES;     // wave-uniform base + one 32-bit lane offset: no per-piece address registers
     char* dst = smem + (t & 1) * STAGE_BYTES;
+    if ((p.tune & 2) && t > PROJ_ST + 1) return;
 #pragma unroll 1
-    for (int q = wave; q < np; q += 4) glds16(src + q * PIECE + lane16, dst + q * PIECE);
+    for (int q = wave; q < np; q += 4) {
+      int q2 = q + rot;                                         // the blocks of an XCD run in step and want the same bytes: spread them over
+      if (q2 >= np) q2 -= np;                                   // the L2 channels instead of all asking for the same 1 KiB at once
+      glds16(src + q2 * PIECE + lane16, dst + q2 * PIECE);
+    }
   };
 
   // ---- the wave's 32 token rows as MFMA operands: lane (row r16, quad g) holds x[row][32 s + 8 g .. +8] ---------------------
   bf16x8 xa[2][KS];
-  {
-    const bf16_t* xr = p.x + (row0 + wave * 32 + r16) * C_ + g * 8;
+  auto load_x = [&](int tile) {
+    const bf16_t* xr = p.x + ((long long)tile * ROWS + wave * 32 + r16) * C_ + g * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const bf16x8*>(xr + i * 16 * C_ + s * 32);
-  }
+  };
+  load_x(tile);
   issue(0);
 
   // LayerNorm statistics of the lane's two rows (two-pass, in registers; the four quads of a row meet through xor 16 / 32)
@@ -149,68 +168,44 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       }
   }
 
+  // The tokens were needed raw for the projection; from here on they are only the FF1 operand: normalise them in place,
+  // (x - mean) rstd rounded to bf16 (what the reference's autocast feeds its Linear), so that no LayerNorm term is left in the
+  // per-chunk gate (gamma is folded into W1, beta into b1: engine/weights.py::fold_layernorm)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        t[e] = pack_bf16x2((__uint_as_float(t[e] << 16) - mu[i]) * rs[i], (__uint_as_float(t[e] & 0xffff0000u) - mu[i]) * rs[i]);
+      xa[i][k] = __builtin_bit_cast(bf16x8, t);
+    }
+
   // ---- hidden chunks -----------------------------------------------------------------------------------------------------------
-  // FF1 of chunk c: pre-activations of the chunk's 64 W1 rows (q = 2 * half + {value, gate}) for the wave's 32 rows
-  auto ff1 = [&](const char* sl, f32x4 (&ha)[2][4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ha[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (VAR == 1) {
-      // the four fragments of k-step s + 1 are requested before the eight MFMAs of k-step s are issued (pinned: left alone the
-      // compiler reads two fragments, waits, issues four MFMAs - the LDS round trip then sits on the matrix pipe's critical path)
-      bf16x8 w[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = frag(sl, q);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        bf16x8 n[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) n[q] = (s + 1 < KS) ? frag(sl, (s + 1) * 4 + q) : w[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) ha[i][q] = mfma(w[q], xa[i][s], ha[i][q]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = n[q];
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bf16x8 wf = frag(sl, s * 4 + q);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) ha[i][q] = mfma(wf, xa[i][s], ha[i][q]);
-        }
-    }
+  // Stage of chunk c:  FF1(c) -> hw (80 MFMAs)  ||  GEGLU gate of chunk c - 1 from hr (VALU) -> hb;  then FF2(c - 1) with hb (40 MFMAs).
+  // The gate of a chunk runs one stage after its FF1 so that its ~250 VALU instructions have independent matrix work beside
+  // them: a wave alone on its SIMD overlaps VALU with the matrix pipe only where the two alternate in program order, so the
+  // gate is cut into 8 units (row block, half, value pair) and one unit follows the MFMAs of each of the first 8 k-steps.
+  // gate unit u = (row block i, half h) of the pre-activations hr -> two packed bf16 pairs of the FF2 operand (two independent
+  // polynomial chains: their dependent v_pk_fma steps fill each other's wait states): k-slots 8 g + e = hidden unit 4 g + e of
+  // half 0 (e < 4), of half 1 (e >= 4)
+  auto gate_unit = [&](int u, const f32x4 (&bi)[4], const f32x4 (&hr)[2][4], u32x4 (&hbw)[2]) {
+    const int i = u >> 1, h = u & 1;
+    const f32x4 v = hr[i][2 * h] + bi[2 * h], gt = hr[i][2 * h + 1] + bi[2 * h + 1];
+    const f32x2 lo = geglu_pair((f32x2){v[0], v[1]}, (f32x2){gt[0], gt[1]}), hi = geglu_pair((f32x2){v[2], v[3]}, (f32x2){gt[2], gt[3]});
+    unsigned p0 = pack_bf16x2(lo.x, lo.y), p1 = pack_bf16x2(hi.x, hi.y);
+    asm volatile("" : "+v"(p0), "+v"(p1));                    // the unit's result is "used" here: LLVM's sinking passes would otherwise move the whole
+    hbw[i][2 * h] = p0;                                       // unit down to FF2, its only real consumer, behind all the MFMAs it is meant to sit beside
+    hbw[i][2 * h + 1] = p1;
   };
-  // GEGLU on the pre-activations: k-slots 8 g + e of the FF2 operand = hidden unit 4 g + e of half 0 (e < 4), of half 1 (e >= 4)
-  auto gate = [&](const char* base, const f32x4 (&ha)[2][4], bf16x8 (&hb)[2]) {
-    const float* cst = reinterpret_cast<const float*>(base + P_CONST * PIECE);    // [colsum 64 | bias 64] of the chunk's 64 W1 rows
-    f32x4 cs[4], bi[4];
+  auto load_consts = [&](const char* base, f32x4 (&bi)[4]) {  // bias (beta folded in) of the PREVIOUS chunk's 64 W1 rows
+    const float* cst = reinterpret_cast<const float*>(base + P_CONST * PIECE);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { cs[q] = *reinterpret_cast<const f32x4*>(cst + q * 16 + g * 4); bi[q] = *reinterpret_cast<const f32x4*>(cst + 64 + q * 16 + g * 4); }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      u32x4 f;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        f32x4 v, gt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = rs[i] * (ha[i][2 * h][r] - mu[i] * cs[2 * h][r]) + bi[2 * h][r];
-          gt[r] = rs[i] * (ha[i][2 * h + 1][r] - mu[i] * cs[2 * h + 1][r]) + bi[2 * h + 1][r];
-        }
-        const f32x2 lo = geglu_pair((f32x2){v[0], v[1]}, (f32x2){gt[0], gt[1]}), hi = geglu_pair((f32x2){v[2], v[3]}, (f32x2){gt[2], gt[3]});
-        f[2 * h] = pack_bf16x2(lo.x, lo.y);
-        f[2 * h + 1] = pack_bf16x2(hi.x, hi.y);
-      }
-      hb[i] = __builtin_bit_cast(bf16x8, f);
-    }
+    for (int q = 0; q < 4; ++q) bi[q] = *reinterpret_cast<const f32x4*>(cst + q * 16 + g * 4);
   };
-  auto ff2 = [&](const char* sl, const bf16x8 (&hb)[2]) {
+  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[2]) {
+    const bf16x8 hb[2] = {__builtin_bit_cast(bf16x8, hbw[0]), __builtin_bit_cast(bf16x8, hbw[1])};
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const bf16x8 wf = frag(sl, P_W2 + j);
@@ -218,41 +213,96 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, hb[i], oacc[i][j]);
     }
   };
+  // WITH_GATE: false for chunk 0 (nothing to gate yet).  The scheduler is pinned per pair of k-steps (sched_barrier): 8 fragment
+  // reads one k-step ahead of their MFMAs, 16 MFMAs, one gate unit; VAR 1 additionally lays the pair out as MFMA, 3 VALU, MFMA, ...
+  auto stage = [&](const char* base, f32x4 (&hw)[2][4], const f32x4 (&hr)[2][4], auto with_gate) {
+    constexpr bool WITH_GATE = decltype(with_gate)::value;
+    const char* sl = base + lane16;
+    f32x4 bi[4];
+    u32x4 hbw[2];
+    if constexpr (WITH_GATE) load_consts(base, bi);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hw[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = frag(sl, q);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 n[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n[q] = (s + 1 < KS) ? frag(sl, (s + 1) * 4 + q) : w[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
+      if constexpr (WITH_GATE) {
+        if (s < 8 && (s & 1)) gate_unit(s >> 1, bi, hr, hbw);
+      }
+      if ((s & 1) || !WITH_GATE) {
+        if constexpr (WITH_GATE && VAR == 1) {                // masks: 0x2 VALU, 0x8 MFMA, 0x100 DS read
+          if (s < 8) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = n[q];
+    }
+    if constexpr (WITH_GATE) ff2(sl, hbw);
+  };
 
-  f32x4 ha[2][4];
-  bf16x8 hb[2], hn[2];
+  f32x4 h0[2][4], h1[2][4];
   __syncthreads();                                            // stage 5 (chunk 0) landed
   issue(PROJ_ST + 1);
-  ff1(smem + (PROJ_ST & 1) * STAGE_BYTES + lane16, ha);
-  gate(smem + (PROJ_ST & 1) * STAGE_BYTES, ha, hb);
-  for (int c = 1; c < CHUNKS; ++c) {
+  if (work) stage(smem + (PROJ_ST & 1) * STAGE_BYTES, h0, h1, std::false_type{});
+  for (int c = 1; c + 1 < CHUNKS; c += 2) {                  // chunks (1, 2), (3, 4), ..., (37, 38): pre-activation buffers alternate
     const int t = PROJ_ST + c;
     __syncthreads();                                          // stage t landed; slot (t+1)&1 free
     issue(t + 1);
-    const char* base = smem + (t & 1) * STAGE_BYTES;
-    ff1(base + lane16, ha);                                   // 80 MFMAs
-    gate(base, ha, hn);                                       // VALU, beside ...
-    ff2(base + lane16, hb);                                   // ... the 40 MFMAs of the previous chunk's FF2
-    hb[0] = hn[0];
-    hb[1] = hn[1];
+    if (work) stage(smem + (t & 1) * STAGE_BYTES, h1, h0, std::true_type{});
+    __syncthreads();
+    issue(t + 2);
+    if (work) stage(smem + ((t + 1) & 1) * STAGE_BYTES, h0, h1, std::true_type{});
   }
-  __syncthreads();                                            // last stage: W2' of chunk 39 only
-  ff2(smem + ((NSTAGE - 1) & 1) * STAGE_BYTES + lane16, hb);
-
-  // ---- epilogue -------------------------------------------------------------------------------------------------------------------
-  __syncthreads();                                            // every wave is done with the ring
-  if (p.res != nullptr) {                                     // the 128 residual rows are one contiguous 80 KiB: flat DMA
+  __syncthreads();                                            // chunk 39
+  issue(NSTAGE - 1);
+  if (work) stage(smem + ((NSTAGE - 2) & 1) * STAGE_BYTES, h1, h0, std::true_type{});
+  __syncthreads();                                            // last stage: gate + FF2 of chunk 39 only (reads pieces 40.. of its slot)
+  if (p.res != nullptr) {                                     // the 128 residual rows are one contiguous 80 KiB: flat DMA over the idle part of the ring
     const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);
 #pragma unroll 1
     for (int q = wave; q < TILE_BYTES / PIECE; q += 4) glds16(src + q * PIECE + lane16, smem + q * PIECE);
   }
-  __syncthreads();
+  if (work) {
+    const char* base = smem + ((NSTAGE - 1) & 1) * STAGE_BYTES;
+    f32x4 bi[4];
+    u32x4 hbw[2];
+    load_consts(base, bi);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gate_unit(u, bi, h1, hbw);
+    ff2(base + lane16, hbw);
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+  __syncthreads();                                            // residual tile landed; every wave is done with the ring
+  const float* bias_out = p.b_out;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       bf16_t* a = reinterpret_cast<bf16_t*>(smem + (wave * 32 + i * 16 + r16) * (C_ * 2)) + j * 16 + g * 4;
-      const f32x4 bo = *reinterpret_cast<const f32x4*>(p.b_out + j * 16 + g * 4);
+      const f32x4 bo = *reinterpret_cast<const f32x4*>(bias_out + j * 16 + g * 4);
       float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
       if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
 #pragma unroll
@@ -260,40 +310,77 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       ElemIO<bf16_t>::st4(a, v);
     }
   __syncthreads();
+  // flat pass over the finished tile: thread (column group cg of 8 channels, row slice rsl) copies rows rsl, rsl + 6, ... to HBM,
+  // 16 B per lane and 3840 contiguous bytes per step, and sums its 8 columns for the statistics of the values as stored
   {
-    char* dst = reinterpret_cast<char*>(p.out + row0 * C_);
-    for (int idx = tid; idx < TILE_BYTES / 16; idx += NT) *reinterpret_cast<u32x4*>(dst + idx * 16) = *reinterpret_cast<const u32x4*>(smem + idx * 16);
-  }
-  if (p.parts != nullptr && tid < 160) {                      // column statistics of the values as stored: one thread per column pair
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    const char* src = smem + tid * 4;
-#pragma unroll 8
-    for (int r = 0; r < ROWS; ++r) {
-      const unsigned u = *reinterpret_cast<const unsigned*>(src + r * (C_ * 2));
-      const float x0 = __uint_as_float(u << 16), x1 = __uint_as_float(u & 0xffff0000u);
-      s0 += x0; q0 = __builtin_fmaf(x0, x0, q0);
-      s1 += x1; q1 = __builtin_fmaf(x1, x1, q1);
+    const int cg = tid % 40, rsl = tid / 40;
+    float cs8[8], cq8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
+    if (rsl < 6) {
+      char* dst = reinterpret_cast<char*>(p.out + row0 * C_) + cg * 16;
+      const char* src = smem + cg * 16;
+#pragma unroll 2
+      for (int row = rsl; row < ROWS; row += 6) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * (C_ * 2));
+        *reinterpret_cast<u32x4*>(dst + row * (C_ * 2)) = v;
+        if (p.parts != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = __uint_as_float(v[e] << 16), x1 = __uint_as_float(v[e] & 0xffff0000u);
+            cs8[2 * e] += x0; cq8[2 * e] = __builtin_fmaf(x0, x0, cq8[2 * e]);
+            cs8[2 * e + 1] += x1; cq8[2 * e + 1] = __builtin_fmaf(x1, x1, cq8[2 * e + 1]);
+          }
+        }
+      }
     }
-    *reinterpret_cast<f32x4*>(p.parts + ((long long)blockIdx.x * C_ + 2 * tid) * 2) = (f32x4){s0, q0, s1, q1};
+    if (p.parts != nullptr) {                                 // wave-uniform: every thread takes the barriers
+      float* scr = reinterpret_cast<float*>(smem + TILE_BYTES);
+      if (rsl < 6) {
+        float* d = scr + (rsl * 40 + cg) * 16;
+        *reinterpret_cast<f32x4*>(d) = (f32x4){cs8[0], cs8[1], cs8[2], cs8[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = (f32x4){cs8[4], cs8[5], cs8[6], cs8[7]};
+        *reinterpret_cast<f32x4*>(d + 8) = (f32x4){cq8[0], cq8[1], cq8[2], cq8[3]};
+        *reinterpret_cast<f32x4*>(d + 12) = (f32x4){cq8[4], cq8[5], cq8[6], cq8[7]};
+      }
+      __syncthreads();
+      if (tid < 160) {                                        // one thread per column pair: add the six row slices
+        const int c2 = tid >> 2, e2 = (tid & 3) * 2;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int sl6 = 0; sl6 < 6; ++sl6) {
+          const float* d = scr + (sl6 * 40 + c2) * 16;
+          s0 += d[e2]; s1 += d[e2 + 1]; q0 += d[8 + e2]; q1 += d[8 + e2 + 1];
+        }
+        *reinterpret_cast<f32x4*>(p.parts + ((long long)tile * C_ + 2 * tid) * 2) = (f32x4){s0, q0, s1, q1};
+      }
+    }
+  }
   }
 }
 
 }  // namespace
+
+// LDS per CU and CU count of this process's device (one GPU per process), queried once; 0 when no device answers
+static void device_limits(int64_t& lds_cap, int64_t& n_cu) {
+  static std::mutex mu;
+  static int64_t cap = -1, cus = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cap < 0) {
+    int64_t caps[8];
+    if (fyc_device_caps(caps) == 0) { cap = caps[1]; cus = caps[0]; } else { cap = 0; cus = 0; }
+  }
+  lds_cap = cap;
+  n_cu = cus;
+}
 
 extern "C" int64_t fyc_ff_block_wstream_bytes(void) { return (int64_t)NSTAGE * STAGE_BYTES; }
 
 extern "C" int fyc_ff_block_supported(const fyc_ff_block_args* a) {
   if (a == nullptr || a->dtype != FYC_BF16 || a->C != C_ || a->hidden != HID || a->rows <= 0 || a->rows % ROWS != 0) return 0;
   if (a->chan_parts != nullptr && (a->cs_rows <= 0 || a->cs_rows % ROWS != 0 || a->rows % a->cs_rows != 0)) return 0;
-  static std::mutex mu;                            // LDS per CU of this process's device (one GPU per process), queried once
-  static int64_t lds_cap = -1;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (lds_cap < 0) {
-      int64_t caps[8];
-      lds_cap = (fyc_device_caps(caps) == 0) ? caps[1] : 0;
-    }
-  }
+  int64_t lds_cap = 0, n_cu = 0;
+  device_limits(lds_cap, n_cu);
   if (lds_cap > 0 && lds_cap < LDS_BYTES) return 0;   // a device / partition mode with less LDS: the caller keeps the unfused schedule
   return 1;
 }
@@ -307,7 +394,7 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
               ((uintptr_t)a->residual % 16) == 0 && ((uintptr_t)a->chan_parts % 16) == 0, "fyc_ff_block: operands must be 16-byte aligned");
   FFP p;
   p.x = (const bf16_t*)a->x; p.res = (const bf16_t*)a->residual; p.out = (bf16_t*)a->out; p.ws = (const char*)a->wstream;
-  p.b_out = a->b_out; p.parts = a->chan_parts; p.eps = a->eps;
+  p.b_out = a->b_out; p.parts = a->chan_parts; p.eps = a->eps; p.tune = g_fyc_tuning[9]; p.ntiles = a->rows / ROWS;
   {  // dynamic LDS above 64 KB needs the function attribute once per device; one process may drive several GPUs from several threads
     constexpr int kMaxDev = 64;
     static std::mutex mu;
@@ -322,8 +409,9 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
       if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
     }
   }
-  if (g_fyc_tuning[8] == 1) hipLaunchKernelGGL(ff_block_kernel<0>, dim3((unsigned)(a->rows / ROWS)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(ff_block_kernel<1>, dim3((unsigned)(a->rows / ROWS)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  const unsigned grid = (unsigned)p.ntiles;
+  if (g_fyc_tuning[8] == 1) hipLaunchKernelGGL(ff_block_kernel<0>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ff_block_kernel<1>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_ff_block");
   return 0;
 }

@@ -233,11 +233,11 @@ def _mfma_fragments(w: Tensor) -> Tensor:
 def pack_ff_block(ff: Packed) -> Tensor:
     """weight stream of fyc_ff_block (csrc/ff_block.hip) from a packed feed-forward (`_ff`) whose LayerNorm is folded into FF1:
     stages x pieces x 512 elements (layout: include/fyc.h; 46 x 61 x 1 KiB at C = 320).  The first stages hold the projection of
-    the token half of the merged [Wp | Wp W2] weight (two k-steps each); stage pst + c: W1 rows of hidden chunk c, their colsum /
-    bias (f32), and the W2' columns of chunk c - 1 in the k-slot order the kernel's GEGLU outputs have (slot 8 g + e = unit
+    the token half of the merged [Wp | Wp W2] weight (two k-steps each); stage pst + c: W1 rows of hidden chunk c, and of chunk
+    c - 1 the bias (f32) and the W2' columns in the k-slot order the kernel's GEGLU outputs have (slot 8 g + e = unit
     4 g + e of the chunk's first 16 hidden units for e < 4, of its second 16 for e >= 4)."""
-    w1, b1, cs1, po = ff.w1, ff.b1, ff.cs1, ff.po_w
-    assert cs1 is not None, "fyc_ff_block needs the LayerNorm folded into FF1"
+    w1, b1, po = ff.w1, ff.b1, ff.po_w
+    assert ff.cs1 is not None, "fyc_ff_block needs the LayerNorm folded into FF1"
     C = w1.shape[1]
     hid = w1.shape[0] // 2
     assert C % 32 == 0 and hid % 32 == 0 and tuple(po.shape) == (C, C + hid) and w1.dtype == po.dtype
@@ -251,11 +251,11 @@ def pack_ff_block(ff: Packed) -> Tensor:
     # FF1: piece s * 4 + q of stage pst + c = W1[64 c + 16 q .. +16][32 s .. +32]
     f1 = _mfma_fragments(w1.reshape(chunks, 4, 16, ks, 32).permute(0, 3, 1, 2, 4))          # [c][s][q][512]
     st[pst: pst + chunks, : 4 * ks] = f1.reshape(chunks, 4 * ks, 512)
-    # constants piece: f32 colsum[64] | bias[64] of the chunk's 64 W1 rows (bit pattern of the floats inside a bf16 stream)
+    # constants piece of stage pst + c + 1: f32 bias[64] (beta folded in) of chunk c's 64 W1 rows (bit pattern of the floats inside a
+    # bf16 stream) - the kernel gates a chunk one stage after its FF1, on LayerNorm-ed tokens: no colsum term is needed
     cst = torch.zeros(chunks, 512 * w1.element_size() // 4, dtype=torch.float32, device=w1.device)
-    cst[:, :64] = cs1.reshape(chunks, 64)
-    cst[:, 64:128] = b1.reshape(chunks, 64)
-    st[pst: pst + chunks, pc] = cst.view(w1.dtype)
+    cst[:, :64] = b1.reshape(chunks, 64)
+    st[pst + 1: pst + 1 + chunks, pc] = cst.view(w1.dtype)
     # FF2: pieces pc + 1 + j of stage pst + c + 1 = W2'[16 j .. +16][k-slots of chunk c]
     slot_unit = torch.tensor([(4 * (k // 8) + k % 8) if k % 8 < 4 else (16 + 4 * (k // 8) + k % 8 - 4) for k in range(32)], device=w1.device)
     w2 = po[:, C:].reshape(nb, 16, chunks, 32)[..., slot_unit]                               # [j][16][c][k-slot]

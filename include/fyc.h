@@ -41,7 +41,8 @@ int fyc_device_caps(int64_t* caps);
 /* tuning knobs for A/B measurements (0 = automatic): key 0 = 1 disables split-K, key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
  * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
  * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one,
- * key 8 = 1: fyc_ff_block with the compiler's own instruction schedule (0: FF1 fragment reads pinned one k-step ahead); keys 9..15 reserved */
+ * key 8 = 1: fyc_ff_block with the compiler's own instruction schedule (0: FF1 fragment reads pinned one k-step ahead); key 9 = fyc_ff_block measurement
+ * bits (1: per-block piece order of the weight DMA, 2: no DMA, 4: no MFMA work - 2 and 4 give wrong results); keys 10..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------
@@ -311,12 +312,13 @@ int fyc_temporal_block_supported(const fyc_temporal_block_args* a);
  * 46 stages x 61 pieces x 1 KiB, a piece = one MFMA operand fragment of a 16 x 32 weight block B in lane order (byte 16 l of
  * the piece = B[l & 15][8 (l >> 4) .. +8], bf16):
  *   stage t < 5      pieces s * 20 + j (s = 0, 1; j < 20): Wp rows 16 j .. +16, columns 32 (2 t + s) .. +32  (Wp = merged weight [:, :C])
- *   stage 5 + c      pieces s * 4 + q (s < 10; q < 4): rows 64 c + 16 q .. +16 of the LayerNorm-folded, GEGLU-packed W1
- *                    (fyc_pack_geglu order: 16 value rows, their 16 gate rows, ...), columns 32 s .. +32;
- *                    piece 40: f32 colsum[64] | bias[64] of those 64 rows (rest of the piece unused);
- *                    pieces 41 + j (j < 20), for c >= 1: rows 16 j .. +16 of W2' = merged weight [:, C:], k-slot 8 g + e =
+ *   stage 5 + c      pieces s * 4 + q (s < 10; q < 4): rows 64 c + 16 q .. +16 of the GEGLU-packed W1 with the LayerNorm weight
+ *                    folded in (W1 * gamma; fyc_pack_geglu order: 16 value rows, their 16 gate rows, ...), columns 32 s .. +32;
+ *                    for c >= 1, of chunk c - 1: piece 40 = f32 bias[64] (b1 + W1 beta) of its 64 W1 rows (rest of the piece
+ *                    unused), pieces 41 + j (j < 20) = rows 16 j .. +16 of W2' = merged weight [:, C:], k-slot 8 g + e =
  *                    hidden unit 32 (c - 1) + 4 g + e (e < 4) or 32 (c - 1) + 16 + 4 g + e - 4 (e >= 4)
- *   stage 45         pieces 41 + j: the same for hidden chunk 39.
+ *   stage 45         piece 40 and pieces 41 + j: the same for hidden chunk 39.
+ * The kernel feeds FF1 the normalised tokens (x - mean) rstd rounded to bf16 (mean / variance over C in f32, two-pass).
  * (engine/weights.py::pack_ff_block builds it.)  chan_parts (optional): [rows / 128][C][2] f32 = per 128-row tile and channel
  * {sum, sum of squares} of the values as stored - fyc_gemm's chan_parts layout with tile_rows = 128 and one slot, for
  * fyc_chan_stats_reduce; needs cs_rows % 128 == 0.  Built for dtype bf16, C = 320, hidden = 1280, rows % 128 == 0

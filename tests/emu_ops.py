@@ -229,7 +229,7 @@ class EmuOps:
     @staticmethod
     def _ff_unpack(wstream, C_, hidden):
         """inverse of the fyc_ff_block weight stream (include/fyc.h), written from the layout description: returns
-        (Wp [C][C], W1 [2 hidden][C] GEGLU-packed, colsum, bias [2 hidden], W2' [C][hidden])"""
+        (Wp [C][C], W1 [2 hidden][C] GEGLU-packed with gamma folded in, bias [2 hidden] with beta folded in, W2' [C][hidden])"""
         nb, ks, chunks = C_ // 16, C_ // 32, hidden // 32
         pst, pc = (ks + 1) // 2, 4 * ks
         npc = max(2 * nb, pc + 1 + nb)
@@ -247,36 +247,38 @@ class EmuOps:
             for j in range(nb):
                 Wp[16 * j: 16 * j + 16, 32 * s_: 32 * s_ + 32] = block(S[s_ // 2, (s_ % 2) * nb + j])
         W1 = torch.zeros(2 * hidden, C_, dtype=wstream.dtype)
-        cs, bi = torch.zeros(2 * hidden), torch.zeros(2 * hidden)
+        bi = torch.zeros(2 * hidden)
         W2 = torch.zeros(C_, hidden, dtype=wstream.dtype)
         for c in range(chunks):
             for s_ in range(ks):
                 for q in range(4):
                     W1[64 * c + 16 * q: 64 * c + 16 * q + 16, 32 * s_: 32 * s_ + 32] = block(S[pst + c, 4 * s_ + q])
-            cst = S[pst + c, pc].reshape(-1).view(torch.float32)
-            cs[64 * c: 64 * c + 64], bi[64 * c: 64 * c + 64] = cst[:64], cst[64:128]
+            bi[64 * c: 64 * c + 64] = S[pst + c + 1, pc].reshape(-1).view(torch.float32)[:64]
             for j in range(nb):
                 blk = block(S[pst + c + 1, pc + 1 + j])                          # columns = k-slots 8 g + e
                 for k in range(32):
                     g_, e = k // 8, k % 8
                     unit = 4 * g_ + e if e < 4 else 16 + 4 * g_ + e - 4
                     W2[16 * j: 16 * j + 16, 32 * c + unit] = blk[:, k]
-        return Wp, W1, cs, bi, W2
+        return Wp, W1, bi, W2
 
     def ff_block(self, x, residual, out, *, wstream, b_out, rows, C_, hidden, eps=1e-5, chan_parts=None, cs_rows=0):
-        """out = residual + b_out + [x | GEGLU(LN(x) W1^T + b1)] [Wp | W2']^T (LayerNorm folded: rstd (x W1'^T - mean colsum) + b1');
-        the hidden activation is rounded to the storage dtype where the kernel packs it into MFMA operands; chan_parts
-        [rows / 128][C][2] = per 128-row tile {sum, sum of squares} of the stored output"""
+        """out = residual + b_out + [x | GEGLU(LN(x) W1^T + b1)] [Wp | W2']^T with gamma / beta folded into W1 / b1: the kernel
+        feeds FF1 the normalised tokens (x - mean) rstd rounded to the storage dtype; the hidden activation is rounded to the
+        storage dtype where the kernel packs it into MFMA operands; chan_parts [rows / 128][C][2] = per 128-row tile {sum, sum of
+        squares} of the stored output"""
         acc_t, T = self.acc, x.dtype
         key = (wstream.data_ptr(), C_, hidden)
         cache = self.__dict__.setdefault("_ff_cache", {})
         if key not in cache:
             cache[key] = self._ff_unpack(wstream, C_, hidden)
-        Wp, W1, cs, bi, W2 = cache[key]
+        Wp, W1, bi, W2 = cache[key]
         X = _flat(x)[: rows * C_].reshape(rows, C_).to(acc_t)
-        mean = X.mean(-1, keepdim=True)
-        rstd = (X.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
-        pre = rstd * (X @ W1.to(acc_t).t() - mean * cs.to(acc_t)) + bi.to(acc_t)
+        Xf = X.float()
+        mean = Xf.mean(-1, keepdim=True)
+        rstd = (Xf.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+        xn = ((Xf - mean) * rstd).to(T).to(acc_t)
+        pre = xn @ W1.to(acc_t).t() + bi.to(acc_t)
         blk = pre.reshape(rows, hidden // 16, 2, 16)
         h = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(rows, hidden).to(T).to(acc_t)
         y = X @ Wp.to(acc_t).t() + h @ W2.to(acc_t).t() + b_out.to(acc_t)

@@ -374,27 +374,35 @@ def test_ff_block_fused(hip, emu, rows, with_res, with_stats, variant):
         hip.ff_block(xc, None, xc, wstream=ws.cuda(), b_out=ff.po_b.cuda(), rows=rows, C_=C, hidden=hid)
 
 
-def test_ff_block_matches_unfused_schedule(hip):
+@pytest.mark.parametrize("rows", [16384, 8192])
+def test_ff_block_matches_unfused_schedule(hip, emu, rows):
     """the fused kernel against the three launches it replaces (row statistics, GEGLU GEMM with the folded LayerNorm, dual-K
-    output GEMM) on the device: same operands, same roundings up to the accumulation order"""
+    output GEMM) on the device: same operands, same roundings up to the accumulation order; both are also held to the
+    specification on a slice of the rows so that a failure names the side that is wrong"""
     from followyourclick_amd.engine.weights import pack_ff_block
     from followyourclick_amd import _lib as L
-    T, C, hid, rows = torch.bfloat16, 320, 1280, 8192
+    T, C, hid = torch.bfloat16, 320, 1280
     ff = _ff_operands(10)
-    ws = pack_ff_block(ff).cuda()
-    x = (rnd((rows, C), torch.float32, 6) * 1.2 - 0.2).to(T).cuda()
-    res = rnd((rows, C), T, 7).cuda()
+    ws = pack_ff_block(ff)
+    xc = (rnd((rows, C), torch.float32, 6) * 1.2 - 0.2).to(T)
+    rc = rnd((rows, C), T, 7)
+    x, res = xc.cuda(), rc.cuda()
     w1, b1, cs1, po_w, po_b = (t.cuda() for t in (ff.w1, ff.b1, ff.cs1, ff.po_w, ff.po_b))
-    o_f = torch.empty(rows, C, dtype=T, device="cuda")
-    hip.ff_block(x, res, o_f, wstream=ws, b_out=po_b, rows=rows, C_=C, hidden=hid)
+    o_f = torch.full((rows, C), float("nan"), dtype=T, device="cuda")
+    hip.ff_block(x, res, o_f, wstream=ws.cuda(), b_out=po_b, rows=rows, C_=C, hidden=hid)
     st = torch.empty(rows, 2, dtype=torch.float32, device="cuda")
     hip.row_stats(x, st, rows=rows, C_=C)
-    hmid = torch.empty(rows, hid, dtype=T, device="cuda")
+    hmid = torch.full((rows, hid), float("nan"), dtype=T, device="cuda")
     hip.gemm(x, w1, hmid, M=rows, N=2 * hid, K=C, lda=C, ldw=C, ldo=hid, bias=b1, epilogue=L.EPI_GEGLU, ln_colsum=cs1, ln_stats=st)
-    o_u = torch.empty(rows, C, dtype=T, device="cuda")
+    o_u = torch.full((rows, C), float("nan"), dtype=T, device="cuda")
     hip.gemm(x, po_w, o_u, M=rows, N=C, K=C + hid, lda=C, ldw=C + hid, ldo=C, bias=po_b, residual=res, ldr=C, a2=hmid, k_split=C, lda2=hid)
     torch.cuda.synchronize()
-    close(o_f, o_u.cpu(), "ff block vs unfused launches", 4e-3)
+    n = 512
+    o_e = torch.zeros(n, C, dtype=T)
+    emu.ff_block(xc[:n], rc[:n], o_e, wstream=ws, b_out=ff.po_b, rows=n, C_=C, hidden=hid)
+    close(o_f[:n], o_e, f"ff block vs specification rows{rows}", 6e-3)
+    close(o_u[:n], o_e, f"unfused launches vs specification rows{rows}", 6e-3)
+    close(o_f, o_u.cpu(), f"ff block vs unfused launches rows{rows}", 6e-3)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ def main():
     ff = Packed(w1=w1, b1=torch.randn(2 * HID, device=DEV) * 0.1, cs1=w1.float().sum(dim=1).contiguous(),
                 po_w=(torch.randn(C, C + HID, device=DEV) * (C + HID) ** -0.5).to(T), po_b=torch.randn(C, device=DEV) * 0.1)
     ws = pack_ff_block(ff)
-    for rows in (131072, 32768, 8192):
+    for rows in (131072, 32768):
         nb = 8 if rows >= 32768 else 16
         sets = [(torch.randn(rows, C, device=DEV).to(T), torch.randn(rows, C, device=DEV).to(T), torch.empty(rows, C, dtype=T, device=DEV),
                  torch.empty(rows, HID, dtype=T, device=DEV)) for _ in range(nb)]
@@ -58,11 +58,15 @@ def main():
 
         res = {}
         for rnd in range(3):                    # interleaved rounds: variants see the same clocks
-            for name, fn, key in (("unfused (3 launches)", unfused, None), ("ff_block pinned prefetch", fused, 0), ("ff_block compiler schedule", fused, 1)):
+            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block pinned prefetch", fused, 0, 0), ("ff_block compiler schedule", fused, 1, 0),
+                                      ("ff_block + rotated DMA order", fused, 0, 1), ("ABLATION no DMA", fused, 0, 2), ("ABLATION no MFMA work", fused, 0, 4),
+                                      ("ABLATION no MFMA, rotated DMA", fused, 0, 5), ("ABLATION neither", fused, 0, 6)):
                 if key is not None:
                     h.set_tuning(8, key)
+                h.set_tuning(9, k9)
                 res.setdefault(name, []).append(timed(fn, 2 * nb))
         h.set_tuning(8, 0)
+        h.set_tuning(9, 0)
         for name, v in res.items():
             us = min(v)
             print(f"rows={rows:7d}  {name:28s} {us:8.1f} us (min of {['%.1f' % t for t in v]})  {flops / us / 1e6:7.0f} TFLOP/s", flush=True)
