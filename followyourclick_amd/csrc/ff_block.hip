@@ -58,22 +58,31 @@ struct FFP {
   float* parts;              // [rows / 128][C][2] or null
   int ntiles;                // rows / 128
   float eps;
-  int tune;                  // fyc_set_tuning key 9 (measurement only): 1 = every block walks a stage's pieces from its own start, 2 = no DMA
-                             // after the first stages, 4 = no MFMA / gate work (DMA + barriers only) - 2 and 4 give wrong results
+  int tune;                  // fyc_set_tuning key 9 (measurement only): 1 = every block walks the pieces of a burst-issued stage from its own
+                             // start, 4 = no MFMA / gate work in the chunk stages (DMA + barriers only; wrong results)
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// 1 KiB global -> LDS by DMA, issued from inline asm: wave-uniform 64-bit base + one 32-bit lane offset, destination = wave-uniform
+// LDS byte address (+ 16 B per lane, implicit).  NOT the builtin: while a builtin LDS-DMA is outstanding hipcc turns every
+// counted lgkmcnt wait of the fragment reads into lgkmcnt(0) (it treats the DMA as a possible out-of-order LDS event), so each
+// k-step paid the full LDS round trip for fragments that were requested a k-step ahead (measured: 35 % of the wave's cycles in
+// s_waitcnt with and without the DMA).  The compiler does not count these loads: every stage barrier has its own vmcnt(0).
+__device__ __forceinline__ void dma16(const char* gbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_landed_barrier() {       // this wave's DMA pieces have landed, then the workgroup meets
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
 
-// VAR: 0 = the compiler's own schedule of a chunk; 1 = FF1 fragment reads pinned one k-step ahead of the MFMAs that consume them
-// (the compiler already deals the GEGLU gate's VALU work out between the FF2 MFMAs: a wave alone on its SIMD overlaps VALU with
-// the matrix pipe only where they alternate in program order)
+// VAR: 0 = the compiler's own interleave inside each pinned pair of k-steps (default: 3 % faster on MI355X, profiles/r03_ff_block_probe.txt);
+// 1 = the pair laid out with sched_group_barrier as MFMA, 3 VALU, MFMA, ... (fyc_set_tuning key 8 = 1)
 template <int VAR>
 __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,16 +99,16 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   const int lane = tid & 63;
   const int g = lane >> 4, r16 = lane & 15;
   const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the dynamic region
   auto issue = [&](int t) {                                   // DMA of stage t into slot t & 1: piece q by wave q % 4
     const int np = t < PROJ_ST ? NPIECE_PROJ : NPIECE;
     const char* src = p.ws + (long long)t * STAGE_BYTES;     // wave-uniform base + one 32-bit lane offset: no per-piece address registers
-    char* dst = smem + (t & 1) * STAGE_BYTES;
-    if ((p.tune & 2) && t > PROJ_ST + 1) return;
+    const unsigned dst = lds0 + (t & 1) * STAGE_BYTES;
 #pragma unroll 1
     for (int q = wave; q < np; q += 4) {
       int q2 = q + rot;                                         // the blocks of an XCD run in step and want the same bytes: spread them over
       if (q2 >= np) q2 -= np;                                   // the L2 channels instead of all asking for the same 1 KiB at once
-      glds16(src + q2 * PIECE + lane16, dst + q2 * PIECE);
+      dma16(src + q2 * PIECE, lane16, dst + q2 * PIECE);
     }
   };
 
@@ -152,20 +161,29 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) oacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // one piece of the NEXT stage's DMA, dealt out between the MFMA groups of this stage: n-th piece of this wave (piece wave + 4 n).
+  // Issued in a burst behind the barrier the 15 pieces of a wave cost it ~1500 cycles with the matrix pipe idle
+  // (profiles/r03_ff_block_ablation.txt: 118 -> 95 us per tile without them); beside MFMAs they are nearly free.
+  // (16 pieces per wave, no branch in the instruction stream: the 16th of waves 1-3 wraps around and fetches pieces 0-2 again.)
+  auto dma_piece = [&](int tnext, int n) {
+    int q = wave + 4 * n;
+    q = q >= NPIECE ? q - NPIECE : q;
+    dma16(p.ws + (long long)tnext * STAGE_BYTES + q * PIECE, lane16, lds0 + (tnext & 1) * STAGE_BYTES + q * PIECE);
+  };
+
   // ---- projection: out = tok Wp^T, stage t = k-steps 2t, 2t + 1 of all 20 column blocks ---------------------------------------
 #pragma unroll
   for (int t = 0; t < PROJ_ST; ++t) {
-    __syncthreads();                                          // stage t landed (the barrier drains the DMA queue); slot (t+1)&1 is free
-    issue(t + 1);
+    dma_landed_barrier();                                     // stage t landed; slot (t+1)&1 is free: its refill is dealt out below
     const char* sl = smem + (t & 1) * STAGE_BYTES + lane16;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int u = 0; u < 2 * NB; ++u) {
+      const int sk = u / NB, j = u % NB;
+      const bf16x8 wf = frag(sl, u);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const bf16x8 wf = frag(sl, s * NB + j);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, xa[i][2 * t + s], oacc[i][j]);
-      }
+      for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, xa[i][2 * t + sk], oacc[i][j]);
+      if (u < 16) dma_piece(t + 1, u);
+    }
   }
 
   // The tokens were needed raw for the projection; from here on they are only the FF1 operand: normalise them in place,
@@ -204,18 +222,31 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bi[q] = *reinterpret_cast<const f32x4*>(cst + q * 16 + g * 4);
   };
-  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[2]) {
+  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[2], int tnext, auto with_dma) {
+    constexpr bool WITH_DMA = decltype(with_dma)::value;
     const bf16x8 hb[2] = {__builtin_bit_cast(bf16x8, hbw[0]), __builtin_bit_cast(bf16x8, hbw[1])};
+    bf16x8 w[4];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const bf16x8 wf = frag(sl, P_W2 + j);
+    for (int q = 0; q < 4; ++q) w[q] = frag(sl, P_W2 + q);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, hb[i], oacc[i][j]);
+    for (int jb = 0; jb < NB / 4; ++jb) {                     // four column blocks per step, the next four fragments in flight
+      bf16x8 n[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n[q] = (jb + 1 < NB / 4) ? frag(sl, P_W2 + (jb + 1) * 4 + q) : w[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) oacc[i][jb * 4 + q] = mfma(w[q], hb[i], oacc[i][jb * 4 + q]);
+      if constexpr (WITH_DMA) dma_piece(tnext, KS + jb);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = n[q];
     }
+    if constexpr (WITH_DMA) dma_piece(tnext, KS + NB / 4);
   };
   // WITH_GATE: false for chunk 0 (nothing to gate yet).  The scheduler is pinned per pair of k-steps (sched_barrier): 8 fragment
   // reads one k-step ahead of their MFMAs, 16 MFMAs, one gate unit; VAR 1 additionally lays the pair out as MFMA, 3 VALU, MFMA, ...
-  auto stage = [&](const char* base, f32x4 (&hw)[2][4], const f32x4 (&hr)[2][4], auto with_gate) {
+  auto stage = [&](const char* base, f32x4 (&hw)[2][4], const f32x4 (&hr)[2][4], auto with_gate, int tnext) {
     constexpr bool WITH_GATE = decltype(with_gate)::value;
     const char* sl = base + lane16;
     f32x4 bi[4];
@@ -237,6 +268,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 2; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
+      if (s < 8) { dma_piece(tnext, 2 * s); dma_piece(tnext, 2 * s + 1); }        // all 16 pieces in the first 8 k-steps: a piece needs ~1 us to land
       if constexpr (WITH_GATE) {
         if (s < 8 && (s & 1)) gate_unit(s >> 1, bi, hr, hbw);
       }
@@ -259,30 +291,30 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) w[q] = n[q];
     }
-    if constexpr (WITH_GATE) ff2(sl, hbw);
+    if constexpr (WITH_GATE) ff2(sl, hbw, tnext, std::false_type{});
   };
 
   f32x4 h0[2][4], h1[2][4];
-  __syncthreads();                                            // stage 5 (chunk 0) landed
-  issue(PROJ_ST + 1);
-  if (work) stage(smem + (PROJ_ST & 1) * STAGE_BYTES, h0, h1, std::false_type{});
+  dma_landed_barrier();                                            // stage 5 (chunk 0) landed
+  if (work) stage(smem + (PROJ_ST & 1) * STAGE_BYTES, h0, h1, std::false_type{}, PROJ_ST + 1);
+  else issue(PROJ_ST + 1);
   for (int c = 1; c + 1 < CHUNKS; c += 2) {                  // chunks (1, 2), (3, 4), ..., (37, 38): pre-activation buffers alternate
     const int t = PROJ_ST + c;
-    __syncthreads();                                          // stage t landed; slot (t+1)&1 free
-    issue(t + 1);
-    if (work) stage(smem + (t & 1) * STAGE_BYTES, h1, h0, std::true_type{});
-    __syncthreads();
-    issue(t + 2);
-    if (work) stage(smem + ((t + 1) & 1) * STAGE_BYTES, h0, h1, std::true_type{});
+    dma_landed_barrier();                                          // stage t landed; slot (t+1)&1 free: its refill is dealt out inside the stage
+    if (work) stage(smem + (t & 1) * STAGE_BYTES, h1, h0, std::true_type{}, t + 1);
+    else issue(t + 1);
+    dma_landed_barrier();
+    if (work) stage(smem + ((t + 1) & 1) * STAGE_BYTES, h0, h1, std::true_type{}, t + 2);
+    else issue(t + 2);
   }
-  __syncthreads();                                            // chunk 39
-  issue(NSTAGE - 1);
-  if (work) stage(smem + ((NSTAGE - 2) & 1) * STAGE_BYTES, h1, h0, std::true_type{});
-  __syncthreads();                                            // last stage: gate + FF2 of chunk 39 only (reads pieces 40.. of its slot)
+  dma_landed_barrier();                                            // chunk 39
+  if (work) stage(smem + ((NSTAGE - 2) & 1) * STAGE_BYTES, h1, h0, std::true_type{}, NSTAGE - 1);
+  else issue(NSTAGE - 1);
+  dma_landed_barrier();                                            // last stage: gate + FF2 of chunk 39 only (reads pieces 40.. of its slot)
   if (p.res != nullptr) {                                     // the 128 residual rows are one contiguous 80 KiB: flat DMA over the idle part of the ring
     const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);
 #pragma unroll 1
-    for (int q = wave; q < TILE_BYTES / PIECE; q += 4) glds16(src + q * PIECE + lane16, smem + q * PIECE);
+    for (int q = wave; q < TILE_BYTES / PIECE; q += 4) dma16(src + q * PIECE, lane16, lds0 + q * PIECE);
   }
   if (work) {
     const char* base = smem + ((NSTAGE - 1) & 1) * STAGE_BYTES;
@@ -291,11 +323,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     load_consts(base, bi);
 #pragma unroll
     for (int u = 0; u < 4; ++u) gate_unit(u, bi, h1, hbw);
-    ff2(base + lane16, hbw);
+    ff2(base + lane16, hbw, 0, std::false_type{});
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------------------------
-  __syncthreads();                                            // residual tile landed; every wave is done with the ring
+  dma_landed_barrier();                                            // residual tile landed; every wave is done with the ring
   const float* bias_out = p.b_out;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -309,7 +341,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       for (int r = 0; r < 4; ++r) v[r] = oacc[i][j][r] + bo[r] + rr[r];
       ElemIO<bf16_t>::st4(a, v);
     }
-  __syncthreads();
+  dma_landed_barrier();
   // flat pass over the finished tile: thread (column group cg of 8 channels, row slice rsl) copies rows rsl, rsl + 6, ... to HBM,
   // 16 B per lane and 3840 contiguous bytes per step, and sums its 8 columns for the statistics of the values as stored
   {
@@ -410,7 +442,7 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
     }
   }
   const unsigned grid = (unsigned)p.ntiles;
-  if (g_fyc_tuning[8] == 1) hipLaunchKernelGGL(ff_block_kernel<0>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  if (g_fyc_tuning[8] != 1) hipLaunchKernelGGL(ff_block_kernel<0>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(ff_block_kernel<1>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_ff_block");
   return 0;

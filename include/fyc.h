@@ -41,8 +41,8 @@ int fyc_device_caps(int64_t* caps);
 /* tuning knobs for A/B measurements (0 = automatic): key 0 = 1 disables split-K, key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
  * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
  * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one,
- * key 8 = 1: fyc_ff_block with the compiler's own instruction schedule (0: FF1 fragment reads pinned one k-step ahead); key 9 = fyc_ff_block measurement
- * bits (1: per-block piece order of the weight DMA, 2: no DMA, 4: no MFMA work - 2 and 4 give wrong results); keys 10..15 reserved */
+ * key 8 = 1: fyc_ff_block with the sched_group_barrier layout of the gate / MFMA interleave (0: the compiler's own); key 9 = fyc_ff_block measurement
+ * bits (1: per-block piece order of the burst-issued weight DMA stages, 4: no MFMA work in the chunk stages - wrong results); keys 10..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------

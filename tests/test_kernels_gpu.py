@@ -351,7 +351,7 @@ def test_ff_block_fused(hip, emu, rows, with_res, with_stats, variant):
     assert not hip.ff_block_supported(T, rows=rows, C_=640, hidden=2560) and not hip.ff_block_supported(T, rows=rows, C_=C, hidden=hid, cs_rows=64)
     o_h = torch.full((rows, C), float("nan"), dtype=T, device="cuda")
     p_h = torch.full((rows // 128, C, 2), float("nan"), dtype=torch.float32, device="cuda") if with_stats else None
-    hip.set_tuning(8, 1 - variant)
+    hip.set_tuning(8, variant)
     try:
         hip.ff_block(x.cuda(), res.cuda() if with_res else None, o_h, wstream=ws.cuda(), b_out=ff.po_b.cuda(), rows=rows, C_=C, hidden=hid,
                      chan_parts=p_h, cs_rows=128 if with_stats else 0)

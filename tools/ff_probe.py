@@ -58,9 +58,8 @@ def main():
 
         res = {}
         for rnd in range(3):                    # interleaved rounds: variants see the same clocks
-            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block pinned prefetch", fused, 0, 0), ("ff_block compiler schedule", fused, 1, 0),
-                                      ("ff_block + rotated DMA order", fused, 0, 1), ("ABLATION no DMA", fused, 0, 2), ("ABLATION no MFMA work", fused, 0, 4),
-                                      ("ABLATION no MFMA, rotated DMA", fused, 0, 5), ("ABLATION neither", fused, 0, 6)):
+            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0), ("ff_block sched_group layout", fused, 1, 0),
+                                      ("ABLATION no MFMA work (weight DMA only)", fused, 0, 4)):
                 if key is not None:
                     h.set_tuning(8, key)
                 h.set_tuning(9, k9)
@@ -69,7 +68,7 @@ def main():
         h.set_tuning(9, 0)
         for name, v in res.items():
             us = min(v)
-            print(f"rows={rows:7d}  {name:28s} {us:8.1f} us (min of {['%.1f' % t for t in v]})  {flops / us / 1e6:7.0f} TFLOP/s", flush=True)
+            print(f"rows={rows:7d}  {name:40s} {us:8.1f} us (min of {['%.1f' % t for t in v]})  {flops / us / 1e6:7.0f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
