@@ -11,8 +11,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "_obj")
-LIB = os.path.join(HERE, "libfyc_hip.so")
+# A/B builds (tools/): FYC_BUILD_EXTRA="-DFYC_ATTN_BUILTIN_DMA" FYC_BUILD_LIB=tools/exp/libfyc_hip_x.so python -m followyourclick_amd._build
+EXTRA = os.environ.get("FYC_BUILD_EXTRA", "").split()
+LIB = os.path.abspath(os.environ.get("FYC_BUILD_LIB") or os.path.join(HERE, "libfyc_hip.so"))
+OBJ = os.path.join(HERE, "_obj") if not (EXTRA or os.environ.get("FYC_BUILD_LIB")) else LIB + ".obj"
 SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "temporal_block.hip", "ff_block.hip", "norm.hip", "elementwise.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file and every
 # kernel here fits in 256 registers), which removes the v_accvgpr_read/write traffic around the
@@ -25,8 +27,8 @@ AGPR_SOURCES = {"ff_block.hip"}
 
 def _flags(src: str):
     if src in AGPR_SOURCES:
-        return [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form=1")]
-    return FLAGS
+        return [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form=1")] + EXTRA
+    return FLAGS + EXTRA
 
 
 def _hipcc() -> str:

@@ -71,6 +71,9 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   if (tile > 0) { cfg = tile & 0xff; if (tile >> 8) ns = tile >> 8; }
   if (g_fyc_tuning[1] > 0) cfg = g_fyc_tuning[1];
   if (g_fyc_tuning[2] > 0) ns = g_fyc_tuning[2];
+  // GEGLU pairs 16-column value / gate blocks inside a wave: config 6 gives a wave 5 column blocks (128x320 over 2x4 waves) and
+  // used to leave the output unwritten (found by tools/gemm_diag.py at M = 4096 / 8192, N = 2560 - shapes the UNet never issued)
+  if (cfg == 6 && p.epilogue == FYC_EPI_GEGLU) cfg = 5;
   if (cfg != 1 || ns != 3) ns = 2;   // only config 1 is also built 3-deep
 }
 // column-tile width / row-tile height of a tile config (gemm_kernel.h::dispatch_cfg)
@@ -92,7 +95,7 @@ void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
   if (a->dtype == FYC_F32) { cfg = (a->N % 128 == 0) ? 1 : 2; ns = 2; return; }
   GemmP q;
   memset(&q, 0, sizeof(q));
-  q.M = a->M; q.N = a->N; q.K = a->K; q.mode = a->mode;
+  q.M = a->M; q.N = a->N; q.K = a->K; q.mode = a->mode; q.epilogue = a->epilogue;
   choose(q, a->batch > 0 ? a->batch : 1, a->tile, cfg, ns);
   if (stats && cfg == 8) cfg = 6;
   if (stats && cfg == 10) cfg = 1;

@@ -626,6 +626,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   constexpr int A_IT = BM * CPR / NT, B_IT = BN * CPR / NT;
   constexpr int LOADS = A_IT + B_IT;       // DMA instructions per thread per K tile
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+  static_assert(EPI != FYC_EPI_GEGLU || WTN % 2 == 0, "GEGLU pairs value / gate column blocks inside a wave");
   constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB;
   constexpr bool STAGGER = (WGM * WGN == 8) && KSTEPS >= 2 && NS == 2;
   static_assert(A_IT * NT == BM * CPR && B_IT * NT == BN * CPR, "tile/threads mismatch");
@@ -914,7 +915,8 @@ int dispatch_cfg(int cfg, int ns, const GemmP& p, int batch, hipStream_t st) {
       case 4: return launch<T, 256, 64, 4, 1, MODE, EPI, 2, 128, true>(p, batch, st);
       // N = 320*k (every layer width of SD-1.5): 320-wide tiles read the A panel once per 320 columns
       case 5: return launch<T, 256, 320, 4, 2, MODE, EPI, 2, 128, true>(p, batch, st);
-      case 6: return launch<T, 128, 320, 2, 4, MODE, EPI, 2, 128, true>(p, batch, st);
+      case 6: if constexpr (EPI == FYC_EPI_GEGLU) FYC_FAIL(-2, "fyc_gemm: tile config 6 gives a wave an odd number of column blocks: not built for GEGLU");
+              else return launch<T, 128, 320, 2, 4, MODE, EPI, 2, 128, true>(p, batch, st);
       case 7: return launch<T, 256, 256, 2, 4, MODE, EPI, 2, 128, true>(p, batch, st);
       // 64-byte K tiles: half the LDS per stage -> two independent 4-wave blocks per CU with 64x160 wave tiles (8)
       case 8: return launch<T, 128, 320, 2, 2, MODE, EPI, 2, 64, true>(p, batch, st);
