@@ -49,22 +49,9 @@ static __device__ __attribute__((aligned(16))) const unsigned short fyc_ones[72]
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-// 1 KiB global -> LDS by DMA (global_load_lds_dwordx4: per-lane source address, destination = wave-uniform LDS address + 16 B per
-// lane).  Default: issued from inline asm rather than through __builtin_amdgcn_global_load_lds - while a builtin LDS-DMA is
-// outstanding hipcc turns the lgkmcnt waits of the K / V^T fragment reads into lgkmcnt(0) (it cannot order the DMA against DS
-// operations), and the 3-deep ring always has DMA in flight.  The waits for the DMA itself are hand-counted (wait_vmcnt + raw
-// s_barrier); M0 is saved and restored because the compiler does not know the statement touches it.  -DFYC_ATTN_BUILTIN_DMA
-// builds the old form for A/B timing.
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-#ifdef FYC_ATTN_BUILTIN_DMA
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-#else
-  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-#endif
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
