@@ -282,8 +282,18 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
 }  // namespace
 
 extern "C" int fyc_temporal_block_supported(const fyc_temporal_block_args* a) {
-  return a != nullptr && a->dtype == FYC_BF16 && a->C == C_ && a->heads == H_ && a->d == D_ && a->frames == F_ && a->pixels > 0 &&
-         a->pixels % PIX == 0 && a->clips > 0;
+  if (!(a != nullptr && a->dtype == FYC_BF16 && a->C == C_ && a->heads == H_ && a->d == D_ && a->frames == F_ && a->pixels > 0 &&
+        a->pixels % PIX == 0 && a->clips > 0)) return 0;
+  static std::mutex mu;                            // LDS per CU of this process's device, queried once (0: no device answered)
+  static int64_t lds_cap = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (lds_cap < 0) {
+      int64_t caps[8];
+      lds_cap = (fyc_device_caps(caps) == 0) ? caps[1] : 0;
+    }
+  }
+  return (lds_cap > 0 && lds_cap < LDS_BYTES) ? 0 : 1;   // less LDS than the 153 KB tile needs: the engine keeps the unfused schedule
 }
 
 extern "C" int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream) {
@@ -303,8 +313,9 @@ extern "C" int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) FYC_FAIL(-3, "fyc_temporal_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
+      if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;      // only after success: a failed call is retried
     }
   }
   hipLaunchKernelGGL(temporal_block_kernel, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(512), LDS_BYTES, (hipStream_t)stream, p);

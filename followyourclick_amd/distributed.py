@@ -1,9 +1,10 @@
 """Data-parallel clip sharding: one process per GPU, zero collectives inside the DDIM loop.
 
 The reference shards prompts with DistributedSampler and makes every rank read every checkpoint from
-disk (reference scripts/inference.py:44-51, 260, 430; no collective is ever issued).  Here rank 0 loads /
-packs the weights once and the packed parameter tree is broadcast over RCCL (xGMI) - the only
-collective of a run; clips are then independent DDIM trajectories.
+disk (reference scripts/inference.py:44-51, 260, 430; no collective is ever issued).  Here rank 0 may load the
+weights once and broadcast them over RCCL (xGMI): `broadcast_packed` for an engine's packed tree (bench.py),
+`load_on_rank0` / `broadcast_module` for the drop-in nn.Modules - explicit calls, never hidden in a forward;
+clips are then independent DDIM trajectories with no collective.
 """
 from __future__ import annotations
 
@@ -93,31 +94,33 @@ def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> 
     return total
 
 
-_share = os.environ.get("FYC_BROADCAST_WEIGHTS", "1") != "0"
-
-
-def enable_weight_broadcast(on: bool = True) -> None:
-    """Whether the drop-in modules (UNet3DConditionModel, UNet2DConditionModel, AutoencoderKL) broadcast their packed weights
-    from rank 0 when torch.distributed is initialised (default on; FYC_BROADCAST_WEIGHTS=0 turns it off)."""
-    global _share
-    _share = bool(on)
-
-
-def share_packed(P: Packed, src: int = 0) -> int:
-    """The drop-in path's one collective: every rank packs what its module holds, then receives rank `src`'s packed tree, so
-    only rank `src` needs the real checkpoint (`load_on_rank0`).  The reference makes every rank read every checkpoint from disk
-    (scripts/inference.py:44-51, 152-181).  Returns bytes moved (0 without a process group)."""
-    if not _share:
+def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 256 << 20) -> int:
+    """Overwrite every parameter and buffer of `module` with rank `src`'s, in place (bucketed like `broadcast_packed`).  An
+    EXPLICIT collective: every rank must call it, at the same point of the script, for the same module.  It covers whatever
+    the module holds - UNet3D / UNet2D (with `image_proj_model`), both halves of AutoencoderKL, Resampler, ImageProjModel,
+    the CLIP wrappers - because it moves the state dict itself, not a packed engine tree; the engines re-pack at the next
+    forward (in-place copies bump the tensor versions they key on).  Returns bytes moved (0 without a process group)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
-    return broadcast_packed(P, src=src)
+    tree = Packed({k: v for k, v in module.state_dict(keep_vars=True).items() if isinstance(v, torch.Tensor)})
+    with torch.no_grad():
+        return broadcast_packed(tree, src=src, bucket_bytes=bucket_bytes)
 
 
-def load_on_rank0(loader, *args, **kwargs):
-    """run a checkpoint loader (e.g. `unet.load_state_dict(torch.load(path))`) on rank 0 only; the other ranks keep their
-    initial parameters, which `share_packed` overwrites in the packed engine tree at first use"""
-    if not dist.is_initialized() or dist.get_rank() == 0 or not _share:
+def load_on_rank0(module, loader=None, *args, **kwargs):
+    """`load_on_rank0(module, loader, *args)`: run a checkpoint loader (e.g. `lambda: unet.load_state_dict(torch.load(path))`) on
+    rank 0 only, then broadcast the module's parameters and buffers from rank 0 (`broadcast_module`) - one disk read instead of
+    the reference's N (scripts/inference.py:44-51, 152-181).  Every rank must make the call.  Returns the loader's result on
+    rank 0, None elsewhere.  Without a process group it just runs the loader.
+    (Round-2 form `load_on_rank0(loader)`, which relied on a broadcast hidden in the first forward, is gone: that broadcast
+    covered only part of the modules and could deadlock rank-divergent scripts.)"""
+    if loader is None or not isinstance(module, torch.nn.Module):
+        raise TypeError("load_on_rank0(module, loader, *args): pass the nn.Module whose weights the loader fills, then the loader")
+    if not dist.is_initialized() or dist.get_world_size() == 1:
         return loader(*args, **kwargs)
-    return None
+    out = loader(*args, **kwargs) if dist.get_rank() == 0 else None
+    broadcast_module(module, src=0)
+    return out
 
 
 def barrier() -> None:

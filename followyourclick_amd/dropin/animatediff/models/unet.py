@@ -20,7 +20,6 @@ from typing import Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from followyourclick_amd import distributed as D
 from followyourclick_amd import ops as ops_mod
 from followyourclick_amd.engine import UNet3DConfig
 from followyourclick_amd.engine.schema import unet_schema
@@ -177,7 +176,6 @@ class UNet3DConditionModel(nn.Module):
                 raise RuntimeError("UNet3DConditionModel runs on an MI355X HIP device only (call .to('cuda')); no CPU fallback")
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith("image_proj_model")}
             packed = pack_unet(sd, self.engine_config, self.compute_dtype, self.device)
-            D.share_packed(packed)          # torch.distributed initialised: rank 0's weights, one RCCL broadcast
             self._engine = UNet3DEngine(packed)
             self._engine_key, self._ctx_key = key, None
         return self._engine

@@ -13,7 +13,6 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
-from followyourclick_amd import distributed as D
 from followyourclick_amd import ops as ops_mod
 from followyourclick_amd.engine import VAEDecoderConfig
 from followyourclick_amd.engine.schema import vae_decoder_schema, vae_encoder_schema
@@ -112,7 +111,6 @@ class AutoencoderKL(nn.Module):
                 raise RuntimeError("AutoencoderKL.decode runs on an MI355X HIP device only (call .to('cuda')); no CPU fallback")
             sd = {k: v for k, v in self.state_dict().items() if k.startswith(("decoder.", "post_quant_conv."))}
             packed = pack_vae_decoder(sd, self.engine_config, self.compute_dtype, self.device)
-            D.share_packed(packed)          # torch.distributed initialised: rank 0's weights, one RCCL broadcast
             self._engine = VAEDecoderEngine(packed)
             self._engine_key = key
         return self._engine

@@ -51,6 +51,8 @@ class HipOps:
         self.lib = L.load()
         self._zero = None
         self._ws = None              # scratch for split-K GEMMs: one buffer, grown on demand (all work is on one stream)
+        self._ws_need = {}           # (shape, flags) -> split-K scratch bytes (fyc_gemm_workspace_bytes), see gemm()
+        self._q_cache = {}           # host-side layout queries (row parts, split bytes, statistics layout) per shape
         self._inited_dev = None
 
     # -- library ---------------------------------------------------------------------------
@@ -79,6 +81,8 @@ class HipOps:
 
     def set_tuning(self, key: int, value: int) -> None:
         L.check(self.lib.fyc_set_tuning(key, value), "fyc_set_tuning")
+        self._ws_need.clear()        # tile / split-K decisions depend on the tuning table
+        self._q_cache.clear()
 
     @staticmethod
     def _stream() -> int:
@@ -102,37 +106,55 @@ class HipOps:
                             stride_a=stride_a, stride_w=stride_w, stride_o=stride_o, heads=heads, tile=tile, a2=a2, k_split=k_split,
                             lda2=lda2, act=act, ln_stats=ln_stats, ln_colsum=ln_colsum, ln_nparts=ln_nparts, ln_eps=ln_eps,
                             chan_parts=chan_parts, cs_rows=cs_rows, row_parts=row_parts, row_nparts=row_nparts)
-        if hasattr(self.lib, "fyc_gemm_workspace_bytes"):
-            need = int(self.lib.fyc_gemm_workspace_bytes(C.byref(g)))     # split-K scratch (small M, long K)
-            if need > 0:
-                if self._ws is None or self._ws.numel() < need or self._ws.device != a.device:
-                    self._ws = torch.empty(need, dtype=torch.uint8, device=a.device)
-                g.workspace, g.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        # split-K scratch (small M, long K): the decision depends on the shape and the flags below only - cached, so that the ~300
+        # GEMM launches of a DDIM step do not each pay a second ctypes call.  One grown-on-demand buffer: all work of a process is on
+        # ONE stream (the engine's), a second stream would need its own HipOps.
+        key = (M, N, K, mode, epilogue, act, batch, tile, g.dtype, ln_stats is not None, chan_parts is not None, row_parts is not None)
+        need = self._ws_need.get(key)
+        if need is None:
+            need = int(self.lib.fyc_gemm_workspace_bytes(C.byref(g))) if hasattr(self.lib, "fyc_gemm_workspace_bytes") else 0
+            self._ws_need[key] = need
+        if need > 0:
+            if self._ws is None or self._ws.numel() < need or self._ws.device != a.device:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+            g.workspace, g.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
         self._call("fyc_gemm", g)
 
     def gemm_row_parts(self, dtype: torch.dtype, *, M: int, N: int, K: int, mode: int = L.GEMM_PLAIN, batch: int = 1, tile: int = 0) -> int:
         """column tiles fyc_gemm will use for this problem = row_nparts of its `row_parts` output (fyc_gemm_row_parts)"""
-        g = L.GemmArgs()
-        g.M, g.N, g.K, g.mode, g.batch, g.tile = M, N, K, mode, batch, tile
-        g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
-        return int(self.lib.fyc_gemm_row_parts(C.byref(g)))
+        key = ("rp", dtype, M, N, K, mode, batch, tile)
+        if key not in self._q_cache:
+            g = L.GemmArgs()
+            g.M, g.N, g.K, g.mode, g.batch, g.tile = M, N, K, mode, batch, tile
+            g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+            self._q_cache[key] = int(self.lib.fyc_gemm_row_parts(C.byref(g))) if hasattr(self.lib, "fyc_gemm_row_parts") else 0
+        return self._q_cache[key]
 
     def gemm_split_bytes(self, dtype: torch.dtype, *, M: int, N: int, K: int, mode: int = L.GEMM_PLAIN) -> int:
         """scratch bytes a plain LINEAR-epilogue problem of this shape would use for split-K (0: it runs unsplit)"""
-        g = L.GemmArgs()
-        g.M, g.N, g.K, g.mode, g.batch, g.epilogue = M, N, K, mode, 1, L.EPI_LINEAR
-        g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
-        return int(self.lib.fyc_gemm_workspace_bytes(C.byref(g)))
+        key = ("sb", dtype, M, N, K, mode)
+        if key not in self._q_cache:
+            g = L.GemmArgs()
+            g.M, g.N, g.K, g.mode, g.batch, g.epilogue = M, N, K, mode, 1, L.EPI_LINEAR
+            g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+            self._q_cache[key] = int(self.lib.fyc_gemm_workspace_bytes(C.byref(g))) if hasattr(self.lib, "fyc_gemm_workspace_bytes") else 0
+        return self._q_cache[key]
 
     def gemm_stat_layout(self, dtype: torch.dtype, *, M: int, N: int, K: int, cs_rows: int, mode: int = L.GEMM_PLAIN, batch: int = 1,
                          tile: int = 0):
         """(row tiles, rows per tile, sample slots per tile) of the `chan_parts` output of this problem (fyc_gemm_stat_layout)"""
-        g = L.GemmArgs()
-        g.M, g.N, g.K, g.mode, g.batch, g.tile, g.cs_rows = M, N, K, mode, batch, tile, cs_rows
-        g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
-        tr, sl = L.i32(0), L.i32(0)
-        n = int(self.lib.fyc_gemm_stat_layout(C.byref(g), C.byref(tr), C.byref(sl)))
-        return n, int(tr.value), int(sl.value)
+        key = ("sl", dtype, M, N, K, cs_rows, mode, batch, tile)
+        if key not in self._q_cache:
+            if not hasattr(self.lib, "fyc_gemm_stat_layout"):       # an older A/B library (FYC_LIB_PATH): no fused statistics
+                self._q_cache[key] = (0, 0, 0)
+            else:
+                g = L.GemmArgs()
+                g.M, g.N, g.K, g.mode, g.batch, g.tile, g.cs_rows = M, N, K, mode, batch, tile, cs_rows
+                g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+                tr, sl = L.i32(0), L.i32(0)
+                n = int(self.lib.fyc_gemm_stat_layout(C.byref(g), C.byref(tr), C.byref(sl)))
+                self._q_cache[key] = (n, int(tr.value), int(sl.value))
+        return self._q_cache[key]
 
     def chan_stats_reduce(self, parts: Tensor, cs: Tensor, *, rows: int, N: int, cs_rows: int, tile_rows: int, slots: int,
                           out_rows: int = 0) -> None:
@@ -220,14 +242,20 @@ class HipOps:
         output statistics for a GroupNorm whose statistics sample has cs_rows rows"""
         if not hasattr(self.lib, "fyc_ff_block_supported"):
             return False
+        key = ("ffs", dtype, rows, C_, hidden, cs_rows)
+        if key in self._q_cache:
+            return self._q_cache[key]
         a = L.FFBlockArgs()
         a.rows, a.C, a.hidden, a.cs_rows = rows, C_, hidden, cs_rows
         a.chan_parts = 16 if cs_rows > 0 else None         # only tested for null / alignment by the query
         a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
-        return bool(self.lib.fyc_ff_block_supported(C.byref(a)))
+        self._q_cache[key] = bool(self.lib.fyc_ff_block_supported(C.byref(a)))
+        return self._q_cache[key]
 
     def ff_block_wstream_bytes(self) -> int:
-        return int(self.lib.fyc_ff_block_wstream_bytes())
+        if "ffw" not in self._q_cache:
+            self._q_cache["ffw"] = int(self.lib.fyc_ff_block_wstream_bytes())
+        return self._q_cache["ffw"]
 
     def ff_block(self, x: Tensor, residual: Optional[Tensor], out: Tensor, *, wstream: Tensor, b_out: Tensor, rows: int, C_: int,
                  hidden: int, eps: float = 1e-5, chan_parts: Optional[Tensor] = None, cs_rows: int = 0) -> None:

@@ -95,8 +95,18 @@ def _dropin_worker(rank, world, port, tmp):
     if rank == 0:
         torch.save(unet.state_dict(), ckpt)
     D.barrier()
-    loaded = D.load_on_rank0(lambda: unet.load_state_dict(torch.load(ckpt), strict=False))
+    loaded = D.load_on_rank0(unet, lambda: unet.load_state_dict(torch.load(ckpt), strict=False))     # explicit collective: every rank calls it
     assert (loaded is not None) == (rank == 0)
+    try:
+        D.load_on_rank0(lambda: None)                       # the round-2 call form (no module) must fail loudly, not skip the broadcast
+        raise AssertionError("load_on_rank0(loader) without a module was accepted")
+    except TypeError:
+        pass
+    # anything with a state dict is covered, buffers included (the VAE encoder half, Resampler, ImageProjModel were not in round 2)
+    extra = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.BatchNorm1d(8))
+    extra[1].running_mean.fill_(float(rank + 1))
+    moved = D.broadcast_module(extra)
+    assert moved > 0 and float(extra[1].running_mean[0]) == 1.0
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 9, 2, 8, 8, generator=g)
     text = torch.randn(2, 77, 64, generator=g)
@@ -106,8 +116,9 @@ def _dropin_worker(rank, world, port, tmp):
 
 
 def test_dropin_unet_receives_rank0_weights(tmp_path):
-    """scripts/inference.py --ddp equivalent: with a process group the drop-in UNet broadcasts rank 0's packed weights, so the
-    ranks that never read the checkpoint produce rank 0's outputs"""
+    """scripts/inference.py --ddp equivalent: `load_on_rank0(module, loader)` reads the checkpoint on rank 0 and broadcasts the
+    module's state dict, so the ranks that never read the checkpoint produce rank 0's outputs; nothing collective is hidden in
+    the forward any more (round-2 advice: the lazy broadcast covered only part of the modules and could deadlock)"""
     world, port = 2, 29743
     mp.spawn(_dropin_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     a, b = (torch.load(os.path.join(tmp_path, f"dropin{r}.pt")) for r in (0, 1))
