@@ -50,10 +50,27 @@ def synthetic_inputs(cfg, frames, h, w, seed, device):
     return dict(latents=lat.to(device), first=first.to(device), mask=mask.to(device), text=text.to(device))
 
 
-def cpu_baseline(sd, frames, h, w, ddim_steps, sample_frames=2, timed=2):
-    """The oracle (CPU port of the reference math, fp32) on all host cores, per BASELINE.md 3: 1 warm-up + `timed` timed CFG-pair
-    UNet3D forwards (= DDIM steps) at the benchmark resolution, on a BOUNDED sample of `sample_frames` of the clip's frames (the
-    cost is linear in the frame count; a full 16-frame step takes minutes), extrapolated x frames x ddim_steps."""
+def physical_cores() -> int:
+    """host cores without SMT siblings (the oracle's matmuls do not gain from hyper-threads; 128 logical threads on the round-2
+    box ran a 2-frame forward slower per frame than 8 cores run the 16-frame one)"""
+    try:
+        seen = set()
+        for d in os.listdir("/sys/devices/system/cpu"):
+            if d.startswith("cpu") and d[3:].isdigit():
+                with open(f"/sys/devices/system/cpu/{d}/topology/thread_siblings_list") as f:
+                    seen.add(f.read().strip())
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(sd, frames, h, w, ddim_steps, sample_frames=2, timed=1):
+    """The oracle (CPU port of the reference math, fp32) per BASELINE.md 3, threads pinned to the physical cores: 1 warm-up + `timed`
+    timed CFG-pair UNet3D forwards (= DDIM steps) at the benchmark resolution, on a BOUNDED sample of `sample_frames` of the clip's
+    frames (the conv / spatial-attention cost is linear in the frame count; a full 16-frame step takes minutes), extrapolated
+    x frames x ddim_steps."""
     from oracle import functional as Fn  # test infrastructure: used only as the reported CPU baseline
     cfg = Fn.UNetConfig()
     g = torch.Generator().manual_seed(1)
@@ -61,17 +78,23 @@ def cpu_baseline(sd, frames, h, w, ddim_steps, sample_frames=2, timed=2):
     x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g)
     text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
-    cores = torch.get_num_threads()
+    before = torch.get_num_threads()
+    cores = min(physical_cores(), before) if before > 0 else physical_cores()
+    torch.set_num_threads(cores)
     times = []
-    with torch.no_grad():
-        for i in range(1 + timed):
-            t0 = time.time()
-            Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961 - 40 * i), text, fps, flow)
-            times.append(time.time() - t0)
+    try:
+        with torch.no_grad():
+            for i in range(1 + timed):
+                t0 = time.time()
+                Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961 - 40 * i), text, fps, flow)
+                times.append(time.time() - t0)
+    finally:
+        torch.set_num_threads(before)
     dt = sum(times[1:]) / timed
     return dict(value=frames / (ddim_steps * dt), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 warm-up ({times[0]:.1f}s) + {timed} timed DDIM steps (mean {dt:.1f}s) on {frames} of the {total_frames} frames: CFG-pair "
-                       f"UNet3D forward at {h * 8}x{w * 8}, fp32 oracle, {cores} threads; frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
+                sample=f"1 warm-up ({times[0]:.1f}s) + {timed} timed DDIM step(s) (mean {dt:.1f}s) on {frames} of the {total_frames} frames: CFG-pair "
+                       f"UNet3D forward at {h * 8}x{w * 8}, fp32 oracle, torch.set_num_threads({cores}) = physical cores of {os.cpu_count()} logical; "
+                       f"frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
 
 
 def main():
@@ -182,18 +205,30 @@ def main():
         ms = sum(v["ms"] for v in mm.values())
         launches = sum(v["launches"] for v in mm.values())
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = None   # HBM bytes per launch from PMC counters (collected offline with rocprofv3 --pmc, see profiles/)
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if os.path.exists(tpath) and args.frames == 16 and args.size == 512 and args.dtype == "bf16":
-            try:
-                traffic = round(json.load(open(tpath))["families"]["gemm"]["hbm_bytes_per_launch"])
-            except Exception:
-                traffic = None
+        # HBM bytes per launch from PMC counters (collected offline with rocprofv3 --pmc, tools/collect_profiles.sh): reported only
+        # when the profile was taken on THIS library binary (sha256 stamped by tools/hbm_traffic.py), otherwise null
+        traffic, traffic_note = None, "no PMC profile of this library binary under profiles/ (tools/collect_profiles.sh regenerates it)"
+        if args.frames == 16 and args.size == 512 and args.dtype == "bf16":
+            import glob
+            import hashlib
+            from followyourclick_amd import _lib as L_
+            with open(L_.LIB_PATH, "rb") as f:
+                digest = hashlib.sha256(f.read()).hexdigest()
+            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+                try:
+                    doc = json.load(open(tpath))
+                    if doc.get("lib_sha256") == digest:
+                        traffic = round(doc["families"]["gemm"]["hbm_bytes_per_launch"])
+                        traffic_note = (f"avg HBM bytes per fyc_gemm_kernel launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE on "
+                                        f"this library binary (sha256 {digest[:12]}), {os.path.relpath(tpath, ROOT)}")
+                        break
+                except Exception:
+                    continue
         alg_bytes = sum(v["bytes"] for v in mm.values()) / launches
         result["roofline"] = {"kernel": "fyc_gemm_kernel (MFMA GEMM + implicit-GEMM conv3x3)", "bound": "mfma",
                               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                               "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": traffic,
-                              "traffic_note": "avg HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r02_hbm_traffic.json",
+                              "traffic_note": traffic_note,
                               "algorithmic_bytes_per_launch": round(alg_bytes),
                               "launches_per_ddim_step": launches // n_inst, "avg_launch_us": round(1e3 * ms / launches, 2),
                               "algorithmic_tflop_per_ddim_step": round(fl / n_inst / 1e12, 3)}

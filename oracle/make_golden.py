@@ -40,7 +40,7 @@ def ref_unet(cfg: Fn.UNetConfig):
         norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps, act_fn="silu", use_linear_projection=False,
         use_motion_module=True, motion_module_resolutions=(1, 2, 4, 8), unet_use_cross_frame_attention=False,
         unet_use_temporal_attention=False, use_fps_condition=True, use_first_frame_mask_condition_concat=True,
-        motion_module_type="Vanilla", motion_module_kwargs=dict(MM_KW),
+        motion_module_type="Vanilla", motion_module_kwargs=dict(MM_KW, temporal_position_encoding_max_len=cfg.temporal_position_encoding_max_len),
         use_ip_cross_attention=cfg.use_ip_cross_attention, num_tokens=cfg.ip_num_tokens, scale=cfg.ip_scale)
 
 

@@ -7,6 +7,8 @@ production precision, by executing the REAL reference (container only; TEST INFR
     python -m oracle.make_golden_full p2         # AnimationPipeline.prepare_latents (init-latents blend / interpolate noise)
     python -m oracle.make_golden_full cfg1       # BASELINE configs[0]: 8 frames 256x256, 5 DDIM steps, full pipeline
     python -m oracle.make_golden_full cfg2       # BASELINE configs[1]: 16 frames 512x512, 25 DDIM steps (~1.5 h on 8 cores)
+    python -m oracle.make_golden_full cfg4       # BASELINE configs[3] paths: F=32 forward (24x24 latent) and a 96x96-latent forward, max_len 32
+    python -m oracle.make_golden_full cfg5       # BASELINE configs[4]: 5-step IP-Adapter + rectangle-mask trajectory (4 frames 128x128)
 
 Every UNet golden exists twice: `*_f32` = the reference as the CPU runs it (fp32), `*_bf16` = the same
 reference code under the CUDA-autocast cast policy with bfloat16 (oracle/autocast_emul.py), i.e. the
@@ -206,6 +208,90 @@ def _trajectory(tag, frames, lat, steps, keep, seed):
         np.savez_compressed(os.path.join(OUT, f"{tag}_trajectory.npz"), **d)
 
 
+def cfg4():
+    """BASELINE configs[3] (32 frames 768x768, temporal_position_encoding_max_len 32): the two paths it adds to cfg2 -
+    (a) F = 32: the 32 x 32-score temporal attention at d = 40 / 80 / 160 and the 32-row positional table (motion_module.py:286-304,
+        371-464), one forward at a reduced 24x24 latent;
+    (b) a 96x96 latent: spatial attention over N = 9216 tokens (F = 2 keeps the CPU run to minutes).
+    Both with the max_len = 32 UNet, f32 and bf16-autocast."""
+    cfg, unet = full_unet(max_len=32)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    kw = dict(use_fps_condition=True, fps_tensor=fps, flow_control=flow)
+    d = dict(timestep=np.int64(961), fps=fps.numpy(), flow=flow.numpy(), weight_seed=np.int64(0), max_len=np.int64(32))
+    for tag, F, lat, seed in (("f32x24", 32, 24, 61), ("f2x96", 2, 96, 62)):
+        inp = W.seeded_inputs(cfg, 1, F, lat, lat, seed=seed)
+        x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+        t0 = time.time()
+        with torch.no_grad():
+            y32 = unet(x9, torch.tensor(961), inp["text"], **kw).sample
+            with CudaAutocastOnCpu(torch.bfloat16):
+                y16 = unet(x9, torch.tensor(961), inp["text"], **kw).sample.float()
+        dr = rel(y16, y32)
+        log(f"cfg4 {tag}: F={F} latent {lat}x{lat}: drift bf16-autocast vs f32 = {dr:.3e} ({time.time() - t0:.0f}s)")
+        d.update({f"{tag}_out_f32": y32.numpy(), f"{tag}_out_bf16": y16.numpy(), f"{tag}_drift": np.float64(dr), f"{tag}_frames": np.int64(F),
+                  f"{tag}_lat": np.int64(lat), f"{tag}_input_seed": np.int64(seed)})
+        np.savez_compressed(os.path.join(OUT, "cfg4_forwards.npz"), **d)
+
+
+def cfg5():
+    """BASELINE configs[4] as a TRAJECTORY: AnimationPipeline.__call__ with the IP-Adapter branch (16 image tokens, scale 0.7), the
+    rectangle region mask + first-frame latent concat, CFG 8, 5 DDIM steps, full SD-1.5 widths, 4 frames 128x128 (pipeline_animation.py
+    :676-680, 716-723; animatediff/models/attention.py:49-127).  The reference's CPU code path runs attn2 at the IP weight as softmax
+    temperature (SURVEY headline 6), so three trajectories are stored: the real reference (f32, and bf16-autocast for the drift),
+    and oracle.functional WITHOUT that quirk (= the deployed xformers semantics the engine implements).  tests/test_oracle_golden.py
+    holds the oracle WITH the quirk to the real reference; tests/test_fullwidth_gpu.py holds the engine to the oracle without it."""
+    frames, lat, steps, seed = 4, 16, 5, 63
+    cfg = Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7, ip_reference_cpu_scale_quirk=True)
+    unet = ref_unet(cfg).eval()
+    sd = W.make_weights(W.unet_state_shapes(cfg), seed=0)
+    unet.load_state_dict(sd, strict=True)
+
+    class Proj(torch.nn.Module):
+        def forward(self, feat):
+            return feat
+    unet.image_proj_model = Proj()
+    pipe = _pipeline(unet, cfg)
+    pipe.decode_latents = lambda latents: np.zeros((1, 3, frames, 8, 8), dtype=np.float32)
+    inp = W.seeded_inputs(cfg, 1, frames, lat, lat, seed=seed)
+    mask = torch.zeros(1, 1, 1, lat, lat)
+    mask[..., lat // 4: 3 * lat // 4, lat // 4: 3 * lat // 4] = 1.0          # the rectangle of SURVEY.md 8d (a SAM box stand-in)
+    inp["first_images_mask"] = mask
+
+    class IP:                                                   # MyIPAdapter.get_image_clip_feat stand-in: seeded "CLIP features"
+        def get_image_clip_feat(self, input_image=None):
+            return inp["ip_tokens"][1:2], inp["ip_tokens"][0:1]
+    pipe.ip_adapter = IP()
+    with torch.no_grad():
+        text_emb = pipe._encode_prompt(["a corgi waving its tail"], "cpu", 1, True, ["blurry"])
+
+    def run():
+        traj = {}
+
+        def cb(i, t, l):
+            traj[i] = l.clone().float()
+        pipe("a corgi waving its tail", video_length=frames, height=lat * 8, width=lat * 8, num_inference_steps=steps, guidance_scale=8.0,
+             negative_prompt="blurry", latents=inp["latents"].clone(), first_image_latents=inp["first_image_latents"],
+             first_images_mask=inp["first_images_mask"], use_first_frame_mask_condition_concat=True, use_fps_condition=True,
+             fps_tensor=torch.tensor([2]), flow_control=torch.tensor([4]), use_ip_cross_attention=True, condition_images=[None],
+             callback=cb, callback_steps=1, output_type="latent")
+        return traj
+    with torch.no_grad():
+        t32 = run()
+        with CudaAutocastOnCpu(torch.bfloat16):
+            t16 = run()
+        ocfg = Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7)
+        tor = {}
+        Fn.denoise(sd, ocfg, Fn.DDIMConfig(), inp["latents"].clone(), text_emb, steps, 8.0, inp["first_image_latents"], inp["first_images_mask"],
+                   torch.tensor([2]), torch.tensor([4]), ip_tokens=inp["ip_tokens"], callback=lambda i, t, l: tor.__setitem__(i, l.clone().float()))
+    d = dict(text_embeddings=text_emb.numpy(), steps=np.int64(steps), frames=np.int64(frames), lat=np.int64(lat), weight_seed=np.int64(0),
+             input_seed=np.int64(seed), ip_scale=np.float64(0.7), ip_num_tokens=np.int64(16), first_images_mask=mask.numpy())
+    for i in range(steps):
+        d[f"step{i}_ref_f32"], d[f"step{i}_ref_bf16"], d[f"step{i}_oracle_noquirk"] = t32[i].numpy(), t16[i].numpy(), tor[i].numpy()
+        d[f"drift{i}"] = np.float64(rel(t16[i], t32[i]))
+        log(f"cfg5 step {i}: ref drift bf16 vs f32 {d[f'drift{i}']:.3e}; oracle(no quirk) vs reference(CPU quirk) {rel(tor[i], t32[i]):.3e}")
+    np.savez_compressed(os.path.join(OUT, "cfg5_trajectory.npz"), **d)
+
+
 def cfg1():
     _trajectory("cfg1", 8, 32, 5, {0, 1, 2, 3, 4}, seed=51)
 
@@ -219,6 +305,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     for part in sys.argv[1:]:
         log("==", part)
-        dict(small=small, ip=ip, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2)[part]()
+        dict(small=small, ip=ip, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2, cfg4=cfg4, cfg5=cfg5)[part]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -35,7 +35,7 @@ def _load(golden_dir, name):
     return {k: torch.from_numpy(v) if v.shape else v for k, v in np.load(os.path.join(golden_dir, name)).items()}
 
 
-@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1.5e-1, 1e-1)])
+@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1.05e-1, 5.5e-2)])      # bf16: 2 x the measured 5.2e-2 / 2.7e-2
 def test_animation_pipeline_call(dropin, golden_dir, dtype, tol_lat, tol_vid):
     from animatediff.models.unet import UNet3DConditionModel
     from animatediff.pipelines.pipeline_animation import AnimationPipeline

@@ -106,7 +106,7 @@ def test_unet_forward_ip_adapter_vs_oracle(dtype, tol):
     assert r < tol, r
 
 
-@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1.5e-1, 1e-1)])
+@pytest.mark.parametrize("dtype,tol_lat,tol_vid", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1.05e-1, 5.5e-2)])      # bf16: 2 x the measured 5.2e-2 / 2.7e-2
 def test_sampling_loop_vs_reference_pipeline(golden_dir, dtype, tol_lat, tol_vid):
     """AnimationPipeline.__call__ of the real reference: 5 DDIM steps, CFG 8, mask + first frame,
     fps/flow conditioning; per-step latents and the decoded video."""

@@ -5,6 +5,8 @@ precision, against golden vectors from the REAL reference (oracle/make_golden_fu
   cfg1_trajectory.npz       BASELINE configs[0]: AnimationPipeline.__call__, 8 frames 256x256, 5 DDIM steps, every step's latents
   cfg2_trajectory.npz       BASELINE configs[1]: 16 frames 512x512, 25 DDIM steps, latents after steps 0 / 4 / 24
   vae_full.npz              AutoencoderKL.decode at (128, 256, 512, 512)
+  cfg4_forwards.npz         BASELINE configs[3] paths: one F = 32 forward (24x24 latent) and one 96x96-latent forward, max_len 32
+  cfg5_trajectory.npz       BASELINE configs[4]: IP-Adapter + rectangle mask, 5 DDIM steps (reference + oracle without the CPU-path quirk)
 
 Each UNet golden holds the reference twice: as the CPU runs it (f32) and under the CUDA-autocast cast policy in bfloat16
 (oracle/autocast_emul.py) = the precision the engine's production mode computes in.  Tiered tolerance:
@@ -13,8 +15,9 @@ Each UNet golden holds the reference twice: as the CPU runs it (f32) and under t
   * bf16 production mode    two different bf16 roundings of a random-weight UNet are NOT within 1e-3 of each other - the
                             reference's own bf16 run is `drift` (1.2e-2 per forward, 4.3e-2 after 5 steps) away from its
                             own f32 run.  The engine's bf16 mode must be no further from the f32 reference than
-                            BF16_FACTOR x that drift, and no further from the bf16 reference than the two bf16 runs'
-                            combined distance allows; both numbers are written to gpurun_out/parity_report.txt.
+                            BF16_FACTOR (1.1) x that drift - it is measured at 0.88-0.95 x, i.e. CLOSER to the f32 reference than
+                            the reference's own bf16 run - and no further from the bf16 reference than BF16_VS_BF16 (1.5) x drift
+                            (measured 1.21-1.28 x); both numbers are written to gpurun_out/parity_report.txt.
 """
 import os
 
@@ -33,7 +36,11 @@ from test_engine_gpu import _load, _nhwc, rel, report
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-BF16_FACTOR = 1.5     # engine-bf16 vs reference-f32 may be at most this x (reference-bf16 vs reference-f32)
+# engine-bf16 vs reference-f32 may be at most BF16_FACTOR x drift (drift = reference-bf16-autocast vs reference-f32); measured over
+# every checkpoint below: 0.88 .. 0.95 x (gpurun_out/parity_report.txt), so 1.1 leaves ~15 %: a 30 % loss of accuracy fails.
+# engine-bf16 vs reference-bf16 (two independent bf16 roundings): measured 1.21 .. 1.28 x drift, bound BF16_VS_BF16 = 1.5.
+BF16_FACTOR = 1.1
+BF16_VS_BF16 = 1.5
 
 
 @pytest.fixture(scope="module")
@@ -74,7 +81,7 @@ def test_full_width_forward_vs_reference(golden_dir, engines):
             assert r32 < 1e-3, r32
         else:
             assert r32 < BF16_FACTOR * drift, (r32, drift)
-            assert r16 < (1.0 + BF16_FACTOR) * drift, (r16, drift)
+            assert r16 < BF16_VS_BF16 * drift, (r16, drift)
 
 
 def test_full_width_ip_adapter_forward_vs_oracle(golden_dir):
@@ -99,7 +106,7 @@ def test_full_width_ip_adapter_forward_vs_oracle(golden_dir):
         r = rel(out, ref)
         report(f"full-width IP fwd (16 tokens) {dtype}: vs oracle-f32 {r:.3e} (reference bf16-autocast drift on its CPU path {drift:.3e})")
         assert torch.isfinite(out).all()
-        assert r < (1e-3 if dtype == torch.float32 else BF16_FACTOR * drift), r
+        assert r < (1e-3 if dtype == torch.float32 else 2.1e-2), r      # bf16 measured 1.77e-2 (the drift of the CPU-quirk path, 3.3e-2, is no yardstick here)
         del eng
         torch.cuda.empty_cache()
 
@@ -140,13 +147,14 @@ def test_cfg1_trajectory_vs_reference_pipeline(golden_dir, engines, dtype):
             assert r32 < 1e-3, (i, r32)
         else:
             assert r32 < BF16_FACTOR * drift, (i, r32, drift)
-            assert r16 < (1.0 + BF16_FACTOR) * drift, (i, r16, drift)
+            assert r16 < BF16_VS_BF16 * drift, (i, r16, drift)
 
 
-@pytest.mark.parametrize("dtype,run_steps", [(torch.float32, 5), (torch.bfloat16, 25)])
+@pytest.mark.parametrize("dtype,run_steps", [(torch.float32, 25), (torch.bfloat16, 25)])
 def test_cfg2_trajectory_vs_reference_pipeline(golden_dir, engines, dtype, run_steps):
-    """BASELINE configs[1] = the benchmarked workload (16 frames 512x512, 25 DDIM steps): latents after steps 0, 4 (both
-    precisions) and 24 (bf16: the whole benchmarked trajectory; the f32 parity mode stops after step 4 to bound test time)"""
+    """BASELINE configs[1] = the benchmarked workload (16 frames 512x512, 25 DDIM steps): latents after steps 0, 4 and 24 - the
+    whole benchmarked trajectory in BOTH precisions (round 2 stopped the f32 parity mode, the one held to north_star's 1e-3,
+    after step 4)"""
     if not os.path.exists(os.path.join(golden_dir, "cfg2_trajectory.npz")):
         pytest.skip("cfg2_trajectory.npz not generated (oracle/make_golden_full.py cfg2, ~1.5 h of CPU)")
     g, got = _trajectory(golden_dir, engines, "cfg2_trajectory.npz", dtype, run_steps)
@@ -161,8 +169,61 @@ def test_cfg2_trajectory_vs_reference_pipeline(golden_dir, engines, dtype, run_s
             assert r32 < 1e-3, (i, r32)
         else:
             assert r32 < BF16_FACTOR * drift, (i, r32, drift)
-            assert r16 < (1.0 + BF16_FACTOR) * drift, (i, r16, drift)
-    assert checked >= 2
+            assert r16 < BF16_VS_BF16 * drift, (i, r16, drift)
+    assert checked == 3
+
+
+@pytest.mark.parametrize("tag", ["f32x24", "f2x96"])
+def test_cfg4_forwards_vs_reference(golden_dir, full_sd, tag):
+    """BASELINE configs[3] (32 frames 768x768, temporal_position_encoding_max_len = 32): the two paths it adds to the benchmarked
+    config, each as one forward of the REAL reference built with max_len 32 (oracle/make_golden_full.py cfg4) -
+    f32x24: F = 32 -> 32 x 32-score temporal attention at d = 40 / 80 / 160 and a 32-row positional table (motion_module.py:286-304,
+    371-464; F = 32 is outside the fused temporal block's shapes: the unfused kernels run), 24x24 latent;
+    f2x96: a 96x96 latent -> spatial attention over N = 9216 keys (d = 40) and 2304 / 576 / 144 at the deeper levels."""
+    g = _load(golden_dir, "cfg4_forwards.npz")
+    ocfg = Fn.UNetConfig(temporal_position_encoding_max_len=int(g["max_len"]))
+    F, lat = int(g[f"{tag}_frames"]), int(g[f"{tag}_lat"])
+    inp = W.seeded_inputs(ocfg, 1, F, lat, lat, seed=int(g[f"{tag}_input_seed"]))
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    drift = float(g[f"{tag}_drift"])
+    for dtype in (torch.float32, torch.bfloat16):
+        eng = UNet3DEngine(pack_unet(full_sd, UNet3DConfig(temporal_position_encoding_max_len=int(g["max_len"])), dtype, DEV))
+        eng.prepare_context(inp["text"])
+        _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), 2)
+        out = eng.forward(_nhwc(x9, dtype), temb, 2, F, lat, lat).float().cpu().reshape(2, F, lat, lat, 4).permute(0, 4, 1, 2, 3)
+        assert torch.isfinite(out).all()
+        r32, r16 = rel(out, g[f"{tag}_out_f32"]), rel(out, g[f"{tag}_out_bf16"])
+        report(f"cfg4 {tag} (F={F}, {lat}x{lat} latent, max_len 32) {dtype}: vs ref-f32 {r32:.3e}, vs ref-bf16-autocast {r16:.3e} (ref-bf16 vs ref-f32 {drift:.3e})")
+        if dtype == torch.float32:
+            assert r32 < 1e-3, r32
+        else:
+            assert r32 < BF16_FACTOR * drift, (r32, drift)
+            assert r16 < BF16_VS_BF16 * drift, (r16, drift)
+        del eng
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cfg5_ip_mask_trajectory_vs_oracle(golden_dir, dtype):
+    """BASELINE configs[4] as a trajectory: IP-Adapter branch (16 image tokens, scale 0.7) + rectangle region mask + first-frame
+    latent concat, CFG 8, 5 DDIM steps at full widths (pipeline_animation.py:676-680, 716-723; attention.py:49-127).  The golden holds the
+    REAL reference's trajectory (its CPU path uses the IP weight as attn2's softmax temperature - tests/test_oracle_golden.py pins
+    the oracle WITH that quirk to it at every step) and the oracle WITHOUT the quirk = the deployed semantics the engine implements."""
+    g = _load(golden_dir, "cfg5_trajectory.npz")
+    ocfg = Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=int(g["ip_num_tokens"]), ip_scale=float(g["ip_scale"]))
+    sd = W.make_weights(W.unet_state_shapes(ocfg), int(g["weight_seed"]))
+    F, lat, steps = int(g["frames"]), int(g["lat"]), int(g["steps"])
+    inp = W.seeded_inputs(ocfg, 1, F, lat, lat, seed=int(g["input_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, UNet3DConfig(use_ip_cross_attention=True, ip_num_tokens=ocfg.ip_num_tokens, ip_scale=ocfg.ip_scale), dtype, DEV))
+    got = {}
+    DDIMSampler(eng, DDIMConfig()).sample(inp["latents"], g["text_embeddings"], steps, 8.0, inp["first_image_latents"], g["first_images_mask"],
+                                          fps=[2], flow=[4], ip_tokens=inp["ip_tokens"], callback=lambda i, t, l: got.__setitem__(i, l.clone().cpu()))
+    torch.cuda.synchronize()
+    assert sorted(got) == list(range(steps))
+    for i in range(steps):
+        r, drift = rel(got[i], g[f"step{i}_oracle_noquirk"]), float(g[f"drift{i}"])
+        report(f"cfg5 IP + mask trajectory step {i} {dtype}: vs oracle-f32 (deployed semantics) {r:.3e} (reference bf16-autocast drift on its CPU path {drift:.3e})")
+        assert r < (1e-3 if dtype == torch.float32 else BF16_FACTOR * drift), (i, r, drift)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -176,4 +237,4 @@ def test_vae_decode_full_width_vs_reference(golden_dir, dtype):
     ref16 = (g["out_bf16"] / 2 + 0.5).clamp(0, 1)
     e, drift = (out - ref).abs().max().item(), (ref16 - ref).abs().max().item()
     report(f"vae full width {dtype}: max abs err {e:.3e} (ref-bf16 vs ref-f32 {drift:.3e})")
-    assert e < (1e-4 if dtype == torch.float32 else max(2.0 * drift, 2e-2)), e
+    assert e < (1e-4 if dtype == torch.float32 else 1.5 * drift), e      # bf16 measured 1.29 x the reference's own bf16 error

@@ -91,6 +91,30 @@ def test_unet_forward_full_width(golden_dir, ip):
     assert (y - ref).abs().max().item() < 1e-4
 
 
+def test_cfg5_ip_mask_trajectory_full_width(golden_dir):
+    """BASELINE configs[4] as a trajectory (IP-Adapter branch + rectangle region mask + first-frame concat, CFG 8, 5 DDIM steps, full
+    widths): the oracle's denoise loop WITH the reference's CPU-path temperature quirk against AnimationPipeline.__call__ of the real
+    reference at every step (oracle/make_golden_full.py cfg5); the same file holds the oracle WITHOUT the quirk, which
+    tests/test_fullwidth_gpu.py holds the engine to - checked here to be what the oracle produces, so the two tests meet."""
+    g = _load(golden_dir, "cfg5_trajectory.npz")
+    steps, F, lat = int(g["steps"]), int(g["frames"]), int(g["lat"])
+    kw = dict(use_ip_cross_attention=True, ip_num_tokens=int(g["ip_num_tokens"]), ip_scale=float(g["ip_scale"]))
+    cfg_q = Fn.UNetConfig(ip_reference_cpu_scale_quirk=True, **kw)
+    sd = W.make_weights(W.unet_state_shapes(cfg_q), int(g["weight_seed"]))
+    inp = W.seeded_inputs(cfg_q, 1, F, lat, lat, seed=int(g["input_seed"]))
+    for cfg, key, tol in ((cfg_q, "ref_f32", 2e-4), (Fn.UNetConfig(**kw), "oracle_noquirk", 1e-6)):
+        traj = {}
+        with torch.no_grad():
+            Fn.denoise(sd, cfg, Fn.DDIMConfig(), inp["latents"].clone(), g["text_embeddings"], steps, 8.0, inp["first_image_latents"], g["first_images_mask"],
+                       torch.tensor([2]), torch.tensor([4]), ip_tokens=inp["ip_tokens"], callback=lambda i, t, l: traj.__setitem__(i, l.clone()))
+        for i in range(steps):
+            ref = g[f"step{i}_{key}"]
+            r = (torch.linalg.norm(traj[i] - ref) / torch.linalg.norm(ref)).item()
+            assert r < tol, (key, i, r)
+        if key == "ref_f32":      # the two semantics really differ (otherwise this golden would pin nothing about the quirk)
+            assert (torch.linalg.norm(g[f"step{steps - 1}_oracle_noquirk"] - ref) / torch.linalg.norm(ref)).item() > 0.1
+
+
 def test_vae_decode_tiny(golden_dir):
     g = _load(golden_dir, "vae_tiny.npz")
     vcfg = Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))

@@ -1,5 +1,5 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) into per-kernel-family HBM bytes per
-launch -> profiles/r02_hbm_traffic.json, which bench.py reports as roofline.traffic.
+launch -> profiles/rNN_hbm_traffic.json, which bench.py reports as roofline.traffic when its `lib_sha256` is the library being benched.
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT/pmc_fetch -o f -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-roofline
@@ -10,11 +10,20 @@ Units (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FET
 reads, so it is doubled; WRITE_SIZE is uncalibrated (taken as is)."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 
-FAMILIES = (("fyc_gemm_kernel", "gemm"), ("fyc_attn_kernel", "attention"), ("temporal_block", "temporal_block"), ("tattn", "attn_temporal"), ("gn_stats", "gn_stats"),
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "followyourclick_amd", "libfyc_hip.so")
+
+
+def lib_digest() -> str:
+    """sha256 of the library the counters were taken on: bench.py reports `traffic` only when it runs the same binary"""
+    with open(LIB, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+FAMILIES = (("fyc_gemm_kernel", "gemm"), ("fyc_attn_kernel", "attention"), ("temporal_block", "temporal_block"), ("ff_block", "ff_block"), ("tattn", "attn_temporal"), ("gn_stats", "gn_stats"),
             ("chan_stats_reduce", "gn_stats"), ("gn_apply", "gn_apply"), ("layernorm", "row_stats"), ("concat", "concat"),
             ("splitk_finish", "gemm_splitk_finish"))
 
@@ -48,7 +57,7 @@ def main(fetch_dir, write_dir, out_path):
         n = max(nf, nw, 1)
         fams[fam] = {"launches": n, "fetch_bytes_per_launch": 2.0 * sf / max(nf, 1), "write_bytes_per_launch": sw / max(nw, 1),
                      "hbm_bytes_per_launch": 2.0 * sf / max(nf, 1) + sw / max(nw, 1)}
-    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 2 DDIM steps of bench.py cfg2 (weights packing and the "
+    doc = {"lib_sha256": lib_digest(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 2 DDIM steps of bench.py cfg2 (weights packing and the "
                      "one-off context projections included in 'other'/'gemm' launch counts); FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 "
                      "correction; WRITE_SIZE uncalibrated", "families": fams}
     with open(out_path, "w") as f:
