@@ -121,7 +121,7 @@ class AutoencoderKL(nn.Module):
         first-frame latents exactly as scripts/inference.py:356-358 computes them."""
         key = (self.device, self.compute_dtype) + tuple(p._version for p in self.parameters())
         if self._encoder is None or key != self._encoder_key:
-            if self.device.type != "cuda":
+            if self.device.type != "cuda" and ops_mod.get().name == "hip":
                 raise RuntimeError("AutoencoderKL.encode runs on an MI355X HIP device only (call .to('cuda')); no CPU fallback")
             sd = {k: v for k, v in self.state_dict().items() if k.startswith(("encoder.", "quant_conv."))}
             self._encoder = VAEEncoderEngine(pack_vae_encoder(sd, self.engine_config, self.compute_dtype, self.device))

@@ -1,0 +1,135 @@
+"""The reference's OWN entry script on top of the drop-in packages (SURVEY.md 8b1 / BASELINE.json north_star: "scripts/inference*.py
+drop in unchanged").
+
+`/root/reference/scripts/inference.py` is executed UNMODIFIED through runpy after `followyourclick_amd.install_dropin()`:
+model construction from a `pretrained_model_path` (:152-155), the `is_xformers_available` assert (:157-158), the motion-module
+checkpoint with its `module.` prefix (:170-181), `DistributedSampler` under --ddp (:260), first image + region mask from files,
+`vae.encode` of the first frame (:356-358), mask plumbing (:361-365), `AnimationPipeline.__call__` (:374-395) and
+`save_videos_grid` (:398-403, :424).  What is fabricated / stubbed is the ENVIRONMENT, never the script: tests/script_env.py.
+
+The latents the script's pipeline call hands to the VAE decoder are then compared with the oracle's denoising loop on the same
+weights, noise, text states and conditioning (captured at the pipeline's own method boundaries).
+
+Runs where the reference tree exists (the build container); the GPU box has no /root/reference, so the `gpu` variant is skipped there.
+"""
+import os
+import runpy
+import sys
+
+import pytest
+import torch
+
+import script_env as E
+
+pytestmark = pytest.mark.skipif(not os.path.exists(E.REF_SCRIPT), reason="the reference tree (/root/reference) is not on this box")
+
+PROMPT = "a corgi waving its tail"
+
+
+def _run_script(tmp_path, monkeypatch, device_is_gpu: bool, port: int):
+    import followyourclick_amd
+    from followyourclick_amd import ops as ops_mod
+    monkeypatch.setattr(sys, "path", list(sys.path))
+    saved_modules = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")}
+    if not device_is_gpu:
+        from emu_ops import EmuOps
+        monkeypatch.setattr(ops_mod, "impl", EmuOps())          # CPU box: host orchestration on the op emulator (tests only)
+        E.alias_cuda_to_cpu(monkeypatch)
+    followyourclick_amd.install_dropin(force=True)
+    E.install_absent_packages(monkeypatch)
+    root = str(tmp_path)
+    fab = E.fabricate_model_dir(root)
+    steps, size, frames = 2, 64, 2
+    cfg_path, sheet, img_path, mask_path = E.write_run_files(root, fab["motion_ckpt"], steps, size)
+    E.patch_authors_environment(monkeypatch, img_path, mask_path, PROMPT)
+    for k, v in dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+
+    # capture points: the pipeline's own method boundaries (class-level wrappers, installed before the script imports the class)
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    seen = {}
+
+    def spy(name, keep):
+        real = getattr(AnimationPipeline, name)
+
+        def wrapper(self, *a, **k):
+            out = real(self, *a, **k)
+            keep(self, a, k, out)
+            return out
+        monkeypatch.setattr(AnimationPipeline, name, wrapper)
+    spy("_encode_prompt", lambda s, a, k, out: seen.__setitem__("text", out.detach().float().cpu().clone()))
+    spy("prepare_latents", lambda s, a, k, out: seen.__setitem__("noise", out.detach().float().cpu().clone()))
+    real_decode = AnimationPipeline.decode_latents
+
+    def decode(self, latents):
+        seen["final"] = latents.detach().float().cpu().clone()
+        seen["unet_sd"] = {k: v.detach().float().cpu().clone() for k, v in self.unet.state_dict().items()}
+        return real_decode(self, latents)
+    monkeypatch.setattr(AnimationPipeline, "decode_latents", decode)
+    real_call = AnimationPipeline.__call__
+
+    def call(self, *a, **k):
+        seen["call"] = {n: (v.detach().float().cpu().clone() if torch.is_tensor(v) else v) for n, v in k.items()}
+        return real_call(self, *a, **k)
+    monkeypatch.setattr(AnimationPipeline, "__call__", call)
+    if not device_is_gpu:                                       # the pipelines' own .to("cuda") (not an nn.Module.to) on the GPU-less box
+        from diffusers import StableDiffusionPipeline
+        for cls in (AnimationPipeline, StableDiffusionPipeline):
+            real_to = cls.to
+            monkeypatch.setattr(cls, "to", lambda self, device, _r=real_to: _r(self, "cpu"))
+
+    out_dir = os.path.join(root, "out")
+    argv = [E.REF_SCRIPT, "--config", cfg_path, "--file", sheet, "--pretrained_model_path", root, "--inference_config", E.REF_INFERENCE_CFG,
+            "--output_path", out_dir, "--manually_input_image", "--use_fps_condition", "--fps", "2", "--flw_ctrl", "4",
+            "--L", str(frames), "--W", str(size), "--H", str(size), "--seed", "1", "--ddp"]
+    monkeypatch.setattr(sys, "argv", argv)
+    monkeypatch.chdir(root)
+    try:
+        runpy.run_path(E.REF_SCRIPT, run_name="__main__")
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        for k in [k for k in sys.modules if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")]:
+            del sys.modules[k]
+        sys.modules.update(saved_modules)
+    return seen, out_dir, dict(steps=steps, size=size, frames=frames)
+
+
+def _check(seen, out_dir, run, tol):
+    from oracle import functional as Fn
+    # the script wrote its GIFs and its config (scripts/inference.py:398-403, 424, 429)
+    runs = [d for d in os.listdir(out_dir)]
+    assert len(runs) == 1, runs
+    savedir = os.path.join(out_dir, runs[0])
+    gifs = os.listdir(os.path.join(savedir, "sample"))
+    assert gifs == [f"0_{PROMPT}.gif"], gifs
+    assert os.path.getsize(os.path.join(savedir, "sample", gifs[0])) > 1000 and os.path.getsize(os.path.join(savedir, "sample.gif")) > 1000
+    assert os.path.exists(os.path.join(savedir, "config.yaml"))
+    # the pipeline call the script made
+    c = seen["call"]
+    lat = run["size"] // 8
+    assert c["video_length"] == run["frames"] and c["num_inference_steps"] == run["steps"] and c["use_first_frame_mask_condition_concat"] is True
+    # (the script's mask is the RGB image's 3 channels on the "frame" axis, scripts/inference.py:361-365; the pipeline takes [:, :, 0:1])
+    assert tuple(c["first_image_latents"].shape) == (1, 4, lat, lat) and tuple(c["first_images_mask"].shape) == (1, 1, 3, lat, lat)
+    mask = c["first_images_mask"][:, :, 0:1]
+    assert set(mask.unique().tolist()) <= {0.0, 1.0} and 0 < mask.sum() < mask.numel()
+    # ... and its result against the oracle's denoising loop on the same weights / noise / text states / conditioning
+    cfg = Fn.tiny_unet_config()
+    with torch.no_grad():
+        ref = Fn.denoise(seen["unet_sd"], cfg, Fn.DDIMConfig(), seen["noise"], seen["text"], run["steps"], float(c["guidance_scale"]),
+                         c["first_image_latents"], mask, torch.tensor([2]), torch.tensor([4]))
+    r = ((seen["final"] - ref).norm() / ref.norm()).item()
+    assert r < tol, r
+
+
+def test_reference_inference_script_runs_unmodified_on_emulator(tmp_path, monkeypatch):
+    """CPU box: the whole script on the op emulator (bf16 storage, f32 accumulation - the drop-in's default precision)"""
+    seen, out_dir, run = _run_script(tmp_path, monkeypatch, device_is_gpu=False, port=29761)
+    _check(seen, out_dir, run, tol=6e-2)
+
+
+@pytest.mark.gpu
+def test_reference_inference_script_runs_unmodified_on_mi355x(tmp_path, monkeypatch):
+    """the same on the HIP kernels (only where the reference tree and a GPU are on one box)"""
+    seen, out_dir, run = _run_script(tmp_path, monkeypatch, device_is_gpu=True, port=29762)
+    _check(seen, out_dir, run, tol=6e-2)
