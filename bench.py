@@ -117,13 +117,28 @@ def main():
     if world != args.gpus:
         if rank == 0 and world > 1:
             print(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # FYC_BENCH_EMULATE=1 is a TEST switch (tests/test_distributed_cpu.py only): the same entry point, rendezvous, barrier and
+    # max-over-ranks timing with gloo on the CPU and the op emulator under tests/ at tiny widths - so that the N > 1 launch path is
+    # exercised before the first multi-GPU node sees it.  Its line is marked "data": "emulated" and is no measurement.
+    emulate = os.environ.get("FYC_BENCH_EMULATE") == "1"
+    if emulate:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_ops import EmuOps
+        from followyourclick_amd import ops as ops_mod
+        ops_mod.impl = EmuOps()
+        device = torch.device("cpu")
+        sync = lambda: None      # noqa: E731
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     cfg = UNet3DConfig(use_ip_cross_attention=args.ip_tokens > 0, ip_num_tokens=max(args.ip_tokens, 4))
+    if emulate:
+        cfg = UNet3DConfig(block_out_channels=(64, 128, 256, 256), cross_attention_dim=64, sample_size=8)
     if args.frames > cfg.temporal_position_encoding_max_len:
         cfg.temporal_position_encoding_max_len = args.frames
     schema = unet_schema(cfg)
@@ -131,7 +146,7 @@ def main():
     packed = pack_unet(sd, cfg, dtype, device)
     t_b = time.time()
     moved = D.broadcast_packed(packed, src=0)          # one-time weight broadcast over RCCL/xGMI
-    torch.cuda.synchronize()
+    sync()
     t_b = time.time() - t_b
     if rank != 0:
         sd = None
@@ -151,13 +166,18 @@ def main():
     for c in clips[: args.warmup]:
         run(c)
     D.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.time()
+    t_host = 0.0
     for c in clips[args.warmup:]:
+        th = time.time()
         out = run(c)
-    torch.cuda.synchronize()
+        t_host += time.time() - th          # time the HOST needs to queue a clip's launches (it returns before the GPU is done)
+    sync()
     D.barrier()
     elapsed = D.max_over_ranks(time.time() - t0, device)
+    # slowest rank's host-side queueing time per DDIM step (~900 ctypes launches): close to ms_per_step / ddim_steps = host-bound
+    host_ms = D.max_over_ranks(1000.0 * t_host / (args.steps * args.ddim_steps), device)
     assert torch.isfinite(out).all(), "non-finite latents"
 
     result = None
@@ -166,8 +186,9 @@ def main():
         result = {
             "metric": "denoised frames/sec, 16f x 512^2 clip @ 25 DDIM steps", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "emulated" if emulate else "synthetic",
             "clips_per_sec": round(world * args.steps / elapsed, 4),
+            "host_launch_ms_per_ddim_step": round(host_ms, 2), "gpu_ms_per_ddim_step": round(1000 * elapsed / (args.steps * args.ddim_steps), 2),
             "config": {"workload": f"configs[1]: AnimationPipeline DDIM loop, SD-1.5 UNet3D + mm_sd_v15-shaped motion modules "
                                    f"(random init), 1 clip/GPU of {args.frames} frames {args.size}x{args.size}, {args.ddim_steps} DDIM steps, "
                                    f"CFG 8.0, mask + first-frame concat, fps/flow conditioning",
@@ -176,7 +197,7 @@ def main():
         }
 
     # ---- roofline leg: one instrumented clip step, per-launch HIP-event timing (rank 0) ---------------
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not emulate:
         timed = TimedOps(eng.ops)
         eng.ops = timed
         c = clips[-1]
@@ -263,7 +284,7 @@ def main():
         result["end_to_end_frames_per_sec"] = round(args.frames / (elapsed / args.steps + result["vae_decode_ms"] / 1000), 3)
         assert torch.isfinite(vid).all()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and os.environ.get("FYC_BENCH_CPU", "1") != "0":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not emulate and os.environ.get("FYC_BENCH_CPU", "1") != "0":
         try:
             result["cpu_baseline"] = cpu_baseline(sd, args.frames, h, w, args.ddim_steps)
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number

@@ -124,3 +124,23 @@ def test_dropin_unet_receives_rank0_weights(tmp_path):
     a, b = (torch.load(os.path.join(tmp_path, f"dropin{r}.pt")) for r in (0, 1))
     assert torch.equal(a["w"], b["w"])
     assert torch.equal(a["out"], b["out"])
+
+
+def test_bench_entry_point_under_torch_distributed_run(tmp_path):
+    """bench.py as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`):
+    rendezvous on 127.0.0.1, weight broadcast, per-rank clips, barrier + max-over-ranks timing, ONE JSON line from rank 0 -
+    with gloo and the op emulator behind FYC_BENCH_EMULATE=1 (a test switch; the line says "data": "emulated").  No RCCL run of this
+    path exists yet (SCALE_rNN.json has been a skip record): this keeps the launch path from failing first on an 8-GPU node."""
+    import json
+    import subprocess
+    env = dict(os.environ, FYC_BENCH_EMULATE="1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29771",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "2", "--size", "64", "--ddim-steps", "2", "--dtype", "f32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "emulated"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 1 / (d["ms_per_step"] / 1000.0)) / d["value"] < 1e-2      # whole-job frames/s = n * frames * K / max time
+    assert d["host_launch_ms_per_ddim_step"] > 0 and "parallelism" in d["config"] and d["config"]["parallelism"].startswith("dp2")
