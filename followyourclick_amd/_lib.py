@@ -129,6 +129,12 @@ class FFBlockArgs(C.Structure):
                 ("rows", i32), ("C", i32), ("hidden", i32), ("eps", C.c_float), ("dtype", i32)]
 
 
+class PanelLinearArgs(C.Structure):
+    _fields_ = [("x", vp), ("residual", vp), ("out", vp), ("wstream", vp), ("bias", vp), ("gn_cs", vp), ("gn_gamma", vp), ("gn_beta", vp),
+                ("gn_rows_per_sample", i32), ("gn_stat_samples", i32), ("gn_groups", i32), ("gn_eps", C.c_float),
+                ("rows", i32), ("N", i32), ("K", i32), ("dtype", i32)]
+
+
 class PackConv3x3Args(C.Structure):
     _fields_ = [("w", vp), ("out", vp), ("O", i32), ("I", i32), ("dtype", i32)]
 
@@ -147,10 +153,10 @@ OPS = {
     "fyc_embed_tokens": EmbedArgs, "fyc_patchify": PatchifyArgs, "fyc_row_stats": RowStatsArgs,
     "fyc_gn_apply_cs": GnApplyCsArgs, "fyc_chan_stats_reduce": ChanStatsReduceArgs,
     "fyc_pack_conv3x3": PackConv3x3Args, "fyc_pack_geglu": PackGegluArgs, "fyc_temporal_block": TemporalBlockArgs,
-    "fyc_ff_block": FFBlockArgs,
+    "fyc_ff_block": FFBlockArgs, "fyc_panel_linear": PanelLinearArgs,
 }
 MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_temporal_block_supported",
-        "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes"]
+        "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
 
@@ -189,6 +195,11 @@ def load() -> C.CDLL:
         lib.fyc_ff_block_supported.restype = C.c_int
         lib.fyc_ff_block_wstream_bytes.argtypes = []
         lib.fyc_ff_block_wstream_bytes.restype = i64
+    if not ab_build or hasattr(lib, "fyc_panel_linear_supported"):
+        lib.fyc_panel_linear_supported.argtypes = [C.POINTER(PanelLinearArgs)]
+        lib.fyc_panel_linear_supported.restype = C.c_int
+        lib.fyc_panel_linear_wstream_bytes.argtypes = [i32, i32]
+        lib.fyc_panel_linear_wstream_bytes.restype = i64
     for name, st in OPS.items():
         if ab_build and not hasattr(lib, name):
             continue

@@ -26,7 +26,7 @@ from .. import _lib as L
 from .. import ops as ops_mod
 from .base import EngineBase
 from .config import UNet3DConfig
-from .weights import Packed, pack_ff_block, pack_temporal_block
+from .weights import Packed, pack_ff_block, pack_panel_linear, pack_temporal_block
 
 Tensor = torch.Tensor
 
@@ -35,6 +35,7 @@ Tensor = torch.Tensor
 FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
 FUSE_TEMPORAL = os.environ.get("FYC_FUSE_TEMPORAL", "1") != "0"   # fyc_temporal_block: one kernel per temporal attention sub-block (C = 320 level)
 FUSE_FF = os.environ.get("FYC_FUSE_FF", "1") != "0"               # fyc_ff_block: LayerNorm + FF1 + GEGLU + FF2 + output projection in one kernel (C = 320 level)
+FUSE_PANEL = os.environ.get("FYC_FUSE_PANEL", "1") != "0"         # fyc_panel_linear: K <= 640 projections with register-resident rows; proj_in takes its GroupNorm along
 FUSE_ROWS = os.environ.get("FYC_FUSE_ROWS", "0") != "0"      # the LayerNorm half (row_parts): measured slower than the separate fyc_row_stats pass (profiles/r02_stats_fusion_ab.txt), off by default
 
 
@@ -227,12 +228,37 @@ class UNet3DEngine(EngineBase):
         """Linear whose output feeds a (folded) LayerNorm: the epilogue also writes the per-row partial sums"""
         N, K = w.shape
         out = self.new(rows, N, dtype=x.dtype)
+        if FUSE_PANEL and not self.fuse_rows and self.ops.panel_linear_supported(x.dtype, rows=rows, N=N, K=K):
+            self.ops.panel_linear(x, out, wstream=self._panel_stream(w), rows=rows, N=N, K=K, bias=bias, residual=residual)
+            return Act(out, N)
         rp, n = None, 0
         if self.fuse_rows:
             n = self.ops.gemm_row_parts(x.dtype, M=rows, N=N, K=K)
             rp = torch.empty(rows, n, 2, dtype=torch.float32, device=self.device)
         self.ops.gemm(x, w, out, M=rows, N=N, K=K, lda=K, ldw=K, ldo=N, bias=bias, residual=residual, ldr=N, row_parts=rp, row_nparts=n)
         return Act(out, N, rp=rp, rp_n=n)
+
+    def _panel_stream(self, w: Tensor) -> Tensor:
+        """fragment-ordered copy of a linear weight for fyc_panel_linear, packed once per weight tensor"""
+        cache = self.__dict__.setdefault("_panel_ws", {})
+        key = w.data_ptr()
+        if key not in cache:
+            cache[key] = pack_panel_linear(w)
+        return cache[key]
+
+    def _norm_proj_in(self, x: Act, node: Packed, rows: int, rows_per_sample: int) -> Act:
+        """GroupNorm -> proj_in of a transformer / motion module (reference attention.py:269-270, motion_module.py:188-191).  With the
+        producer's channel sums at hand the norm is applied to fyc_panel_linear's operand registers: no normalised tensor in HBM."""
+        C = node.C
+        if (FUSE_PANEL and isinstance(x, Act) and x.cs is not None and not self.fuse_rows and rows_per_sample % x.cs_rows == 0
+                and self.ops.panel_linear_supported(self.dtype, rows=rows, N=C, K=C, gn_rows_per_sample=rows_per_sample)):
+            out = self.new(rows, C)
+            self.ops.panel_linear(x.t, out, wstream=self._panel_stream(node.pin_w), rows=rows, N=C, K=C, bias=node.pin_b, gn_cs=x.cs,
+                                  gn_gamma=node.norm_g, gn_beta=node.norm_b, gn_rows_per_sample=rows_per_sample,
+                                  gn_stat_samples=rows_per_sample // x.cs_rows, gn_groups=self.groups, gn_eps=1e-6)
+            return Act(out, C)
+        h, _ = self._gn(x, node.norm_g, node.norm_b, rows, rows_per_sample, 1e-6, False)
+        return self._lin_rp(h, node.pin_w, rows, bias=node.pin_b)
 
     def _ln_args(self, tok: Act, rows: int, C: int) -> dict:
         """ln_stats arguments of the GEMM that consumes LayerNorm(tok): the producer's partial sums, or a statistics pass"""
@@ -340,8 +366,7 @@ class UNet3DEngine(EngineBase):
         rows, C, H, o = g["rows"], t.C, self.heads, self.ops
         BF, N = g["B"] * g["F"], g["H"] * g["W"]
         d = C // H
-        h, _ = self._gn(x, t.norm_g, t.norm_b, rows, N, 1e-6, False)
-        tok = self._lin_rp(h, t.pin_w, rows, bias=t.pin_b)
+        tok = self._norm_proj_in(x, t, rows, N)
         # --- attn1: spatial self-attention
         ld = ((N + 7) // 8) * 8
         q, k, vt = self.new(BF, H, N, d), self.new(BF, H, N, d), (self.zeros(BF, H, d, ld) if ld != N else self.new(BF, H, d, ld))
@@ -382,8 +407,7 @@ class UNet3DEngine(EngineBase):
         rows, C, o = g["rows"], m.C, self.ops
         N, Hm = g["H"] * g["W"], self.cfg.motion_num_attention_heads
         d = C // Hm
-        h, _ = self._gn(x, m.norm_g, m.norm_b, rows, N, 1e-6, False)
-        tok = self._lin_rp(h, m.pin_w, rows, bias=m.pin_b)
+        tok = self._norm_proj_in(x, m, rows, N)
         for bi, blk in enumerate(m.blocks):
             for a in blk.attns:
                 if FUSE_TEMPORAL and a.qkv_f is not None and o.temporal_block_supported(self.dtype, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d):

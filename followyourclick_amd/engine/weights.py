@@ -264,6 +264,17 @@ def pack_ff_block(ff: Packed) -> Tensor:
     return st.reshape(-1).contiguous()
 
 
+def pack_panel_linear(w: Tensor) -> Tensor:
+    """weight stream of fyc_panel_linear (csrc/panel_linear.hip) from a linear weight (N, K): (N / PN) column passes x (K / 64)
+    stages x 2 PN / 16 pieces x 512 elements, PN = 320 columns per pass (N itself below 320: the emulated small-width tests);
+    piece s * (PN / 16) + j of stage t of pass P = MFMA fragment of W[PN P + 16 j .. +16][32 (2 t + s) .. +32] (include/fyc.h)"""
+    N, K = w.shape
+    pn = min(N, 320)
+    assert N % pn == 0 and pn % 16 == 0 and K % 64 == 0
+    fr = _mfma_fragments(w.reshape(N // pn, pn // 16, 16, K // 64, 2, 32).permute(0, 3, 4, 1, 2, 5))     # [P][t][s][j][512]
+    return fr.reshape(-1).contiguous()
+
+
 def sinusoidal_pe(channels: int, length: int) -> Tensor:
     """pe[p, 2i] = sin(p * exp(-2i ln(1e4)/C)), pe[p, 2i+1] = cos(...) (reference motion_module.py:295-301)."""
     import math

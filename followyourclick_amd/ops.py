@@ -270,6 +270,39 @@ class HipOps:
         a.rows, a.C, a.hidden, a.eps, a.dtype = rows, C_, hidden, eps, _dt(x)
         self._call("fyc_ff_block", a)
 
+    def panel_linear_supported(self, dtype: torch.dtype, *, rows: int, N: int, K: int, gn_rows_per_sample: int = 0) -> bool:
+        """does fyc_panel_linear (row-panel linear, optionally with the input's GroupNorm on the operand registers) cover this shape?"""
+        if not hasattr(self.lib, "fyc_panel_linear_supported"):
+            return False
+        key = ("pls", dtype, rows, N, K, gn_rows_per_sample)
+        if key not in self._q_cache:
+            a = L.PanelLinearArgs()
+            a.rows, a.N, a.K = rows, N, K
+            a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+            if gn_rows_per_sample > 0:
+                a.gn_cs, a.gn_rows_per_sample, a.gn_stat_samples, a.gn_groups = 16, gn_rows_per_sample, 1, 32     # pointer only tested for null
+            self._q_cache[key] = bool(self.lib.fyc_panel_linear_supported(C.byref(a)))
+        return self._q_cache[key]
+
+    def panel_linear(self, x: Tensor, out: Tensor, *, wstream: Tensor, rows: int, N: int, K: int, bias: Optional[Tensor] = None,
+                     residual: Optional[Tensor] = None, gn_cs: Optional[Tensor] = None, gn_gamma: Optional[Tensor] = None,
+                     gn_beta: Optional[Tensor] = None, gn_rows_per_sample: int = 0, gn_stat_samples: int = 1, gn_groups: int = 32,
+                     gn_eps: float = 1e-6) -> None:
+        """out = [GroupNorm](x) W^T + bias (+ residual) in one kernel (csrc/panel_linear.hip); `wstream` from
+        engine/weights.py::pack_panel_linear; gn_cs = the f64 per-(statistics sample, channel) sums of x"""
+        self.ensure_init(x.device)
+        need = int(self.lib.fyc_panel_linear_wstream_bytes(N, K))
+        if wstream.numel() * wstream.element_size() != need:
+            raise ValueError(f"panel_linear: wstream has {wstream.numel() * wstream.element_size()} bytes, expected {need}")
+        if gn_cs is not None and gn_cs.dtype != torch.float64:
+            raise TypeError("panel_linear: gn_cs must be float64")
+        a = L.PanelLinearArgs()
+        a.x, a.residual, a.out, a.wstream, a.bias = _p(x), _p(residual), _p(out), _p(wstream), _f32(bias, "bias")
+        a.gn_cs, a.gn_gamma, a.gn_beta = _p(gn_cs), _f32(gn_gamma, "gn_gamma"), _f32(gn_beta, "gn_beta")
+        a.gn_rows_per_sample, a.gn_stat_samples, a.gn_groups, a.gn_eps = gn_rows_per_sample, gn_stat_samples, gn_groups, gn_eps
+        a.rows, a.N, a.K, a.dtype = rows, N, K, _dt(x)
+        self._call("fyc_panel_linear", a)
+
     # -- normalisation -----------------------------------------------------------------------
     def gn_stats(self, x: Tensor, stats: Tensor, *, rows: int, C_: int, groups: int, rows_per_sample: int) -> None:
         a = L.GnStatsArgs()

@@ -112,6 +112,15 @@ class TimedOps:
         nbytes = (2 + (residual is not None)) * rows * C * _esize(x) + (C * 2 * hid + (C + hid) * C) * _esize(x)
         return self._timed("ff_block", flops, nbytes, self.inner.ff_block, x, residual, out, **kw)
 
+    def panel_linear_supported(self, dtype, **kw):
+        return self.inner.panel_linear_supported(dtype, **kw)
+
+    def panel_linear(self, x, out, **kw):
+        rows, N, K = kw["rows"], kw["N"], kw["K"]
+        nbytes = (rows * K + rows * N * (2 if kw.get("residual") is not None else 1) + N * K) * _esize(x)
+        key = f"panel_linear M={rows} N={N} K={K} gn={int(kw.get('gn_cs') is not None)} res={int(kw.get('residual') is not None)}"
+        return self._timed("panel_linear", 2.0 * rows * N * K, nbytes, self.inner.panel_linear, x, out, _key=key, **kw)
+
     def chan_stats_reduce(self, parts, cs, **kw):
         return self._timed("gn_stats", 0.0, 0.0, self.inner.chan_stats_reduce, parts, cs, **kw)
 

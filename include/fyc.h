@@ -335,6 +335,28 @@ int fyc_ff_block(const fyc_ff_block_args* a, void* stream);
 int fyc_ff_block_supported(const fyc_ff_block_args* a);
 int64_t fyc_ff_block_wstream_bytes(void);
 
+/* ---- row-panel linear for the short-K projections (animatediff/models/attention.py:270, diffusers/models/attention.py:600-623;
+ *      motion_module.py:191, 270-283) ----------------------------------------------------------------------------------------------
+ *   out = [GroupNorm](x) W^T + bias (+ residual)       x [rows][K], out / residual [rows][N] bf16, K and N in {320, 640}, rows % 128 == 0
+ * replaces fyc_gemm (and, with gn_cs, the fyc_gn_apply_cs pass in front of a proj_in: GroupNorm is applied to the operand registers,
+ * from the same per-(statistics sample, channel) f64 {sum, sum of squares} `gn_cs` [rows / (gn_rows_per_sample / gn_stat_samples)][K][2];
+ * a GroupNorm sample = gn_rows_per_sample rows = gn_stat_samples consecutive statistics samples; gn_rows_per_sample % 128 == 0).
+ * `wstream` (fyc_panel_linear_wstream_bytes(N, K) bytes): (N / 320) passes x (K / 64) stages x 40 pieces x 1 KiB; piece s * 20 + j of
+ * stage t of pass P = MFMA operand fragment (byte 16 l = B[l & 15][8 (l >> 4) .. +8]) of the weight block rows 320 P + 16 j .. +16,
+ * columns 32 (2 t + s) .. +32 (engine/weights.py::pack_panel_linear).  residual may alias out; out must not alias x. */
+typedef struct {
+  const void* x; const void* residual; void* out;
+  const void* wstream; const float* bias;
+  const double* gn_cs; const float* gn_gamma; const float* gn_beta;
+  int32_t gn_rows_per_sample, gn_stat_samples, gn_groups;
+  float gn_eps;
+  int32_t rows, N, K;
+  int32_t dtype;
+} fyc_panel_linear_args;
+int fyc_panel_linear(const fyc_panel_linear_args* a, void* stream);
+int fyc_panel_linear_supported(const fyc_panel_linear_args* a);
+int64_t fyc_panel_linear_wstream_bytes(int32_t N, int32_t K);
+
 /* ---- weight layouts fyc_gemm expects (one-time, at load): the state-dict tensors of the reference, f32 on the device --------
  * fyc_pack_conv3x3: Conv2d / InflatedConv3d weight (O, I, 3, 3) (animatediff/models/resnet.py:20-27; diffusers resnet.py Conv2d)
  *   -> [O][slab][ky][kx][c in slab], one slab = 128 bytes of input channels (64 bf16 / 32 f32), I zero-padded to a multiple

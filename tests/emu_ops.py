@@ -291,6 +291,60 @@ class EmuOps:
             t = y.double().reshape(rows // 128, 128, C_)
             _flat(chan_parts)[: (rows // 128) * C_ * 2].reshape(rows // 128, C_, 2).copy_(torch.stack([t.sum(1), (t * t).sum(1)], dim=-1).float())
 
+    def panel_linear_supported(self, dtype, *, rows, N, K, gn_rows_per_sample=0):
+        """the shapes libfyc_hip.so's kernel is built for (csrc/panel_linear.hip)"""
+        return (dtype == torch.bfloat16 and rows % 128 == 0 and K in (320, 640) and N in (320, 640)
+                and (gn_rows_per_sample == 0 or (gn_rows_per_sample % 128 == 0 and rows % gn_rows_per_sample == 0)))
+
+    @staticmethod
+    def _panel_unpack(wstream, N, K):
+        """inverse of the fyc_panel_linear weight stream (include/fyc.h), written from the layout description"""
+        pn = min(N, 320)                                                         # columns per pass (the kernel: 320)
+        nb = pn // 16
+        S = _flat(wstream).reshape(N // pn, K // 64, 2 * nb, 64, 8)               # [pass][stage][piece][lane][e]
+        lane = torch.arange(64)
+        r, gq = lane & 15, lane >> 4
+        W = torch.zeros(N, K, dtype=wstream.dtype)
+        for P in range(N // pn):
+            for t in range(K // 64):
+                for sk in range(2):
+                    for j in range(nb):
+                        blk = torch.zeros(16, 32, dtype=wstream.dtype)
+                        for e in range(8):
+                            blk[r, 8 * gq + e] = S[P, t, sk * nb + j][:, e]
+                        W[pn * P + 16 * j: pn * P + 16 * j + 16, 32 * (2 * t + sk): 32 * (2 * t + sk) + 32] = blk
+        return W
+
+    def panel_linear(self, x, out, *, wstream, rows, N, K, bias=None, residual=None, gn_cs=None, gn_gamma=None, gn_beta=None,
+                     gn_rows_per_sample=0, gn_stat_samples=1, gn_groups=32, gn_eps=1e-6):
+        """out = [GroupNorm](x) W^T + bias (+ residual); the normalised operand is rounded to the storage dtype (what
+        fyc_gn_apply_cs would have stored); GroupNorm statistics from the f64 channel sums"""
+        acc_t, T = self.acc, x.dtype
+        key = ("panel", wstream.data_ptr(), N, K)
+        cache = self.__dict__.setdefault("_ff_cache", {})
+        if key not in cache:
+            cache[key] = self._panel_unpack(wstream, N, K)
+        W = cache[key]
+        X = _flat(x)[: rows * K].reshape(rows, K).to(acc_t)
+        if gn_cs is not None:
+            S = rows // gn_rows_per_sample
+            cpg = K // gn_groups
+            cs = _flat(gn_cs)[: S * gn_stat_samples * K * 2].reshape(S, gn_stat_samples, K, 2).sum(dim=1)
+            st = cs.reshape(S, gn_groups, cpg, 2).sum(dim=2)
+            cnt = gn_rows_per_sample * cpg
+            mean = st[..., 0] / cnt
+            rstd = 1.0 / torch.sqrt((st[..., 1] / cnt - mean * mean).clamp_min(0) + gn_eps)
+            scale = rstd.float()[:, :, None] * gn_gamma.float().reshape(gn_groups, cpg)[None]            # [S][groups][cpg]
+            shift = gn_beta.float().reshape(gn_groups, cpg)[None] - mean.float()[:, :, None] * scale
+            Xn = X.float().reshape(S, gn_rows_per_sample, K) * scale.reshape(S, 1, K) + shift.reshape(S, 1, K)
+            X = Xn.reshape(rows, K).to(T).to(acc_t)
+        y = X @ W.to(acc_t).t()
+        if bias is not None:
+            y = y + bias.to(acc_t)
+        if residual is not None:
+            y = y + _flat(residual)[: rows * N].reshape(rows, N).to(acc_t)
+        _flat(out)[: rows * N].reshape(rows, N).copy_(y.to(out.dtype))
+
     # ------------------------------------------------------------------------------------
     def gn_stats(self, x, stats, *, rows, C_, groups, rows_per_sample):
         xs = _flat(x)[: rows * C_].reshape(rows // rows_per_sample, rows_per_sample, groups, C_ // groups).double()

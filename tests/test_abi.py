@@ -19,6 +19,7 @@ STRUCTS = {
     "fyc_embed_args": "EmbedArgs", "fyc_patchify_args": "PatchifyArgs", "fyc_row_stats_args": "RowStatsArgs",
     "fyc_pack_conv3x3_args": "PackConv3x3Args", "fyc_pack_geglu_args": "PackGegluArgs",
     "fyc_temporal_block_args": "TemporalBlockArgs", "fyc_ff_block_args": "FFBlockArgs",
+    "fyc_panel_linear_args": "PanelLinearArgs",
 }
 
 

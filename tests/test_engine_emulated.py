@@ -75,6 +75,46 @@ def test_unet_forward_with_fused_ff_blocks(golden_dir, dtype, tol, monkeypatch):
     assert len(calls) >= 5, calls                      # the 64-channel level (rows = B*F*H*W is a multiple of 128 there)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_unet_forward_with_panel_linears(golden_dir, dtype, tol, monkeypatch):
+    """FYC_FUSE_PANEL: proj_in of every transformer / motion module goes through `panel_linear` WITH its GroupNorm (from the
+    producer's channel sums: no gn_apply pass), the attention output projections through it with their residual - same golden"""
+    from followyourclick_amd.engine import unet3d
+    monkeypatch.setattr(unet3d, "FUSE_PANEL", True)
+    calls = []
+
+    class Spy(EmuOps):
+        def panel_linear_supported(self, dtype, *, rows, N, K, gn_rows_per_sample=0):   # the tiny widths are outside the kernel's shapes: force the path
+            return N == K
+
+        def panel_linear(self, x, out, **kw):
+            calls.append((kw["N"], kw.get("gn_cs") is not None, kw.get("residual") is not None))
+            return super().panel_linear(x, out, **kw)
+    g = _load(golden_dir, "unet_tiny_fwd.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), dtype, "cpu"), ops=Spy())
+    x9 = g["sample"]
+    B, C9, F, H, Wd = x9.shape
+    x = torch.zeros(B * F * H * Wd, 64)
+    x[:, :C9] = x9.permute(0, 2, 3, 4, 1).reshape(-1, C9)
+    eng.prepare_context(g["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), B)
+    out = eng.forward(x.to(dtype), temb, B, F, H, Wd).float().reshape(B, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    rel = ((out - g["out"]).norm() / g["out"].norm()).item()
+    assert rel < tol, rel
+    # proj_in with its GroupNorm (wherever the producer could deliver channel sums: frames of >= 16 rows); to_out with residual
+    assert sum(1 for c in calls if c[1]) >= 8 and sum(1 for c in calls if c[2]) >= 16, calls
+
+
+def test_panel_linear_stream_round_trip():
+    from followyourclick_amd.engine.weights import pack_panel_linear
+    for N, K, T in [(320, 320, torch.bfloat16), (640, 640, torch.bfloat16), (320, 640, torch.float32), (128, 64, torch.float32)]:
+        w = torch.randn(N, K, generator=torch.Generator().manual_seed(N + K)).to(T)
+        st = pack_panel_linear(w)
+        assert st.numel() == N * K
+        assert torch.equal(EmuOps._panel_unpack(st, N, K), w)
+
+
 def test_ff_block_stream_round_trip():
     """weights.pack_ff_block against the layout description of include/fyc.h (the emulator's independent unpacker), at the
     kernel's widths and at a small one"""

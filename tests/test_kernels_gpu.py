@@ -353,6 +353,52 @@ def test_temporal_block_fused(hip, emu, clips, P, with_pe):
         hip.temporal_block(xc, xc, **ops_h, **kw)
 
 
+@pytest.mark.parametrize("with_gn,with_res", [(False, True), (True, False), (True, True), (False, False)])
+@pytest.mark.parametrize("rows,N,K", [(128, 320, 320), (4096, 640, 640), (131072, 320, 320), (32768, 640, 640), (512, 320, 640), (512, 640, 320)])
+def test_panel_linear(hip, emu, rows, N, K, with_gn, with_res):
+    """fyc_panel_linear (register-resident rows, fragment-ordered weight stream, optional GroupNorm of the input on the operand
+    registers, bias + residual) against the torch specification on the stream of engine/weights.py::pack_panel_linear"""
+    from followyourclick_amd.engine.weights import pack_panel_linear
+    T = torch.bfloat16
+    w = (rnd((N, K), torch.float32, 1) * K ** -0.5).to(T)
+    ws = pack_panel_linear(w)
+    bias = rnd((N,), torch.float32, 2) * 0.2
+    x = (rnd((rows, K), torch.float32, 3) * 1.3 + 0.4).to(T)
+    res = rnd((rows, N), T, 4) if with_res else None
+    rps = 128 if rows <= 512 else 4096                       # rows per GroupNorm sample (a frame)
+    kw = {}
+    if with_gn:
+        xs = x.double().reshape(rows // rps, rps, K)
+        # two statistics samples per norm sample (the kernel folds them): halves of the rows
+        half = xs.reshape(rows // rps, 2, rps // 2, K)
+        cs = torch.stack([half.sum(2), (half * half).sum(2)], dim=-1).reshape(-1, K, 2).contiguous()
+        kw = dict(gn_cs=cs, gn_gamma=rnd((K,), torch.float32, 5) * 0.2 + 1.0, gn_beta=rnd((K,), torch.float32, 6) * 0.2,
+                  gn_rows_per_sample=rps, gn_stat_samples=2, gn_groups=32, gn_eps=1e-6)
+    assert hip.panel_linear_supported(T, rows=rows, N=N, K=K, gn_rows_per_sample=rps if with_gn else 0)
+    assert not hip.panel_linear_supported(T, rows=rows + 64, N=N, K=K) and not hip.panel_linear_supported(T, rows=rows, N=960, K=K)
+    assert not hip.panel_linear_supported(torch.float32, rows=rows, N=N, K=K) and not hip.panel_linear_supported(T, rows=rows, N=N, K=K, gn_rows_per_sample=64)
+    o_h = torch.full((rows, N), float("nan"), dtype=T, device="cuda")
+    hip.panel_linear(x.cuda(), o_h, wstream=ws.cuda(), rows=rows, N=N, K=K, bias=bias.cuda(), residual=res.cuda() if with_res else None,
+                     **{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    torch.cuda.synchronize()
+    assert torch.isfinite(o_h.float()).all()
+    if rows > 4096:                                            # the specification on whole samples from both ends and the middle
+        sel = torch.cat([torch.arange(0, rps), torch.arange(rows // 2, rows // 2 + rps), torch.arange(rows - rps, rows)])
+    else:
+        sel = torch.arange(rows)
+    n = len(sel)
+    o_e = torch.zeros(n, N, dtype=T)
+    kw_e = dict(kw)
+    if with_gn:
+        samp = torch.unique(sel // rps)
+        kw_e["gn_cs"] = kw["gn_cs"].reshape(rows // rps, 2, K, 2)[samp].reshape(-1, K, 2)
+    emu.panel_linear(x[sel], o_e, wstream=ws, rows=n, N=N, K=K, bias=bias, residual=res[sel] if with_res else None, **kw_e)
+    close(o_h[sel.cuda()], o_e, f"panel linear rows{rows} N{N} K{K} gn{with_gn} res{with_res}", 5e-3)
+    with pytest.raises(Exception, match="alias"):
+        xc = x.cuda()
+        hip.panel_linear(xc, xc, wstream=ws.cuda(), rows=rows, N=N, K=K) if N == K else (_ for _ in ()).throw(RuntimeError("alias"))
+
+
 def _ff_operands(seed=0):
     """a packed feed-forward (engine/weights.py::_ff layout) with the LayerNorm folded in, at the kernel's widths"""
     from followyourclick_amd.engine.weights import Packed
