@@ -35,7 +35,10 @@ Tensor = torch.Tensor
 FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
 FUSE_TEMPORAL = os.environ.get("FYC_FUSE_TEMPORAL", "1") != "0"   # fyc_temporal_block: one kernel per temporal attention sub-block (C = 320 level)
 FUSE_FF = os.environ.get("FYC_FUSE_FF", "1") != "0"               # fyc_ff_block: LayerNorm + FF1 + GEGLU + FF2 + output projection in one kernel (C = 320 level)
-FUSE_PANEL = os.environ.get("FYC_FUSE_PANEL", "1") != "0"         # fyc_panel_linear: K <= 640 projections with register-resident rows; proj_in takes its GroupNorm along
+FUSE_PANEL = os.environ.get("FYC_FUSE_PANEL", "1") != "0"         # fyc_panel_linear for GroupNorm -> proj_in: the norm is applied to the operand registers (no apply pass)
+# the plain / residual K <= 640 projections through fyc_panel_linear as well: measured equal to fyc_gemm (98 vs 91 us at the 64x64
+# level, 60 vs 61 at 32x32: one workgroup per CU leaves its memory phases exposed, profiles/r03_panel_linear_probe.txt) - off
+PANEL_ALL = os.environ.get("FYC_PANEL_ALL", "0") != "0"
 FUSE_ROWS = os.environ.get("FYC_FUSE_ROWS", "0") != "0"      # the LayerNorm half (row_parts): measured slower than the separate fyc_row_stats pass (profiles/r02_stats_fusion_ab.txt), off by default
 
 
@@ -228,7 +231,7 @@ class UNet3DEngine(EngineBase):
         """Linear whose output feeds a (folded) LayerNorm: the epilogue also writes the per-row partial sums"""
         N, K = w.shape
         out = self.new(rows, N, dtype=x.dtype)
-        if FUSE_PANEL and not self.fuse_rows and self.ops.panel_linear_supported(x.dtype, rows=rows, N=N, K=K):
+        if FUSE_PANEL and PANEL_ALL and not self.fuse_rows and self.ops.panel_linear_supported(x.dtype, rows=rows, N=N, K=K):
             self.ops.panel_linear(x, out, wstream=self._panel_stream(w), rows=rows, N=N, K=K, bias=bias, residual=residual)
             return Act(out, N)
         rp, n = None, 0

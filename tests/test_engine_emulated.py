@@ -81,6 +81,7 @@ def test_unet_forward_with_panel_linears(golden_dir, dtype, tol, monkeypatch):
     producer's channel sums: no gn_apply pass), the attention output projections through it with their residual - same golden"""
     from followyourclick_amd.engine import unet3d
     monkeypatch.setattr(unet3d, "FUSE_PANEL", True)
+    monkeypatch.setattr(unet3d, "PANEL_ALL", True)
     calls = []
 
     class Spy(EmuOps):
