@@ -77,6 +77,18 @@ __device__ __forceinline__ void dma_landed_barrier() {       // this wave's DMA 
   __syncthreads();
 }
 
+// sum over the four 16-lane rows of a wave (every lane gets it): gfx950's v_permlane16_swap / v_permlane32_swap, plain VALU.
+// NOT __shfl_xor: that is ds_bpermute_b32, an LDS-queue instruction, and hipcc (which cannot see the asm DMAs above) waits for it
+// with a COUNTED lgkmcnt between the fragment reads of the projection stages it sinks this code into - with LDS-DMA writes in
+// flight the result was consumed early in ~12 % of the 16-row blocks (row statistics off by ~1e-3: tools/ff_stress.py found the
+// kernel's output changing from launch to launch; profiles/r03_ff_block_race.txt)
+__device__ __forceinline__ float rows_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
@@ -135,8 +147,12 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) s += __uint_as_float(t[e] << 16) + __uint_as_float(t[e] & 0xffff0000u);
     }
+#ifdef FF_BPERMUTE
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
+#else
+    s = rows_sum(s);
+#endif
     const float m = s * (1.0f / C_);
     float q = 0.f;
 #pragma unroll
@@ -149,8 +165,12 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
         q = __builtin_fmaf(b, b, q);
       }
     }
+#ifdef FF_BPERMUTE
     q += __shfl_xor(q, 16);
     q += __shfl_xor(q, 32);
+#else
+    q = rows_sum(q);
+#endif
     mu[i] = m;
     rs[i] = rsqrtf(q * (1.0f / C_) + p.eps);
   }

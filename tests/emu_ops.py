@@ -268,11 +268,13 @@ class EmuOps:
         storage dtype where the kernel packs it into MFMA operands; chan_parts [rows / 128][C][2] = per 128-row tile {sum, sum of
         squares} of the stored output"""
         acc_t, T = self.acc, x.dtype
+        # unpacked weights per stream; the entry keeps the stream tensor alive: keyed by address alone, a NEW stream that the
+        # allocator put where a freed one had been got the old weights (a test then failed at random, round 3)
         key = (wstream.data_ptr(), C_, hidden)
         cache = self.__dict__.setdefault("_ff_cache", {})
         if key not in cache:
-            cache[key] = self._ff_unpack(wstream, C_, hidden)
-        Wp, W1, bi, W2 = cache[key]
+            cache[key] = (wstream, self._ff_unpack(wstream, C_, hidden))
+        Wp, W1, bi, W2 = cache[key][1]
         X = _flat(x)[: rows * C_].reshape(rows, C_).to(acc_t)
         Xf = X.float()
         mean = Xf.mean(-1, keepdim=True)
@@ -323,8 +325,8 @@ class EmuOps:
         key = ("panel", wstream.data_ptr(), N, K)
         cache = self.__dict__.setdefault("_ff_cache", {})
         if key not in cache:
-            cache[key] = self._panel_unpack(wstream, N, K)
-        W = cache[key]
+            cache[key] = (wstream, self._panel_unpack(wstream, N, K))      # (holds the stream: see ff_block)
+        W = cache[key][1]
         X = _flat(x)[: rows * K].reshape(rows, K).to(acc_t)
         if gn_cs is not None:
             S = rows // gn_rows_per_sample

@@ -481,6 +481,69 @@ def test_ff_block_matches_unfused_schedule(hip, emu, rows):
     close(o_f, o_u.cpu(), f"ff block vs unfused launches rows{rows}", 6e-3)
 
 
+@pytest.mark.parametrize("rows", [65536, 8192])
+def test_ff_block_is_repeatable(hip, rows):
+    """the kernel has no atomics: every launch on the same operands must give the same bits, cold or warm caches.  (Round 3: the
+    LayerNorm row sums went through ds_bpermute between LDS-DMA pieces and were consumed early in ~12 % of the 16-row blocks -
+    output off by an ulp or two, differently on every launch; tools/ff_stress.py, profiles/r03_ff_block_race.txt)"""
+    from followyourclick_amd.engine.weights import pack_ff_block
+    T, C, hid = torch.bfloat16, 320, 1280
+    ff = _ff_operands(11)
+    ws, po_b = pack_ff_block(ff).cuda(), ff.po_b.cuda()
+    x = (rnd((rows, C), torch.float32, 8) * 1.2 - 0.2).to(T).cuda()
+    res = rnd((rows, C), T, 9).cuda()
+    junk = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+    parts0 = out0 = None
+    for it in range(24):
+        if it % 3 == 1:
+            junk.fill_(it)                                     # cold L2 / Infinity Cache
+        out = torch.full((rows, C), float("nan"), dtype=T, device="cuda")
+        parts = torch.full((rows // 128, C, 2), float("nan"), dtype=torch.float32, device="cuda")
+        hip.ff_block(x, res, out, wstream=ws, b_out=po_b, rows=rows, C_=C, hidden=hid, chan_parts=parts, cs_rows=128)
+        torch.cuda.synchronize()
+        if out0 is None:
+            out0, parts0 = out, parts
+            assert torch.isfinite(out.float()).all() and torch.isfinite(parts).all()
+            continue
+        d = (out.view(torch.int16) != out0.view(torch.int16)).any(dim=1).sum().item()
+        assert d == 0, f"launch {it}: {d} of {rows} rows differ from launch 0"
+        assert torch.equal(parts, parts0), f"launch {it}: statistics differ from launch 0"
+
+
+@pytest.mark.parametrize("C,gn", [(320, True), (320, False), (640, True)])
+def test_panel_linear_is_repeatable(hip, C, gn):
+    """same for the row-panel linear (asm-issued LDS-DMA as well)"""
+    from followyourclick_amd.engine.weights import pack_panel_linear
+    T = torch.bfloat16
+    rps, samples = (4096, 8) if C == 320 else (1024, 16)
+    rows = rps * samples
+    w = rnd((C, C), torch.float32, 3, 0.05).to(T)
+    ws = pack_panel_linear(w).cuda()
+    bias = rnd((C,), torch.float32, 4, 0.1).cuda()
+    x = (rnd((rows, C), torch.float32, 5) + 0.3).to(T).cuda()
+    res = rnd((rows, C), T, 6).cuda()
+    kw = {}
+    if gn:
+        xf = x.double().reshape(samples, rps, C)
+        cs = torch.stack([xf.sum(1), (xf * xf).sum(1)], dim=-1).contiguous()        # [samples][C][2] f64
+        kw = dict(gn_cs=cs, gn_gamma=(rnd((C,), torch.float32, 7) * 0.1 + 1).cuda(), gn_beta=(rnd((C,), torch.float32, 8) * 0.1).cuda(),
+                  gn_rows_per_sample=rps, gn_groups=32)
+    junk = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+    out0 = None
+    for it in range(16):
+        if it % 3 == 1:
+            junk.fill_(it)
+        out = torch.full((rows, C), float("nan"), dtype=T, device="cuda")
+        hip.panel_linear(x, out, wstream=ws, rows=rows, N=C, K=C, bias=bias, residual=None if gn else res, **kw)
+        torch.cuda.synchronize()
+        if out0 is None:
+            out0 = out
+            assert torch.isfinite(out.float()).all()
+            continue
+        d = (out.view(torch.int16) != out0.view(torch.int16)).any(dim=1).sum().item()
+        assert d == 0, f"launch {it}: {d} of {rows} rows differ from launch 0"
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("samples,rps,C", [(2, 4 * 64, 320), (8, 64, 64), (2, 16 * 16, 2560), (6, 1, 128), (3, 1000, 960), (2, 37, 1920)])
