@@ -15,14 +15,14 @@ CSRC = os.path.join(HERE, "csrc")
 EXTRA = os.environ.get("FYC_BUILD_EXTRA", "").split()
 LIB = os.path.abspath(os.environ.get("FYC_BUILD_LIB") or os.path.join(HERE, "libfyc_hip.so"))
 OBJ = os.path.join(HERE, "_obj") if not (EXTRA or os.environ.get("FYC_BUILD_LIB")) else LIB + ".obj"
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "temporal_block.hip", "ff_block.hip", "panel_linear.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "temporal_block.hip", "temporal_block_rr.hip", "ff_block.hip", "panel_linear.hip", "norm.hip", "elementwise.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file and every
 # kernel here fits in 256 registers), which removes the v_accvgpr_read/write traffic around the
 # softmax rescale and the epilogues (312 -> 0 such moves in the attention main loop).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-# ff_block.hip / panel_linear.hip run one wave per SIMD with the whole 512-register file: the accumulators must be AGPRs
-AGPR_SOURCES = {"ff_block.hip", "panel_linear.hip"}
+# ff_block.hip / panel_linear.hip / temporal_block_rr.hip run one wave per SIMD with the whole 512-register file: the accumulators must be AGPRs
+AGPR_SOURCES = {"ff_block.hip", "panel_linear.hip", "temporal_block_rr.hip"}
 
 
 def _flags(src: str):

@@ -121,7 +121,7 @@ class PatchifyArgs(C.Structure):
 class TemporalBlockArgs(C.Structure):
     _fields_ = [("x", vp), ("out", vp), ("w_qkv", vp), ("colsum", vp), ("bias", vp), ("pe_bias", vp), ("w_out", vp), ("b_out", vp),
                 ("clips", i32), ("frames", i32), ("pixels", i32), ("heads", i32), ("d", i32), ("C", i32),
-                ("scale", C.c_float), ("eps", C.c_float), ("dtype", i32)]
+                ("scale", C.c_float), ("eps", C.c_float), ("dtype", i32), ("wstream", vp)]
 
 
 class FFBlockArgs(C.Structure):
@@ -155,7 +155,7 @@ OPS = {
     "fyc_pack_conv3x3": PackConv3x3Args, "fyc_pack_geglu": PackGegluArgs, "fyc_temporal_block": TemporalBlockArgs,
     "fyc_ff_block": FFBlockArgs, "fyc_panel_linear": PanelLinearArgs,
 }
-MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_temporal_block_supported",
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_temporal_block_supported", "fyc_temporal_block_wstream_bytes",
         "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
@@ -190,6 +190,9 @@ def load() -> C.CDLL:
     if not ab_build or hasattr(lib, "fyc_temporal_block_supported"):
         lib.fyc_temporal_block_supported.argtypes = [C.POINTER(TemporalBlockArgs)]
         lib.fyc_temporal_block_supported.restype = C.c_int
+    if not ab_build or hasattr(lib, "fyc_temporal_block_wstream_bytes"):
+        lib.fyc_temporal_block_wstream_bytes.argtypes = []
+        lib.fyc_temporal_block_wstream_bytes.restype = i64
     if not ab_build or hasattr(lib, "fyc_ff_block_supported"):
         lib.fyc_ff_block_supported.argtypes = [C.POINTER(FFBlockArgs)]
         lib.fyc_ff_block_supported.restype = C.c_int

@@ -22,8 +22,8 @@
 //     operand of FF2 as they stand (the k-slots of the W2' fragments are packed in the order the gate outputs sit in the lanes:
 //     no shuffle, no LDS round trip) - and 40 MFMAs of FF2 for the PREVIOUS chunk, so that the gate's VALU work has independent
 //     matrix work beside it.  One barrier per stage;
-//   * epilogue: residual tile by DMA into the (now idle) ring, + bias + accumulators in f32, one rounding to bf16 in LDS, the
-//     tile leaves as a flat 80-KiB copy (16 B / lane); per-(row tile, channel) {sum, sum sq} of the stored values for the
+//   * epilogue: residual tile by DMA into the (now idle) ring (row pitch padded against bank conflicts), + bias + accumulators
+//     in f32, one rounding to bf16 in LDS, the tile leaves in 640-B rows (16 B / lane); per-(row tile, channel) {sum, sum sq} of the stored values for the
 //     GroupNorm that consumes the block (fyc_gemm's chan_parts layout with tile_rows = 128, one slot).
 //
 // Built for the level where it pays (C = 320, hidden 1280, bf16, rows % 128 == 0); other shapes keep the unfused schedule.
@@ -44,10 +44,14 @@ constexpr int NSTAGE = PROJ_ST + CHUNKS + 1;   // 46
 constexpr int PIECE = 1024;                    // one MFMA fragment for all 64 lanes
 constexpr int P_CONST = 40, P_W2 = 41, NPIECE = 61, NPIECE_PROJ = 40;
 constexpr int STAGE_BYTES = NPIECE * PIECE;    // 62464
-constexpr int TILE_BYTES = ROWS * C_ * 2;      // 81920: the residual / output tile of the epilogue (overlays the ring)
+// the residual / output tile of the epilogue (overlays the ring).  Row pitch 672 B: consecutive rows are 168 dwords = 40 (mod 64
+// banks) apart, so the 16 rows x 4 quads x 8 B of one in-place add spread over all banks; at the natural 640 B (32 mod 64) they
+// met in two banks, 8-way (the same defect cost csrc/temporal_block_rr.hip a fifth of its tile time: profiles/r03_temporal_block_rr_phases.txt)
+constexpr int TP = C_ * 2 + 32;
+constexpr int TILE_BYTES = ROWS * TP;          // 86016 = 84 pieces
 constexpr int SCR_BYTES = 6 * 40 * 16 * 4;       // statistics partials of the epilogue: [row slice][column group][8 sums | 8 sums of squares]
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-static_assert(TILE_BYTES <= STAGE_BYTES + P_CONST * PIECE, "the residual tile lands while the last stage still reads its constants / W2' pieces");
+static_assert(TILE_BYTES % PIECE == 0 && TILE_BYTES <= STAGE_BYTES + P_CONST * PIECE, "the residual tile lands while the last stage still reads its constants / W2' pieces");
 static_assert(TILE_BYTES + SCR_BYTES <= LDS_BYTES, "epilogue tile + statistics scratch overlay the ring");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
@@ -71,6 +75,11 @@ __device__ __forceinline__ void dma16(const char* gbase, unsigned voff, unsigned
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma16v(const void* gsrc, unsigned lds_dst) {                        // per-lane source address
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void dma_landed_barrier() {       // this wave's DMA pieces have landed, then the workgroup meets
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -331,10 +340,14 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   if (work) stage(smem + ((NSTAGE - 2) & 1) * STAGE_BYTES, h1, h0, std::true_type{}, NSTAGE - 1);
   else issue(NSTAGE - 1);
   dma_landed_barrier();                                            // last stage: gate + FF2 of chunk 39 only (reads pieces 40.. of its slot)
-  if (p.res != nullptr) {                                     // the 128 residual rows are one contiguous 80 KiB: flat DMA over the idle part of the ring
-    const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);
+  if (p.res != nullptr) {                                     // residual tile over the idle part of the ring: the LDS image is linear, every
+    const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);      // lane fetches the 16 B that belong at its place
 #pragma unroll 1
-    for (int q = wave; q < TILE_BYTES / PIECE; q += 4) dma16(src + q * PIECE, lane16, lds0 + q * PIECE);
+    for (int q = wave; q < TILE_BYTES / PIECE; q += 4) {
+      const int off = q * PIECE + (int)lane16, row = off / TP;
+      const int col = min(off - row * TP, C_ * 2 - 16);         // (the 32 pad bytes of a row re-fetch its last chunk)
+      dma16v(src + row * (C_ * 2) + col, lds0 + q * PIECE);
+    }
   }
   if (work) {
     const char* base = smem + ((NSTAGE - 1) & 1) * STAGE_BYTES;
@@ -353,7 +366,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      bf16_t* a = reinterpret_cast<bf16_t*>(smem + (wave * 32 + i * 16 + r16) * (C_ * 2)) + j * 16 + g * 4;
+      bf16_t* a = reinterpret_cast<bf16_t*>(smem + (wave * 32 + i * 16 + r16) * TP) + j * 16 + g * 4;
       const f32x4 bo = *reinterpret_cast<const f32x4*>(bias_out + j * 16 + g * 4);
       float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
       if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
@@ -374,7 +387,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       const char* src = smem + cg * 16;
 #pragma unroll 2
       for (int row = rsl; row < ROWS; row += 6) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * (C_ * 2));
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * TP);
         *reinterpret_cast<u32x4*>(dst + row * (C_ * 2)) = v;
         if (p.parts != nullptr) {
 #pragma unroll

@@ -19,6 +19,10 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // ---- error plumbing (host) ----------------------------------------------------------------
 extern thread_local char g_fyc_err[512];
 extern const void* g_fyc_zero_page;
+// csrc/temporal_block_rr.hip (register-resident form of fyc_temporal_block, taken when the caller passes `wstream`)
+int64_t fyc_temporal_block_rr_wstream_bytes();
+int64_t fyc_temporal_block_rr_lds_bytes();
+int fyc_temporal_block_rr_launch(const fyc_temporal_block_args* a, void* stream);
 extern int g_fyc_tuning[16];  // [1] forced GEMM tile config, [2] forced ring depth, [3] attention variant, [4] GEMM tile-order strip width (-1 = row-major)
 
 #define FYC_FAIL(code, ...)                                   \

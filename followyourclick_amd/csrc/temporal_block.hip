@@ -296,11 +296,14 @@ extern "C" int fyc_temporal_block_supported(const fyc_temporal_block_args* a) {
   return (lds_cap > 0 && lds_cap < LDS_BYTES) ? 0 : 1;   // less LDS than the 153 KB tile needs: the engine keeps the unfused schedule
 }
 
+extern "C" int64_t fyc_temporal_block_wstream_bytes(void) { return fyc_temporal_block_rr_wstream_bytes(); }
+
 extern "C" int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream) {
-  FYC_REQUIRE(a && a->x && a->out && a->w_qkv && a->colsum && a->bias && a->w_out && a->b_out, "fyc_temporal_block: null pointer");
+  FYC_REQUIRE(a && a->x && a->out && a->b_out && (a->wstream || (a->w_qkv && a->colsum && a->bias && a->w_out)), "fyc_temporal_block: null pointer");
   FYC_REQUIRE(fyc_temporal_block_supported(a), "fyc_temporal_block: built for bf16, C=320, 8 heads of 40, 16 frames, pixels %% 8 == 0 (got C=%d heads=%d d=%d frames=%d pixels=%d)",
               a->C, a->heads, a->d, a->frames, a->pixels);
   FYC_REQUIRE(a->x != a->out, "fyc_temporal_block: in-place operation is not supported (tiles read rows of every frame)");
+  if (a->wstream != nullptr) return fyc_temporal_block_rr_launch(a, stream);      // pre-packed stream: the register-resident kernel
   TBlockP p;
   p.x = (const bf16_t*)a->x; p.out = (bf16_t*)a->out; p.w_qkv = (const bf16_t*)a->w_qkv; p.colsum = a->colsum; p.bias = a->bias;
   p.pe_bias = a->pe_bias; p.w_out = (const bf16_t*)a->w_out; p.b_out = a->b_out; p.clips = a->clips; p.pixels = a->pixels;

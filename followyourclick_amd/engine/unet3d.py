@@ -34,6 +34,7 @@ Tensor = torch.Tensor
 # instead of by a read pass per GroupNorm / LayerNorm.  FYC_FUSE_STATS=0 restores the separate passes (A/B measurements).
 FUSE_STATS = os.environ.get("FYC_FUSE_STATS", "1") != "0"
 FUSE_TEMPORAL = os.environ.get("FYC_FUSE_TEMPORAL", "1") != "0"   # fyc_temporal_block: one kernel per temporal attention sub-block (C = 320 level)
+TEMPORAL_RR = os.environ.get("FYC_TEMPORAL_RR", "1") != "0"       # ... in its register-resident form (csrc/temporal_block_rr.hip, pre-packed weight stream)
 FUSE_FF = os.environ.get("FYC_FUSE_FF", "1") != "0"               # fyc_ff_block: LayerNorm + FF1 + GEGLU + FF2 + output projection in one kernel (C = 320 level)
 FUSE_PANEL = os.environ.get("FYC_FUSE_PANEL", "1") != "0"         # fyc_panel_linear for GroupNorm -> proj_in: the norm is applied to the operand registers (no apply pass)
 # the plain / residual K <= 640 projections through fyc_panel_linear as well: measured equal to fyc_gemm (98 vs 91 us at the 64x64
@@ -418,7 +419,10 @@ class UNet3DEngine(EngineBase):
                     if g["F"] not in cache:
                         cache[g["F"]] = pack_temporal_block(a, Hm, g["F"])
                     out = self.new(rows, C)
-                    o.temporal_block(tok.t, out, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5, **cache[g["F"]])
+                    kw = cache[g["F"]]
+                    if not TEMPORAL_RR and "wstream" in kw:
+                        kw = {k: v for k, v in kw.items() if k != "wstream"}
+                    o.temporal_block(tok.t, out, clips=g["B"], frames=g["F"], pixels=N, heads=Hm, d=d, scale=d ** -0.5, **kw)
                     tok = Act(out, C)
                     continue
                 if a.qkv_f is not None:     # LayerNorm folded into the QKV projection, positional table as a per-frame row bias

@@ -212,7 +212,64 @@ def pack_temporal_block(att: Packed, heads: int, frames: int) -> dict:
         pe = per_head(att.pe_w[:frames].t().contiguous()).permute(2, 0, 1).contiguous()       # [F][H][128]
     wo = torch.zeros(heads, C, 48, dtype=att.o_w.dtype, device=att.o_w.device)
     wo[:, :, :d] = att.o_w.reshape(C, heads, d).permute(1, 0, 2)
-    return dict(w_qkv=per_head(w), colsum=per_head(cs), bias=per_head(b), pe_bias=pe, w_out=wo.contiguous(), b_out=att.o_b)
+    ops = dict(w_qkv=per_head(w), colsum=per_head(cs), bias=per_head(b), pe_bias=pe, w_out=wo.contiguous(), b_out=att.o_b)
+    if frames == 16 and C % 32 == 0:
+        ops["wstream"] = pack_temporal_stream(ops["w_qkv"], ops["bias"], pe, ops["w_out"], d)
+    return ops
+
+
+def temporal_block_layout(C: int) -> dict:
+    """piece indices of the two stages per head of the fyc_temporal_block weight stream (include/fyc.h); at C = 320: stage A =
+    60 q/k fragments + 6 table pieces, stage B = 30 v fragments + 40 Wo' fragments + 3 table pieces, stride 73 pieces"""
+    ks, nb = C // 32, C // 16
+    lay = dict(ks=ks, nb=nb, a_tab=6 * ks, a_pieces=6 * ks + 6, b_wo=3 * ks, b_tab=3 * ks + 2 * nb, b_pieces=3 * ks + 2 * nb + 3)
+    lay["stride"] = max(lay["a_pieces"], lay["b_pieces"])
+    return lay
+
+
+def temporal_slot_feature(t: int, k: int) -> int:
+    """head feature that k-slot k (0..31) of k-step t of the attention output operand carries in csrc/temporal_block_rr.hip (a lane
+    holds 4 consecutive features of each 16-feature block where an MFMA operand wants 8 consecutive k), 48 = none (zero)"""
+    g, e = k // 8, k % 8
+    if t == 0:
+        return 4 * g + e if e < 4 else 16 + 4 * g + e - 4
+    return 32 + 4 * g + e if e < 4 else 48
+
+
+def pack_temporal_stream(w_qkv: Tensor, bias: Tensor, pe_bias: Optional[Tensor], w_out: Tensor, d: int) -> Tensor:
+    """weight stream of the register-resident fyc_temporal_block (csrc/temporal_block_rr.hip; layout: include/fyc.h) from the
+    per-head operands above: w_qkv [H][128][C] (q | k | v rows of the head), bias [H][128], pe_bias [16][H][128] or None,
+    w_out [H][C][48].  Two stages per head, 1-KiB MFMA fragments; the bias tables are f32 bytes inside the stream."""
+    H, _, C = w_qkv.shape
+    F = 16
+    assert d <= 48 and C % 32 == 0 and (pe_bias is None or pe_bias.shape[0] == F)
+    lay = temporal_block_layout(C)
+    ks, nb = lay["ks"], lay["nb"]
+    T, dev = w_qkv.dtype, w_qkv.device
+    st = torch.zeros(2 * H, lay["stride"], 512, dtype=T, device=dev)
+    qkv = torch.zeros(H, 3, 48, C, dtype=T, device=dev)
+    for i in range(3):
+        qkv[:, i, :d] = w_qkv[:, i * d:(i + 1) * d]
+    # stage A: piece s * 6 + (which * 3 + b) = rows 16 b .. +16 of q (which = 0) / k (1), columns 32 s .. +32
+    blk = qkv[:, :2].reshape(H, 2, 3, 16, ks, 32).permute(0, 4, 1, 2, 3, 5).reshape(H, ks * 6, 16, 32)
+    st[0::2, :6 * ks] = _mfma_fragments(blk)
+    tb = bias.float()[:, None, :] + (pe_bias.float().permute(1, 0, 2) if pe_bias is not None else 0.0)      # [H][F][128]
+    tb = tb.expand(H, F, 128)
+    ta = torch.zeros(H, F, 96, dtype=torch.float32, device=dev)
+    ta[:, :, :d] = tb[:, :, :d]
+    ta[:, :, 48:48 + d] = tb[:, :, d:2 * d]
+    st[0::2, lay["a_tab"]:lay["a_tab"] + 6] = ta.reshape(H, -1).contiguous().view(T).reshape(H, 6, 512)
+    # stage B: v fragments, Wo' fragments in the k-slot order of the attention output, v table [48][F]
+    blk = qkv[:, 2].reshape(H, 3, 16, ks, 32).permute(0, 3, 1, 2, 4).reshape(H, ks * 3, 16, 32)
+    st[1::2, :3 * ks] = _mfma_fragments(blk)
+    slot = torch.tensor([[temporal_slot_feature(t, k) for k in range(32)] for t in range(2)], device=dev)   # [2][32]
+    wo_ext = torch.cat([w_out, torch.zeros(H, C, 1, dtype=w_out.dtype, device=dev)], dim=2)                  # column 48 = zero
+    wog = wo_ext[:, :, slot.reshape(-1)].reshape(H, nb, 16, 2, 32).permute(0, 3, 1, 2, 4).reshape(H, 2 * nb, 16, 32)
+    st[1::2, lay["b_wo"]:lay["b_wo"] + 2 * nb] = _mfma_fragments(wog.to(T))
+    tv = torch.zeros(H, 48, F, dtype=torch.float32, device=dev)
+    tv[:, :d] = tb[:, :, 2 * d:3 * d].transpose(1, 2)
+    st[1::2, lay["b_tab"]:lay["b_tab"] + 3] = tv.reshape(H, -1).contiguous().view(T).reshape(H, 3, 512)
+    return st.reshape(-1).contiguous()
 
 
 def ff_block_layout(C: int, hidden: int):

@@ -237,11 +237,18 @@ class HipOps:
 
     def temporal_block(self, x: Tensor, out: Tensor, *, w_qkv: Tensor, colsum: Tensor, bias: Tensor, pe_bias: Optional[Tensor],
                        w_out: Tensor, b_out: Tensor, clips: int, frames: int, pixels: int, heads: int, d: int, scale: float,
-                       eps: float = 1e-5) -> None:
-        """out = x + Attn_F(LayerNorm(x) + pe) Wo^T + bo in one kernel (csrc/temporal_block.hip)"""
+                       eps: float = 1e-5, wstream: Optional[Tensor] = None) -> None:
+        """out = x + Attn_F(LayerNorm(x) + pe) Wo^T + bo in one kernel (csrc/temporal_block.hip); with `wstream`
+        (engine/weights.py::pack_temporal_stream) the register-resident kernel (csrc/temporal_block_rr.hip) runs instead"""
         self.ensure_init(x.device)
-        self._call("fyc_temporal_block", self._tblock_args(x, out, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels,
-                                                           heads, d, scale, eps))
+        a = self._tblock_args(x, out, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels, heads, d, scale, eps)
+        if wstream is not None and hasattr(self.lib, "fyc_temporal_block_wstream_bytes"):
+            if "tbw" not in self._q_cache:
+                self._q_cache["tbw"] = int(self.lib.fyc_temporal_block_wstream_bytes())
+            if wstream.numel() * wstream.element_size() != self._q_cache["tbw"]:
+                raise ValueError(f"temporal_block: wstream has {wstream.numel() * wstream.element_size()} bytes, expected {self._q_cache['tbw']}")
+            a.wstream = _p(wstream)
+        self._call("fyc_temporal_block", a)
 
     def ff_block_supported(self, dtype: torch.dtype, *, rows: int, C_: int, hidden: int, cs_rows: int = 0) -> bool:
         """does fyc_ff_block (the fused GEGLU feed-forward block) cover this shape?  (no launch); cs_rows > 0: with the fused

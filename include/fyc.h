@@ -291,7 +291,20 @@ int fyc_patchify(const fyc_patchify_args* a, void* stream);
  *   colsum, bias [heads][128] f32 (sum_k gamma_k W[n][k];  beta W^T + b),  pe_bias [frames][heads][128] f32 = pe_f W^T or NULL
  *   w_out [heads][C][48]   Wo[n][head*d + k] for k < d, zero for k >= d;  b_out [C] f32
  * Built for dtype bf16, C = 320, 8 heads of 40, 16 frames, pixels % 8 == 0 (fyc_temporal_block_supported says so without
- * launching); x and out must not alias. */
+ * launching); x and out must not alias.
+ * `wstream` (optional, 16-byte aligned, fyc_temporal_block_wstream_bytes() bytes): the same weights pre-packed for the
+ * register-resident kernel (csrc/temporal_block_rr.hip; w_qkv / colsum / bias / pe_bias / w_out are then not read and may be
+ * NULL): 16 stages x 73 pieces x 1 KiB, a piece = one MFMA operand fragment of a 16 x 32 block B in lane order (byte 16 l =
+ * B[l & 15][8 (l >> 4) .. +8], bf16).  Head h:
+ *   stage 2 h      pieces s * 6 + b (s < 10): rows 16 b .. +16 (b < 3) of the head's gamma-scaled to_q rows zero-padded to 48,
+ *                  or rows 16 (b - 3) .. +16 (b >= 3) of its to_k rows, columns 32 s .. +32;
+ *                  pieces 60..65 = f32 table [16 frames][96]: (beta W^T + b + pe_f W^T) of the 48 q and the 48 k features
+ *   stage 2 h + 1  pieces s * 3 + b: to_v rows 16 b .. +16 (padded to 48), columns 32 s .. +32;
+ *                  pieces 30 + 20 t + j (t < 2, j < 20): Wo rows 16 j .. +16 with k-slot 8 g + e of k-step t = head feature
+ *                  4 g + e (t = 0, e < 4), 16 + 4 g + e - 4 (t = 0, e >= 4), 32 + 4 g + e (t = 1, e < 4; zero from feature 40), zero (t = 1, e >= 4);
+ *                  pieces 70..72 = f32 table [48 v features][16 frames] of the same bias sum.
+ * This kernel feeds the projections the normalised tokens (x - mean) rstd rounded to bf16 (engine/weights.py::pack_temporal_block
+ * builds the stream). */
 typedef struct {
   const void* x; void* out;
   const void* w_qkv; const float* colsum; const float* bias; const float* pe_bias;
@@ -299,8 +312,10 @@ typedef struct {
   int32_t clips, frames, pixels, heads, d, C;
   float scale, eps;
   int32_t dtype;
+  const void* wstream;
 } fyc_temporal_block_args;
 int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream);
+int64_t fyc_temporal_block_wstream_bytes(void);
 int fyc_temporal_block_supported(const fyc_temporal_block_args* a);
 
 /* ---- fused GEGLU feed-forward block (diffusers/models/attention.py:772-775, 819-821; animatediff/models/attention.py:489-564;

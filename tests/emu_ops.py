@@ -200,13 +200,77 @@ class EmuOps:
         specification for any head layout that fits the operand packing (3 d <= 128, d <= 48)"""
         return dtype == torch.bfloat16 and heads == 8 and d == 40 and frames == 16 and pixels % 8 == 0
 
-    def temporal_block(self, x, out, *, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels, heads, d, scale, eps=1e-5):
+    @staticmethod
+    def _tblock_unpack(wstream, C_, heads, d):
+        """inverse of the fyc_temporal_block weight stream (include/fyc.h), written from the layout description: returns
+        (w [H][3][48][C] q | k | v rows, table [H][16][3][48] f32 bias + positional term per frame, wo [H][C][48])"""
+        ks, nb = C_ // 32, C_ // 16
+        a_tab, a_n = 6 * ks, 6 * ks + 6
+        b_wo, b_tab, b_n = 3 * ks, 3 * ks + 2 * nb, 3 * ks + 2 * nb + 3
+        S = _flat(wstream).reshape(2 * heads, max(a_n, b_n), 64, 8)                 # [stage][piece][lane][e]
+        lane = torch.arange(64)
+        r, gq = lane & 15, lane >> 4
+
+        def block(piece):                                                            # [64][8] fragment -> [16][32] weight block
+            blk = torch.zeros(16, 32, dtype=piece.dtype)
+            for e in range(8):
+                blk[r, 8 * gq + e] = piece[:, e]
+            return blk
+        w = torch.zeros(heads, 3, 48, C_, dtype=wstream.dtype)
+        tab = torch.zeros(heads, 16, 3, 48)
+        wo = torch.zeros(heads, C_, 48, dtype=wstream.dtype)
+        for h in range(heads):
+            A, B = S[2 * h], S[2 * h + 1]
+            for s_ in range(ks):
+                for b in range(6):
+                    w[h, b // 3, 16 * (b % 3): 16 * (b % 3) + 16, 32 * s_: 32 * s_ + 32] = block(A[6 * s_ + b])
+                for b in range(3):
+                    w[h, 2, 16 * b: 16 * b + 16, 32 * s_: 32 * s_ + 32] = block(B[3 * s_ + b])
+            ta = A[a_tab: a_tab + 6].reshape(-1).view(torch.float32).reshape(16, 96)
+            tab[h, :, 0], tab[h, :, 1] = ta[:, :48], ta[:, 48:]
+            tab[h, :, 2] = B[b_tab: b_tab + 3].reshape(-1).view(torch.float32).reshape(48, 16).t()
+            for t in range(2):
+                for j in range(nb):
+                    blk = block(B[b_wo + t * nb + j])                                # columns = k-slots 8 g + e of k-step t
+                    for k in range(32):
+                        g_, e = k // 8, k % 8
+                        if t == 0:
+                            f = 4 * g_ + e if e < 4 else 16 + 4 * g_ + e - 4
+                        else:
+                            f = 32 + 4 * g_ + e if e < 4 else None
+                        if f is None:
+                            assert not blk[:, k].float().any(), "unused k-slots of the Wo' fragments must be zero"
+                        else:
+                            wo[h, 16 * j: 16 * j + 16, f] = blk[:, k]
+        return w, tab, wo
+
+    def temporal_block(self, x, out, *, w_qkv, colsum, bias, pe_bias, w_out, b_out, clips, frames, pixels, heads, d, scale, eps=1e-5,
+                       wstream=None):
         """out = x + Attn_F(LayerNorm(x) + pe) Wo^T + bo from the per-head operands of engine/weights.py::pack_temporal_block
         (LayerNorm folded: rstd (x W'^T - mean colsum) + bias); q|k|v, the probabilities and the attention output are rounded to
-        the storage dtype where the kernel stores them"""
+        the storage dtype where the kernel stores them.  With `wstream` (the register-resident kernel's packed weights) the
+        operands are taken from the stream and the projections see the normalised tokens (x - mean) rstd rounded to the storage
+        dtype, as that kernel computes them"""
         acc_t, T = self.acc, x.dtype
         Cc = heads * d
         X = _flat(x)[: clips * frames * pixels * Cc].reshape(clips, frames, pixels, Cc).to(acc_t)
+        if wstream is not None:
+            key = ("tblock", wstream.data_ptr(), Cc, heads, d)
+            cache = self.__dict__.setdefault("_ff_cache", {})
+            if key not in cache:
+                cache[key] = (wstream, self._tblock_unpack(wstream, Cc, heads, d))      # (holds the stream: see ff_block)
+            w, tab, wo = cache[key][1]
+            Xf = X.float()
+            xn = ((Xf - Xf.mean(-1, keepdim=True)) * (Xf.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()).to(T).to(acc_t)
+            qkv = torch.einsum("bfpc,hsnc->bfphsn", xn, w.to(acc_t)) + tab.to(acc_t).permute(1, 0, 2, 3)[None, :, None]   # b f p h 3 48
+            qkv = qkv.to(T).to(acc_t)
+            q, k, v = qkv[..., 0, :d], qkv[..., 1, :d], qkv[..., 2, :d]
+            S = torch.einsum("bfphd,bgphd->bphfg", q, k) * scale
+            P = S.softmax(dim=-1).to(T).to(acc_t)
+            O = torch.einsum("bphfg,bgphd->bfphd", P, v).to(T).to(acc_t)
+            y = X + torch.einsum("bfphk,hnk->bfpn", O, wo.to(acc_t)[:, :, :d]) + b_out.to(acc_t)
+            _flat(out)[: y.numel()].reshape(y.shape).copy_(y.to(out.dtype))
+            return
         mean = X.mean(-1, keepdim=True)
         rstd = (X.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
         a = torch.einsum("bfpc,hnc->bfphn", X, w_qkv.to(acc_t))

@@ -132,6 +132,37 @@ def test_ff_block_stream_round_trip():
         assert torch.equal(Wp, ff.po_w[:, :C]) and torch.equal(W1, ff.w1) and torch.equal(W2, ff.po_w[:, C:]) and torch.equal(bi, ff.b1)
 
 
+@pytest.mark.parametrize("with_pe", [True, False])
+def test_temporal_block_stream_round_trip(with_pe):
+    """weights.pack_temporal_stream against the unpacker written from include/fyc.h's layout description, and the two
+    specifications of the sub-block (per-head operands with the LayerNorm folded / packed stream with normalised tokens)
+    against each other"""
+    from followyourclick_amd.engine.weights import Packed, pack_temporal_block, temporal_block_layout
+    T, H, d, F, P, clips = torch.bfloat16, 8, 40, 16, 3, 2
+    C = H * d
+    g = lambda shape, seed, scale=1.0: torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale     # noqa: E731
+    att = Packed(qkv_f=((g((3 * C, C), 1) * C ** -0.5).to(T), g((3 * C,), 2, 0.1), None), pe_w=g((24, 3 * C), 3, 0.5) if with_pe else None,
+                 o_w=(g((C, C), 4) * C ** -0.5).to(T), o_b=g((C,), 5, 0.1))
+    att["qkv_f"] = (att.qkv_f[0], att.qkv_f[1], att.qkv_f[0].float().sum(dim=1))
+    ops = pack_temporal_block(att, H, F)
+    lay = temporal_block_layout(C)
+    assert (lay["a_pieces"], lay["b_pieces"], lay["stride"]) == (66, 73, 73) and ops["wstream"].numel() == 2 * H * 73 * 512
+    w, tab, wo = EmuOps._tblock_unpack(ops["wstream"], C, H, d)
+    for i in range(3):
+        assert torch.equal(w[:, i, :d], ops["w_qkv"][:, i * d:(i + 1) * d]) and not w[:, i, d:].float().any()
+        ref = ops["bias"][:, None, i * d:(i + 1) * d] + (ops["pe_bias"].permute(1, 0, 2)[:, :, i * d:(i + 1) * d] if with_pe else 0.0)
+        assert torch.equal(tab[:, :, i, :d], ref.expand(H, F, d)) and not tab[:, :, i, d:].any()
+    assert torch.equal(wo, ops["w_out"])
+    x = (g((clips * F * P, C), 6) * 1.5 + 0.3).to(T)
+    kw = dict(clips=clips, frames=F, pixels=P, heads=H, d=d, scale=d ** -0.5)
+    emu = EmuOps(acc=torch.float64)
+    o_a, o_b = torch.zeros_like(x), torch.zeros_like(x)
+    emu.temporal_block(x, o_a, **ops, **kw)
+    emu.temporal_block(x, o_b, **{k: v for k, v in ops.items() if k != "wstream"}, **kw)
+    rel = ((o_a.double() - o_b.double()).norm() / o_b.double().norm()).item()
+    assert rel < 4e-3, rel
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
 def test_unet_forward_with_fused_temporal_blocks(golden_dir, dtype, tol, monkeypatch):
     """FYC_FUSE_TEMPORAL: every temporal attention sub-block goes through `temporal_block` with the per-head operands of

@@ -316,19 +316,31 @@ def test_temporal_attention(hip, emu, dt, clips, F, P, H, d):
     close(o_h, o_e, f"tattn {dt} F{F} P{P} d{d}", 6e-3 if dt == "bf16" else 2e-5)
 
 
-@pytest.mark.parametrize("with_pe", [True, False])
-@pytest.mark.parametrize("clips,P", [(2, 64), (1, 8), (3, 4096)])
-def test_temporal_block_fused(hip, emu, clips, P, with_pe):
-    """fyc_temporal_block (row statistics + LayerNorm-folded QKV + attention over frames + output projection + residual in
-    one kernel) against the torch specification on the per-head operands of engine/weights.py::pack_temporal_block"""
+def _temporal_operands(with_pe, seed=0):
     from followyourclick_amd.engine.weights import Packed, pack_temporal_block
     T, H, d, F = torch.bfloat16, 8, 40, 16
     C = H * d
-    att = Packed(qkv_f=((rnd((3 * C, C), torch.float32, 1) * C ** -0.5).to(T), rnd((3 * C,), torch.float32, 2) * 0.1, None),
-                 pe_w=rnd((24, 3 * C), torch.float32, 3) * 0.5 if with_pe else None,
-                 o_w=(rnd((C, C), torch.float32, 4) * C ** -0.5).to(T), o_b=rnd((C,), torch.float32, 5) * 0.1)
+    att = Packed(qkv_f=((rnd((3 * C, C), torch.float32, seed + 1) * C ** -0.5).to(T), rnd((3 * C,), torch.float32, seed + 2) * 0.1, None),
+                 pe_w=rnd((24, 3 * C), torch.float32, seed + 3) * 0.5 if with_pe else None,
+                 o_w=(rnd((C, C), torch.float32, seed + 4) * C ** -0.5).to(T), o_b=rnd((C,), torch.float32, seed + 5) * 0.1)
     att["qkv_f"] = (att.qkv_f[0], att.qkv_f[1], att.qkv_f[0].float().sum(dim=1))
-    ops_e = pack_temporal_block(att, H, F)
+    return pack_temporal_block(att, H, F)
+
+
+@pytest.mark.parametrize("rr", [True, False])
+@pytest.mark.parametrize("with_pe", [True, False])
+@pytest.mark.parametrize("clips,P", [(2, 64), (1, 8), (3, 4096)])
+def test_temporal_block_fused(hip, emu, clips, P, with_pe, rr):
+    """fyc_temporal_block (row statistics + LayerNorm-folded QKV + attention over frames + output projection + residual in
+    one kernel) against the torch specification on the per-head operands of engine/weights.py::pack_temporal_block;
+    rr: the register-resident kernel on the packed weight stream (csrc/temporal_block_rr.hip) against the specification
+    computed from the UNPACKED stream"""
+    T, H, d, F = torch.bfloat16, 8, 40, 16
+    C = H * d
+    ops_e = _temporal_operands(with_pe)
+    assert "wstream" in ops_e
+    if not rr:
+        del ops_e["wstream"]
     ops_h = {k: (v.cuda() if v is not None else None) for k, v in ops_e.items()}
     x = (rnd((clips * F * P, C), torch.float32, 6) * 1.5 + 0.3).to(T)
     kw = dict(clips=clips, frames=F, pixels=P, heads=H, d=d, scale=d ** -0.5)
@@ -508,6 +520,29 @@ def test_ff_block_is_repeatable(hip, rows):
         d = (out.view(torch.int16) != out0.view(torch.int16)).any(dim=1).sum().item()
         assert d == 0, f"launch {it}: {d} of {rows} rows differ from launch 0"
         assert torch.equal(parts, parts0), f"launch {it}: statistics differ from launch 0"
+
+
+def test_temporal_block_is_repeatable(hip):
+    """same for the register-resident temporal sub-block (asm-issued LDS-DMA, lane-swap reductions)"""
+    T, H, d, F, clips, P = torch.bfloat16, 8, 40, 16, 2, 4096
+    C = H * d
+    ops_h = {k: (v.cuda() if v is not None else None) for k, v in _temporal_operands(True, seed=20).items()}
+    x = (rnd((clips * F * P, C), torch.float32, 26) * 1.5 + 0.3).to(T).cuda()
+    kw = dict(clips=clips, frames=F, pixels=P, heads=H, d=d, scale=d ** -0.5)
+    junk = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+    out0 = None
+    for it in range(16):
+        if it % 3 == 1:
+            junk.fill_(it)
+        out = torch.full((clips * F * P, C), float("nan"), dtype=T, device="cuda")
+        hip.temporal_block(x, out, **ops_h, **kw)
+        torch.cuda.synchronize()
+        if out0 is None:
+            out0 = out
+            assert torch.isfinite(out.float()).all()
+            continue
+        dd = (out.view(torch.int16) != out0.view(torch.int16)).any(dim=1).sum().item()
+        assert dd == 0, f"launch {it}: {dd} rows differ from launch 0"
 
 
 @pytest.mark.parametrize("C,gn", [(320, True), (320, False), (640, True)])
