@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-2 measurement set (run on the GPU box: gpurun -- 'bash tools/collect_profiles.sh').  Writes under gpurun_out/; the
+# Round-3 measurement set (run on the GPU box: gpurun -- 'bash tools/collect_profiles.sh').  Writes under gpurun_out/; the
 # summaries are then copied to profiles/ (see profiles/README.md).  PMC passes are separate runs (no trace domains beside them).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/r03
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 3 --warmup 1 > $O/bench_final.json 2> $O/bench_final.err
+python $R/bench.py --steps 5 --warmup 2 --vae > $O/bench_final.json 2> $O/bench_final.err
 python $R/bench.py --steps 3 --warmup 1 --graph --no-cpu-baseline --no-roofline > $O/bench_graph.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $O/ktrace -o kt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python $R/tools/rocprof_summary.py $(find $O/ktrace -name "*.db" | head -1) $O/kernel_stats.txt

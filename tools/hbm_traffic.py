@@ -23,7 +23,7 @@ def lib_digest() -> str:
     with open(LIB, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()
 
-FAMILIES = (("fyc_gemm_kernel", "gemm"), ("fyc_attn_kernel", "attention"), ("temporal_block", "temporal_block"), ("ff_block", "ff_block"), ("tattn", "attn_temporal"), ("gn_stats", "gn_stats"),
+FAMILIES = (("fyc_gemm_kernel", "gemm"), ("fyc_attn_kernel", "attention"), ("temporal_block", "temporal_block"), ("tblock_rr", "temporal_block"), ("ff_block", "ff_block"), ("panel_linear", "panel_linear"), ("tattn", "attn_temporal"), ("gn_stats", "gn_stats"),
             ("chan_stats_reduce", "gn_stats"), ("gn_apply", "gn_apply"), ("layernorm", "row_stats"), ("concat", "concat"),
             ("splitk_finish", "gemm_splitk_finish"))
 
