@@ -233,21 +233,27 @@ def main():
         launches = sum(v["launches"] for v in mm.values())
         ach = fl / (ms * 1e-3) / 1e12
         # HBM bytes per launch from PMC counters (collected offline with rocprofv3 --pmc, tools/collect_profiles.sh): reported only
-        # when the profile was taken on THIS library binary (sha256 stamped by tools/hbm_traffic.py), otherwise null
+        # when the profile was taken on THIS library binary or on a build of the same sources + flags (digests stamped by
+        # tools/hbm_traffic.py; hipcc output is not bit-stable across output paths), otherwise null
         traffic, traffic_note = None, "no PMC profile of this library binary under profiles/ (tools/collect_profiles.sh regenerates it)"
         if args.frames == 16 and args.size == 512 and args.dtype == "bf16":
             import glob
             import hashlib
             from followyourclick_amd import _lib as L_
+            from followyourclick_amd._build import source_digest
             with open(L_.LIB_PATH, "rb") as f:
                 digest = hashlib.sha256(f.read()).hexdigest()
+            # the loaded library is a build of the sources in the tree unless FYC_LIB_PATH points elsewhere (A/B builds)
+            src_digest = source_digest() if not os.environ.get("FYC_LIB_PATH") else None
             for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
                 try:
                     doc = json.load(open(tpath))
-                    if doc.get("lib_sha256") == digest:
+                    same_binary = doc.get("lib_sha256") == digest
+                    if same_binary or (src_digest and doc.get("source_sha256") == src_digest):
                         traffic = round(doc["families"]["gemm"]["hbm_bytes_per_launch"])
+                        ident = f"this library binary (sha256 {digest[:12]})" if same_binary else f"a build of these same kernel sources and flags (source digest {src_digest[:12]})"
                         traffic_note = (f"avg HBM bytes per fyc_gemm_kernel launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE on "
-                                        f"this library binary (sha256 {digest[:12]}), {os.path.relpath(tpath, ROOT)}")
+                                        f"{ident}, {os.path.relpath(tpath, ROOT)}")
                         break
                 except Exception:
                     continue

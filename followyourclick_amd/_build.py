@@ -47,6 +47,23 @@ def _digest(path: str) -> str:
     return h.hexdigest()
 
 
+def source_digest() -> str:
+    """sha256 over everything the kernels are compiled from (all csrc sources and headers, include/fyc.h, the compiler flags per
+    source): the reproducible identity of the library.  hipcc's output is not bit-stable across output paths, so profiles taken
+    on one build (tools/hbm_traffic.py) are matched to another build of the same sources through this, not through the .so"""
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(HERE, "..", "include", "fyc.h"), "rb") as fh:
+        h.update(fh.read())
+    for src in SOURCES:
+        h.update((src + " " + " ".join(_flags(src))).encode())
+    return h.hexdigest()
+
+
 def _compile(src: str) -> str:
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))

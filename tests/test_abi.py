@@ -79,3 +79,16 @@ def test_argument_validation_without_gpu(lib):
     assert rc != 0 and b"fyc" in lib.fyc_last_error()
     assert lib.fyc_init(None) != 0
     assert lib.fyc_set_tuning(99, 1) != 0
+
+
+def test_source_digest_identifies_the_kernel_sources():
+    """bench.py matches PMC traffic profiles to the running library through this digest (and the binary's sha256)"""
+    import json
+    import os
+    import re
+    from followyourclick_amd._build import source_digest
+    d = source_digest()
+    assert re.fullmatch(r"[0-9a-f]{64}", d) and d == source_digest()
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    stamped = [json.load(open(os.path.join(prof, f))).get("source_sha256") for f in sorted(os.listdir(prof)) if f.endswith("_hbm_traffic.json")]
+    assert any(stamped), "no traffic profile carries a source digest"

@@ -1,5 +1,6 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) into per-kernel-family HBM bytes per
-launch -> profiles/rNN_hbm_traffic.json, which bench.py reports as roofline.traffic when its `lib_sha256` is the library being benched.
+launch -> profiles/rNN_hbm_traffic.json, which bench.py reports as roofline.traffic when its `lib_sha256` is the library being benched or its
+`source_sha256` is the digest of the sources that library was built from (followyourclick_amd/_build.py::source_digest).
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT/pmc_fetch -o f -- python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline --no-roofline
@@ -57,7 +58,9 @@ def main(fetch_dir, write_dir, out_path):
         n = max(nf, nw, 1)
         fams[fam] = {"launches": n, "fetch_bytes_per_launch": 2.0 * sf / max(nf, 1), "write_bytes_per_launch": sw / max(nw, 1),
                      "hbm_bytes_per_launch": 2.0 * sf / max(nf, 1) + sw / max(nw, 1)}
-    doc = {"lib_sha256": lib_digest(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 2 DDIM steps of bench.py cfg2 (weights packing and the "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from followyourclick_amd._build import source_digest
+    doc = {"lib_sha256": lib_digest(), "source_sha256": source_digest(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 2 DDIM steps of bench.py cfg2 (weights packing and the "
                      "one-off context projections included in 'other'/'gemm' launch counts); FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 "
                      "correction; WRITE_SIZE uncalibrated", "families": fams}
     with open(out_path, "w") as f:
