@@ -76,6 +76,20 @@ __device__ __forceinline__ void dma16(const char* gbase, unsigned voff, unsigned
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
 }
+// Four consecutive pieces (4 KiB of the stream -> 4 KiB of the ring) by one wave: ONE M0 write, the instruction's immediate
+// offset moves the global and the LDS address together.  A wave alone on its SIMD issues one instruction per ~4 cycles, so
+// beside a 16-cycle MFMA only three other instructions are free; piece by piece the DMA cost 8 issue slots per KiB (M0 save /
+// set / restore, wait state, 64-bit address add, the load) = a quarter of a stage's issue budget (PMC: 49 % of the wave's
+// cycles issuing at 3.7 non-MFMA instructions per MFMA, profiles/r03_rr_kernels_pmc.txt); this form costs 1.75.
+// (M0 is not preserved: nothing else in these kernels uses it - hipcc treats it as reserved.)
+__device__ __forceinline__ void dma16x4(const char* gbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:3072"
+               :: "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void dma16v(const void* gsrc, unsigned lds_dst) {                        // per-lane source address
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -194,6 +208,15 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   // Issued in a burst behind the barrier the 15 pieces of a wave cost it ~1500 cycles with the matrix pipe idle
   // (profiles/r03_ff_block_ablation.txt: 118 -> 95 us per tile without them); beside MFMAs they are nearly free.
   // (16 pieces per wave, no branch in the instruction stream: the 16th of waves 1-3 wraps around and fetches pieces 0-2 again.)
+  // n-th group of four pieces of this wave of stage tnext: group wave + 4 n, n < 4 (16 groups; the last one, wave 3's fourth,
+  // holds the single piece 60)
+  auto dma_group = [&](int tnext, int n) {
+    const int grp = wave + 4 * n;
+    const char* src = p.ws + (long long)tnext * STAGE_BYTES + grp * (4 * PIECE);
+    const unsigned dst = lds0 + (tnext & 1) * STAGE_BYTES + grp * (4 * PIECE);
+    if (grp * 4 + 4 <= NPIECE) dma16x4(src, lane16, dst);
+    else dma16(src, lane16, dst);
+  };
   auto dma_piece = [&](int tnext, int n) {
     int q = wave + 4 * n;
     q = q >= NPIECE ? q - NPIECE : q;
@@ -211,7 +234,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       const bf16x8 wf = frag(sl, u);
 #pragma unroll
       for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, xa[i][2 * t + sk], oacc[i][j]);
+#ifdef FF_DMA_PIECEWISE
       if (u < 16) dma_piece(t + 1, u);
+#else
+      if (u % 8 == 0 && u < 32) dma_group(t + 1, u / 8);
+#endif
     }
   }
 
@@ -297,7 +324,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 2; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
+#ifdef FF_DMA_PIECEWISE
       if (s < 8) { dma_piece(tnext, 2 * s); dma_piece(tnext, 2 * s + 1); }        // all 16 pieces in the first 8 k-steps: a piece needs ~1 us to land
+#else
+      if (s < 8 && !(s & 1)) dma_group(tnext, s >> 1);                              // all 16 pieces in the first 8 k-steps: a piece needs ~1 us to land
+#endif
       if constexpr (WITH_GATE) {
         if (s < 8 && (s & 1)) gate_unit(s >> 1, bi, hr, hbw);
       }
