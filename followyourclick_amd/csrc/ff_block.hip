@@ -35,7 +35,7 @@
 
 namespace {
 
-constexpr int C_ = 320, HID = 1280, ROWS = 128, NT = 256;
+constexpr int C_ = 320, HID = 1280, ROWS = 128;
 constexpr int KS = C_ / 32;                    // 10 MFMA k-steps over C
 constexpr int NB = C_ / 16;                    // 20 column blocks of the output
 constexpr int CHUNKS = HID / 32;               // 40 hidden chunks of 32 units
@@ -49,7 +49,7 @@ constexpr int STAGE_BYTES = NPIECE * PIECE;    // 62464
 // met in two banks, 8-way (the same defect cost csrc/temporal_block_rr.hip a fifth of its tile time: profiles/r03_temporal_block_rr_phases.txt)
 constexpr int TP = C_ * 2 + 32;
 constexpr int TILE_BYTES = ROWS * TP;          // 86016 = 84 pieces
-constexpr int SCR_BYTES = 6 * 40 * 16 * 4;       // statistics partials of the epilogue: [row slice][column group][8 sums | 8 sums of squares]
+constexpr int SCR_BYTES = 12 * 40 * 16 * 4;      // statistics partials of the epilogue: [row slice (6 or 12)][column group][8 sums | 8 sums of squares]
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 static_assert(TILE_BYTES % PIECE == 0 && TILE_BYTES <= STAGE_BYTES + P_CONST * PIECE, "the residual tile lands while the last stage still reads its constants / W2' pieces");
 static_assert(TILE_BYTES + SCR_BYTES <= LDS_BYTES, "epilogue tile + statistics scratch overlay the ring");
@@ -118,8 +118,15 @@ __device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *rein
 
 // VAR: 0 = the compiler's own interleave inside each pinned pair of k-steps (default: 3 % faster on MI355X, profiles/r03_ff_block_probe.txt);
 // 1 = the pair laid out with sched_group_barrier as MFMA, 3 VALU, MFMA, ... (fyc_set_tuning key 8 = 1)
-template <int VAR>
-__global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
+// RI: 16-row blocks per wave.  2 = four waves, one per SIMD with the whole 512-register file (32 rows per wave, every weight
+// fragment feeds two MFMAs);  1 = eight waves, TWO per SIMD at 256 registers (16 rows per wave, a fragment feeds one MFMA: twice the
+// LDS reads, but a second wave to issue while the first one waits - the lone wave of RI = 2 spends half its cycles stalled,
+// profiles/r03_rr_kernels_pmc.txt).  fyc_set_tuning key 8 = 2 selects it.
+template <int VAR, int RI>
+__global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
+  constexpr int NW = 8 / RI, NT = 64 * NW, RW = 16 * RI;     // waves, threads, rows per wave
+  constexpr int NSL = NT / 40;                                 // row slices of the copy-out pass (6 or 12)
+  static_assert(VAR == 0 || RI == 2, "the sched_group_barrier layout is written for 32 rows per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     const char* src = p.ws + (long long)t * STAGE_BYTES;     // wave-uniform base + one 32-bit lane offset: no per-piece address registers
     const unsigned dst = lds0 + (t & 1) * STAGE_BYTES;
 #pragma unroll 1
-    for (int q = wave; q < np; q += 4) {
+    for (int q = wave; q < np; q += NW) {
       int q2 = q + rot;                                         // the blocks of an XCD run in step and want the same bytes: spread them over
       if (q2 >= np) q2 -= np;                                   // the L2 channels instead of all asking for the same 1 KiB at once
       dma16(src + q2 * PIECE, lane16, dst + q2 * PIECE);
@@ -148,11 +155,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   };
 
   // ---- the wave's 32 token rows as MFMA operands: lane (row r16, quad g) holds x[row][32 s + 8 g .. +8] ---------------------
-  bf16x8 xa[2][KS];
+  bf16x8 xa[RI][KS];
   auto load_x = [&](int tile) {
-    const bf16_t* xr = p.x + ((long long)tile * ROWS + wave * 32 + r16) * C_ + g * 8;
+    const bf16_t* xr = p.x + ((long long)tile * ROWS + wave * RW + r16) * C_ + g * 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
       for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const bf16x8*>(xr + i * 16 * C_ + s * 32);
   };
@@ -160,9 +167,9 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   issue(0);
 
   // LayerNorm statistics of the lane's two rows (two-pass, in registers; the four quads of a row meet through xor 16 / 32)
-  float mu[2], rs[2];
+  float mu[RI], rs[RI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < RI; ++i) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
@@ -198,9 +205,9 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     rs[i] = rsqrtf(q * (1.0f / C_) + p.eps);
   }
 
-  f32x4 oacc[2][NB];                                          // out rows 16 i + r16, columns 16 j + 4 g .. +4
+  f32x4 oacc[RI][NB];                                         // out rows 16 i + r16, columns 16 j + 4 g .. +4
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) oacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -210,8 +217,8 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   // (16 pieces per wave, no branch in the instruction stream: the 16th of waves 1-3 wraps around and fetches pieces 0-2 again.)
   // n-th group of four pieces of this wave of stage tnext: group wave + 4 n, n < 4 (16 groups; the last one, wave 3's fourth,
   // holds the single piece 60)
-  auto dma_group = [&](int tnext, int n) {
-    const int grp = wave + 4 * n;
+  auto dma_group = [&](int tnext, int n) {                    // n < 16 / NW
+    const int grp = wave + NW * n;
     const char* src = p.ws + (long long)tnext * STAGE_BYTES + grp * (4 * PIECE);
     const unsigned dst = lds0 + (tnext & 1) * STAGE_BYTES + grp * (4 * PIECE);
     if (grp * 4 + 4 <= NPIECE) dma16x4(src, lane16, dst);
@@ -233,11 +240,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       const int sk = u / NB, j = u % NB;
       const bf16x8 wf = frag(sl, u);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, xa[i][2 * t + sk], oacc[i][j]);
+      for (int i = 0; i < RI; ++i) oacc[i][j] = mfma(wf, xa[i][2 * t + sk], oacc[i][j]);
 #ifdef FF_DMA_PIECEWISE
       if (u < 16) dma_piece(t + 1, u);
 #else
-      if (u % 8 == 0 && u < 32) dma_group(t + 1, u / 8);
+      if (u % 8 == 0 && u < 8 * (16 / NW)) dma_group(t + 1, u / 8);
 #endif
     }
   }
@@ -246,7 +253,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   // (x - mean) rstd rounded to bf16 (what the reference's autocast feeds its Linear), so that no LayerNorm term is left in the
   // per-chunk gate (gamma is folded into W1, beta into b1: engine/weights.py::fold_layernorm)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   // gate unit u = (row block i, half h) of the pre-activations hr -> two packed bf16 pairs of the FF2 operand (two independent
   // polynomial chains: their dependent v_pk_fma steps fill each other's wait states): k-slots 8 g + e = hidden unit 4 g + e of
   // half 0 (e < 4), of half 1 (e >= 4)
-  auto gate_unit = [&](int u, const f32x4 (&bi)[4], const f32x4 (&hr)[2][4], u32x4 (&hbw)[2]) {
+  auto gate_unit = [&](int u, const f32x4 (&bi)[4], const f32x4 (&hr)[RI][4], u32x4 (&hbw)[RI]) {
     const int i = u >> 1, h = u & 1;
     const f32x4 v = hr[i][2 * h] + bi[2 * h], gt = hr[i][2 * h + 1] + bi[2 * h + 1];
     const f32x2 lo = geglu_pair((f32x2){v[0], v[1]}, (f32x2){gt[0], gt[1]}), hi = geglu_pair((f32x2){v[2], v[3]}, (f32x2){gt[2], gt[3]});
@@ -278,9 +285,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bi[q] = *reinterpret_cast<const f32x4*>(cst + q * 16 + g * 4);
   };
-  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[2], int tnext, auto with_dma) {
+  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[RI], int tnext, auto with_dma) {
     constexpr bool WITH_DMA = decltype(with_dma)::value;
-    const bf16x8 hb[2] = {__builtin_bit_cast(bf16x8, hbw[0]), __builtin_bit_cast(bf16x8, hbw[1])};
+    bf16x8 hb[RI];
+#pragma unroll
+    for (int i = 0; i < RI; ++i) hb[i] = __builtin_bit_cast(bf16x8, hbw[i]);
     bf16x8 w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = frag(sl, P_W2 + q);
@@ -292,7 +301,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) oacc[i][jb * 4 + q] = mfma(w[q], hb[i], oacc[i][jb * 4 + q]);
+        for (int i = 0; i < RI; ++i) oacc[i][jb * 4 + q] = mfma(w[q], hb[i], oacc[i][jb * 4 + q]);
       if constexpr (WITH_DMA) dma_piece(tnext, KS + jb);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -302,14 +311,14 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   };
   // WITH_GATE: false for chunk 0 (nothing to gate yet).  The scheduler is pinned per pair of k-steps (sched_barrier): 8 fragment
   // reads one k-step ahead of their MFMAs, 16 MFMAs, one gate unit; VAR 1 additionally lays the pair out as MFMA, 3 VALU, MFMA, ...
-  auto stage = [&](const char* base, f32x4 (&hw)[2][4], const f32x4 (&hr)[2][4], auto with_gate, int tnext) {
+  auto stage = [&](const char* base, f32x4 (&hw)[RI][4], const f32x4 (&hr)[RI][4], auto with_gate, int tnext) {
     constexpr bool WITH_GATE = decltype(with_gate)::value;
     const char* sl = base + lane16;
     f32x4 bi[4];
-    u32x4 hbw[2];
+    u32x4 hbw[RI];
     if constexpr (WITH_GATE) load_consts(base, bi);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) hw[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 w[4];
@@ -323,14 +332,14 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
+        for (int i = 0; i < RI; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
 #ifdef FF_DMA_PIECEWISE
       if (s < 8) { dma_piece(tnext, 2 * s); dma_piece(tnext, 2 * s + 1); }        // all 16 pieces in the first 8 k-steps: a piece needs ~1 us to land
 #else
-      if (s < 8 && !(s & 1)) dma_group(tnext, s >> 1);                              // all 16 pieces in the first 8 k-steps: a piece needs ~1 us to land
+      if (s < 8 && !(s & 1) && (s >> 1) < 16 / NW) dma_group(tnext, s >> 1);        // all pieces in the first k-steps: a piece needs ~1 us to land
 #endif
       if constexpr (WITH_GATE) {
-        if (s < 8 && (s & 1)) gate_unit(s >> 1, bi, hr, hbw);
+        if (s < 4 * RI && (s & 1)) gate_unit(s >> 1, bi, hr, hbw);
       }
       if ((s & 1) || !WITH_GATE) {
         if constexpr (WITH_GATE && VAR == 1) {                // masks: 0x2 VALU, 0x8 MFMA, 0x100 DS read
@@ -354,7 +363,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     if constexpr (WITH_GATE) ff2(sl, hbw, tnext, std::false_type{});
   };
 
-  f32x4 h0[2][4], h1[2][4];
+  f32x4 h0[RI][4], h1[RI][4];
   dma_landed_barrier();                                            // stage 5 (chunk 0) landed
   if (work) stage(smem + (PROJ_ST & 1) * STAGE_BYTES, h0, h1, std::false_type{}, PROJ_ST + 1);
   else issue(PROJ_ST + 1);
@@ -374,7 +383,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   if (p.res != nullptr) {                                     // residual tile over the idle part of the ring: the LDS image is linear, every
     const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);      // lane fetches the 16 B that belong at its place
 #pragma unroll 1
-    for (int q = wave; q < TILE_BYTES / PIECE; q += 4) {
+    for (int q = wave; q < TILE_BYTES / PIECE; q += NW) {
       const int off = q * PIECE + (int)lane16, row = off / TP;
       const int col = min(off - row * TP, C_ * 2 - 16);         // (the 32 pad bytes of a row re-fetch its last chunk)
       dma16v(src + row * (C_ * 2) + col, lds0 + q * PIECE);
@@ -383,10 +392,10 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   if (work) {
     const char* base = smem + ((NSTAGE - 1) & 1) * STAGE_BYTES;
     f32x4 bi[4];
-    u32x4 hbw[2];
+    u32x4 hbw[RI];
     load_consts(base, bi);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) gate_unit(u, bi, h1, hbw);
+    for (int u = 0; u < 2 * RI; ++u) gate_unit(u, bi, h1, hbw);
     ff2(base + lane16, hbw, 0, std::false_type{});
   }
 
@@ -394,10 +403,10 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   dma_landed_barrier();                                            // residual tile landed; every wave is done with the ring
   const float* bias_out = p.b_out;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      bf16_t* a = reinterpret_cast<bf16_t*>(smem + (wave * 32 + i * 16 + r16) * TP) + j * 16 + g * 4;
+      bf16_t* a = reinterpret_cast<bf16_t*>(smem + (wave * RW + i * 16 + r16) * TP) + j * 16 + g * 4;
       const f32x4 bo = *reinterpret_cast<const f32x4*>(bias_out + j * 16 + g * 4);
       float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
       if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
@@ -413,11 +422,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     float cs8[8], cq8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
-    if (rsl < 6) {
+    if (rsl < NSL) {
       char* dst = reinterpret_cast<char*>(p.out + row0 * C_) + cg * 16;
       const char* src = smem + cg * 16;
 #pragma unroll 2
-      for (int row = rsl; row < ROWS; row += 6) {
+      for (int row = rsl; row < ROWS; row += NSL) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * TP);
         *reinterpret_cast<u32x4*>(dst + row * (C_ * 2)) = v;
         if (p.parts != nullptr) {
@@ -432,7 +441,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     }
     if (p.parts != nullptr) {                                 // wave-uniform: every thread takes the barriers
       float* scr = reinterpret_cast<float*>(smem + TILE_BYTES);
-      if (rsl < 6) {
+      if (rsl < NSL) {
         float* d = scr + (rsl * 40 + cg) * 16;
         *reinterpret_cast<f32x4*>(d) = (f32x4){cs8[0], cs8[1], cs8[2], cs8[3]};
         *reinterpret_cast<f32x4*>(d + 4) = (f32x4){cs8[4], cs8[5], cs8[6], cs8[7]};
@@ -444,7 +453,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
         const int c2 = tid >> 2, e2 = (tid & 3) * 2;
         float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
-        for (int sl6 = 0; sl6 < 6; ++sl6) {
+        for (int sl6 = 0; sl6 < NSL; ++sl6) {
           const float* d = scr + (sl6 * 40 + c2) * 16;
           s0 += d[e2]; s1 += d[e2 + 1]; q0 += d[8 + e2]; q1 += d[8 + e2 + 1];
         }
@@ -499,15 +508,17 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) FYC_FAIL(-3, "fyc_ff_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
       if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
     }
   }
   const unsigned grid = (unsigned)p.ntiles;
-  if (g_fyc_tuning[8] != 1) hipLaunchKernelGGL(ff_block_kernel<0>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(ff_block_kernel<1>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  if (g_fyc_tuning[8] == 2) hipLaunchKernelGGL((ff_block_kernel<0, 1>), dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+  else if (g_fyc_tuning[8] == 1) hipLaunchKernelGGL((ff_block_kernel<1, 2>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((ff_block_kernel<0, 2>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_ff_block");
   return 0;
 }

@@ -58,7 +58,7 @@ def main():
 
         res = {}
         for rnd in range(3):                    # interleaved rounds: variants see the same clocks
-            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0), ("ff_block sched_group layout", fused, 1, 0),
+            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0), ("ff_block sched_group layout", fused, 1, 0), ("ff_block 8 waves x 16 rows", fused, 2, 0),
                                       ("ABLATION no MFMA work (weight DMA only)", fused, 0, 4)):
                 if key is not None:
                     h.set_tuning(8, key)
