@@ -39,31 +39,38 @@ constexpr int C_ = 320, HID = 1280, ROWS = 128;
 constexpr int KS = C_ / 32;                    // 10 MFMA k-steps over C
 constexpr int NB = C_ / 16;                    // 20 column blocks of the output
 constexpr int CHUNKS = HID / 32;               // 40 hidden chunks of 32 units
-constexpr int PROJ_ST = KS / 2;                // 5 projection stages of 2 k-steps
-constexpr int NSTAGE = PROJ_ST + CHUNKS + 1;   // 46
 constexpr int PIECE = 1024;                    // one MFMA fragment for all 64 lanes
-constexpr int P_CONST = 40, P_W2 = 41, NPIECE = 61, NPIECE_PROJ = 40;
-constexpr int STAGE_BYTES = NPIECE * PIECE;    // 62464
+// The weight stream is cut into HALF-STAGES of HP = 32 pieces (32 KiB) that go through a 4-deep LDS ring: the pieces of half
+// h + 2 are requested while half h computes, i.e. a whole stage-time before they are needed.  (The first version had 46 stages
+// of 61 pieces in a 2-deep ring: the refill of a slot could only start when its previous stage was done, one stage before its
+// use, and a 61-KiB refill alone takes 1.4 us of the 2.1 us a stage took - profiles/r03_ff_block_ablation.txt, DMA-only run.)
+//   half t < 10           k-step t of the projection: pieces j < 20 = Wp rows 16 j .. +16, columns 32 t .. +32
+//   half 10 + 2 c  ("A")  pieces 4 s + q (s < 7): W1 rows 64 c + 16 q .. +16, columns 32 s .. +32; piece 28: f32 bias[64] of chunk c - 1
+//   half 11 + 2 c  ("B")  pieces 4 (s - 7) + q (s = 7, 8, 9): the rest of W1 of chunk c; pieces 12 + j (j < 20): W2' of chunk c - 1
+//   halves 90, 91         piece 28 / pieces 12 + j of the same for chunk 39
+constexpr int HP = 32, HALF_BYTES = HP * PIECE, NSLOT = 4;
+constexpr int SA = 7;                          // FF1 k-steps in half A
+constexpr int P_BIAS = 4 * SA, P_W2 = 4 * (KS - SA);
+constexpr int NHALF = KS + 2 * CHUNKS + 2;     // 92
 // the residual / output tile of the epilogue (overlays the ring).  Row pitch 672 B: consecutive rows are 168 dwords = 40 (mod 64
 // banks) apart, so the 16 rows x 4 quads x 8 B of one in-place add spread over all banks; at the natural 640 B (32 mod 64) they
 // met in two banks, 8-way (the same defect cost csrc/temporal_block_rr.hip a fifth of its tile time: profiles/r03_temporal_block_rr_phases.txt)
 constexpr int TP = C_ * 2 + 32;
 constexpr int TILE_BYTES = ROWS * TP;          // 86016 = 84 pieces
 constexpr int SCR_BYTES = 12 * 40 * 16 * 4;      // statistics partials of the epilogue: [row slice (6 or 12)][column group][8 sums | 8 sums of squares]
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-static_assert(TILE_BYTES % PIECE == 0 && TILE_BYTES <= STAGE_BYTES + P_CONST * PIECE, "the residual tile lands while the last stage still reads its constants / W2' pieces");
+constexpr int LDS_BYTES = NSLOT * HALF_BYTES;  // 131072
+static_assert(TILE_BYTES % PIECE == 0 && TILE_BYTES <= ((NHALF - 2) % NSLOT) * HALF_BYTES + P_BIAS * PIECE && (NHALF - 1) % NSLOT == 3,
+              "the residual tile lands while the last two halves (slots 2 and 3) still hold the bias and W2' pieces of chunk 39");
 static_assert(TILE_BYTES + SCR_BYTES <= LDS_BYTES, "epilogue tile + statistics scratch overlay the ring");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 struct FFP {
   const bf16_t* x; const bf16_t* res; bf16_t* out;
-  const char* ws;            // packed weight stream, NSTAGE * STAGE_BYTES
+  const char* ws;            // packed weight stream, NHALF * HALF_BYTES
   const float* b_out;        // [C]
   float* parts;              // [rows / 128][C][2] or null
   int ntiles;                // rows / 128
   float eps;
-  int tune;                  // fyc_set_tuning key 9 (measurement only): 1 = every block walks the pieces of a burst-issued stage from its own
-                             // start, 4 = no MFMA / gate work in the chunk stages (DMA + barriers only; wrong results)
 };
 
 // 1 KiB global -> LDS by DMA, issued from inline asm: wave-uniform 64-bit base + one 32-bit lane offset, destination = wave-uniform
@@ -116,22 +123,24 @@ __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __bu
 
 __device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
 
-// VAR: 0 = the compiler's own interleave inside each pinned pair of k-steps (default: 3 % faster on MI355X, profiles/r03_ff_block_probe.txt);
-// 1 = the pair laid out with sched_group_barrier as MFMA, 3 VALU, MFMA, ... (fyc_set_tuning key 8 = 1)
 // RI: 16-row blocks per wave.  2 = four waves, one per SIMD with the whole 512-register file (32 rows per wave, every weight
 // fragment feeds two MFMAs);  1 = eight waves, TWO per SIMD at 256 registers (16 rows per wave, a fragment feeds one MFMA: twice the
-// LDS reads, but a second wave to issue while the first one waits - the lone wave of RI = 2 spends half its cycles stalled,
-// profiles/r03_rr_kernels_pmc.txt).  fyc_set_tuning key 8 = 2 selects it.
-template <int VAR, int RI>
+// LDS reads, but a second wave to issue while the first one waits).  fyc_set_tuning key 8 = 2 selects RI = 1.
+#ifdef FF_TIMING                                                // phase timestamps of wave 0 of every workgroup (tools/ff_probe.py prints them)
+__device__ unsigned long long g_ff_time[1024 * 16];
+#define FF_MARK(k) do { if (tid == 0) g_ff_time[(blockIdx.x & 1023) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FF_MARK(k) do {} while (0)
+#endif
+
+template <int RI>
 __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
   constexpr int NW = 8 / RI, NT = 64 * NW, RW = 16 * RI;     // waves, threads, rows per wave
   constexpr int NSL = NT / 40;                                 // row slices of the copy-out pass (6 or 12)
-  static_assert(VAR == 0 || RI == 2, "the sched_group_barrier layout is written for 32 rows per wave");
+  constexpr int GPW = HP / 4 / NW;                             // groups of four pieces per wave and half (2 or 1)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rot = (p.tune & 1) ? (int)(((blockIdx.x >> 3) * 5u) % NPIECE_PROJ) : 0;
-  const bool work = !(p.tune & 4);
 
   // One row tile per workgroup.  (A persistent loop over tiles was tried - with and without requesting the next tile's tokens
   // during the last stage: inside an outer loop the register allocator spilled 85-95 registers of this 496-register kernel.)
@@ -142,16 +151,18 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
   const int g = lane >> 4, r16 = lane & 15;
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the dynamic region
-  auto issue = [&](int t) {                                   // DMA of stage t into slot t & 1: piece q by wave q % 4
-    const int np = t < PROJ_ST ? NPIECE_PROJ : NPIECE;
-    const char* src = p.ws + (long long)t * STAGE_BYTES;     // wave-uniform base + one 32-bit lane offset: no per-piece address registers
-    const unsigned dst = lds0 + (t & 1) * STAGE_BYTES;
-#pragma unroll 1
-    for (int q = wave; q < np; q += NW) {
-      int q2 = q + rot;                                         // the blocks of an XCD run in step and want the same bytes: spread them over
-      if (q2 >= np) q2 -= np;                                   // the L2 channels instead of all asking for the same 1 KiB at once
-      dma16(src + q2 * PIECE, lane16, dst + q2 * PIECE);
-    }
+  // n-th group of four pieces of this wave of half h (n < GPW): group wave + NW n; every wave issues exactly 4 GPW loads per
+  // half, so "everything but the newest half has landed" is the constant s_waitcnt vmcnt(4 GPW)
+  auto dma_group = [&](int h, int n) {
+#ifdef FF_NO_DMA
+    if (h >= 2) return;                                       // ablation build (tools/ff_probe.py): no weight stream, wrong results
+#endif
+    const int grp = wave + NW * n;
+    dma16x4(p.ws + (long long)h * HALF_BYTES + grp * (4 * PIECE), lane16, lds0 + (h & (NSLOT - 1)) * HALF_BYTES + grp * (4 * PIECE));
+  };
+  auto half_landed_barrier = [&]() {                          // the oldest outstanding half of this wave has landed, then the workgroup meets
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * GPW) : "memory");
+    __syncthreads();
   };
 
   // ---- the wave's 32 token rows as MFMA operands: lane (row r16, quad g) holds x[row][32 s + 8 g .. +8] ---------------------
@@ -163,8 +174,12 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const bf16x8*>(xr + i * 16 * C_ + s * 32);
   };
+  FF_MARK(0);
   load_x(tile);
-  issue(0);
+#pragma unroll
+  for (int n = 0; n < GPW; ++n) dma_group(0, n);
+#pragma unroll
+  for (int n = 0; n < GPW; ++n) dma_group(1, n);
 
   // LayerNorm statistics of the lane's two rows (two-pass, in registers; the four quads of a row meet through xor 16 / 32)
   float mu[RI], rs[RI];
@@ -211,44 +226,22 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) oacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // one piece of the NEXT stage's DMA, dealt out between the MFMA groups of this stage: n-th piece of this wave (piece wave + 4 n).
-  // Issued in a burst behind the barrier the 15 pieces of a wave cost it ~1500 cycles with the matrix pipe idle
-  // (profiles/r03_ff_block_ablation.txt: 118 -> 95 us per tile without them); beside MFMAs they are nearly free.
-  // (16 pieces per wave, no branch in the instruction stream: the 16th of waves 1-3 wraps around and fetches pieces 0-2 again.)
-  // n-th group of four pieces of this wave of stage tnext: group wave + 4 n, n < 4 (16 groups; the last one, wave 3's fourth,
-  // holds the single piece 60)
-  auto dma_group = [&](int tnext, int n) {                    // n < 16 / NW
-    const int grp = wave + NW * n;
-    const char* src = p.ws + (long long)tnext * STAGE_BYTES + grp * (4 * PIECE);
-    const unsigned dst = lds0 + (tnext & 1) * STAGE_BYTES + grp * (4 * PIECE);
-    if (grp * 4 + 4 <= NPIECE) dma16x4(src, lane16, dst);
-    else dma16(src, lane16, dst);
-  };
-  auto dma_piece = [&](int tnext, int n) {
-    int q = wave + 4 * n;
-    q = q >= NPIECE ? q - NPIECE : q;
-    dma16(p.ws + (long long)tnext * STAGE_BYTES + q * PIECE, lane16, lds0 + (tnext & 1) * STAGE_BYTES + q * PIECE);
-  };
-
-  // ---- projection: out = tok Wp^T, stage t = k-steps 2t, 2t + 1 of all 20 column blocks ---------------------------------------
+  FF_MARK(1);
+  // ---- projection: out = tok Wp^T, half t = k-step t of all 20 column blocks ----------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < PROJ_ST; ++t) {
-    dma_landed_barrier();                                     // stage t landed; slot (t+1)&1 is free: its refill is dealt out below
-    const char* sl = smem + (t & 1) * STAGE_BYTES + lane16;
+  for (int t = 0; t < KS; ++t) {
+    half_landed_barrier();                                    // half t landed; slot (t + 2) & 3 is free (half t - 2 is done): refill it
+    const char* sl = smem + (t & (NSLOT - 1)) * HALF_BYTES + lane16;
 #pragma unroll
-    for (int u = 0; u < 2 * NB; ++u) {
-      const int sk = u / NB, j = u % NB;
-      const bf16x8 wf = frag(sl, u);
+    for (int j = 0; j < NB; ++j) {
+      const bf16x8 wf = frag(sl, j);
 #pragma unroll
-      for (int i = 0; i < RI; ++i) oacc[i][j] = mfma(wf, xa[i][2 * t + sk], oacc[i][j]);
-#ifdef FF_DMA_PIECEWISE
-      if (u < 16) dma_piece(t + 1, u);
-#else
-      if (u % 8 == 0 && u < 8 * (16 / NW)) dma_group(t + 1, u / 8);
-#endif
+      for (int i = 0; i < RI; ++i) oacc[i][j] = mfma(wf, xa[i][t], oacc[i][j]);
+      if (j % 8 == 0 && j / 8 < GPW) dma_group(t + 2, j / 8);
     }
   }
 
+  FF_MARK(2);
   // The tokens were needed raw for the projection; from here on they are only the FF1 operand: normalise them in place,
   // (x - mean) rstd rounded to bf16 (what the reference's autocast feeds its Linear), so that no LayerNorm term is left in the
   // per-chunk gate (gamma is folded into W1, beta into b1: engine/weights.py::fold_layernorm)
@@ -264,29 +257,60 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
     }
 
   // ---- hidden chunks -----------------------------------------------------------------------------------------------------------
-  // Stage of chunk c:  FF1(c) -> hw (80 MFMAs)  ||  GEGLU gate of chunk c - 1 from hr (VALU) -> hb;  then FF2(c - 1) with hb (40 MFMAs).
-  // The gate of a chunk runs one stage after its FF1 so that its ~250 VALU instructions have independent matrix work beside
-  // them: a wave alone on its SIMD overlaps VALU with the matrix pipe only where the two alternate in program order, so the
-  // gate is cut into 8 units (row block, half, value pair) and one unit follows the MFMAs of each of the first 8 k-steps.
+  // Chunk c:  half A = FF1(c) k-steps 0..6 -> hw (28 RI MFMAs)  ||  GEGLU gate of chunk c - 1 from hr (VALU) -> hb;
+  //           half B = FF1(c) k-steps 7..9 (12 RI)  then  FF2(c - 1) with hb (20 RI MFMAs).
+  // The gate of a chunk runs one chunk after its FF1 so that its ~250 VALU instructions have independent matrix work beside
+  // them: a wave overlaps VALU with the matrix pipe only where the two alternate in program order, so the gate is cut into
+  // units (row block, half) and one unit follows the MFMAs of a k-step.
   // gate unit u = (row block i, half h) of the pre-activations hr -> two packed bf16 pairs of the FF2 operand (two independent
   // polynomial chains: their dependent v_pk_fma steps fill each other's wait states): k-slots 8 g + e = hidden unit 4 g + e of
   // half 0 (e < 4), of half 1 (e >= 4)
   auto gate_unit = [&](int u, const f32x4 (&bi)[4], const f32x4 (&hr)[RI][4], u32x4 (&hbw)[RI]) {
     const int i = u >> 1, h = u & 1;
+#ifdef FF_GATE_PACKED
     const f32x4 v = hr[i][2 * h] + bi[2 * h], gt = hr[i][2 * h + 1] + bi[2 * h + 1];
     const f32x2 lo = geglu_pair((f32x2){v[0], v[1]}, (f32x2){gt[0], gt[1]}), hi = geglu_pair((f32x2){v[2], v[3]}, (f32x2){gt[2], gt[3]});
     unsigned p0 = pack_bf16x2(lo.x, lo.y), p1 = pack_bf16x2(hi.x, hi.y);
+#else
+    // four independent SCALAR chains: beside MFMAs a packed f32 VALU instruction costs a lone wave ~22 cycles more than the two
+    // scalar ones it replaces (MI355X_MICROARCH.md; half A of a chunk took 2 350 cycles for 900 cycles of MFMA with the packed gate)
+    float o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = geglu_one(hr[i][2 * h][e] + bi[2 * h][e], hr[i][2 * h + 1][e] + bi[2 * h + 1][e]);
+    unsigned p0 = pack_bf16x2(o4[0], o4[1]), p1 = pack_bf16x2(o4[2], o4[3]);
+#endif
     asm volatile("" : "+v"(p0), "+v"(p1));                    // the unit's result is "used" here: LLVM's sinking passes would otherwise move the whole
     hbw[i][2 * h] = p0;                                       // unit down to FF2, its only real consumer, behind all the MFMAs it is meant to sit beside
     hbw[i][2 * h + 1] = p1;
   };
   auto load_consts = [&](const char* base, f32x4 (&bi)[4]) {  // bias (beta folded in) of the PREVIOUS chunk's 64 W1 rows
-    const float* cst = reinterpret_cast<const float*>(base + P_CONST * PIECE);
+    const float* cst = reinterpret_cast<const float*>(base + P_BIAS * PIECE);
 #pragma unroll
     for (int q = 0; q < 4; ++q) bi[q] = *reinterpret_cast<const f32x4*>(cst + q * 16 + g * 4);
   };
-  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[RI], int tnext, auto with_dma) {
-    constexpr bool WITH_DMA = decltype(with_dma)::value;
+  // FF1 k-steps [S0, S1) of the chunk whose pieces start at `first` in the half at sl; the next k-step's fragments in flight;
+  // `after(s)` runs behind the MFMAs of k-step s (DMA groups of half hnext, gate units)
+  auto ff1_steps = [&](const char* sl, auto s0_, auto s1_, f32x4 (&hw)[RI][4], auto after) {
+    constexpr int S0 = decltype(s0_)::value, S1 = decltype(s1_)::value;
+    bf16x8 w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = frag(sl, q);
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+      bf16x8 n[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n[q] = (s + 1 < S1) ? frag(sl, (s + 1 - S0) * 4 + q) : w[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < RI; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
+      after(s);
+      if (((s - S0) & 1) || s + 1 == S1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = n[q];
+    }
+  };
+  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[RI]) {
     bf16x8 hb[RI];
 #pragma unroll
     for (int i = 0; i < RI; ++i) hb[i] = __builtin_bit_cast(bf16x8, hbw[i]);
@@ -302,105 +326,87 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < RI; ++i) oacc[i][jb * 4 + q] = mfma(w[q], hb[i], oacc[i][jb * 4 + q]);
-      if constexpr (WITH_DMA) dma_piece(tnext, KS + jb);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) w[q] = n[q];
     }
-    if constexpr (WITH_DMA) dma_piece(tnext, KS + NB / 4);
   };
-  // WITH_GATE: false for chunk 0 (nothing to gate yet).  The scheduler is pinned per pair of k-steps (sched_barrier): 8 fragment
-  // reads one k-step ahead of their MFMAs, 16 MFMAs, one gate unit; VAR 1 additionally lays the pair out as MFMA, 3 VALU, MFMA, ...
-  auto stage = [&](const char* base, f32x4 (&hw)[RI][4], const f32x4 (&hr)[RI][4], auto with_gate, int tnext) {
+  using I0 = std::integral_constant<int, 0>;
+  using IA = std::integral_constant<int, SA>;
+  using IK = std::integral_constant<int, KS>;
+  // one chunk = halves ha (A) and ha + 1 (B): FF1 -> hw; with_gate: gate + FF2 of the previous chunk from hr
+  auto chunk = [&](int ha, f32x4 (&hw)[RI][4], const f32x4 (&hr)[RI][4], auto with_gate) {
     constexpr bool WITH_GATE = decltype(with_gate)::value;
-    const char* sl = base + lane16;
-    f32x4 bi[4];
     u32x4 hbw[RI];
-    if constexpr (WITH_GATE) load_consts(base, bi);
+    if (ha == KS + 40) FF_MARK(4);
+    half_landed_barrier();                                    // half A landed; slot (ha + 2) & 3 free
+    if (ha == KS + 40) FF_MARK(5);
+    {
+      const char* base = smem + (ha & (NSLOT - 1)) * HALF_BYTES;
+      f32x4 bi[4];
+      if constexpr (WITH_GATE) load_consts(base, bi);
 #pragma unroll
-    for (int i = 0; i < RI; ++i)
+      for (int i = 0; i < RI; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hw[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = frag(sl, q);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      bf16x8 n[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) n[q] = (s + 1 < KS) ? frag(sl, (s + 1) * 4 + q) : w[q];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < RI; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
-#ifdef FF_DMA_PIECEWISE
-      if (s < 8) { dma_piece(tnext, 2 * s); dma_piece(tnext, 2 * s + 1); }        // all 16 pieces in the first 8 k-steps: a piece needs ~1 us to land
-#else
-      if (s < 8 && !(s & 1) && (s >> 1) < 16 / NW) dma_group(tnext, s >> 1);        // all pieces in the first k-steps: a piece needs ~1 us to land
-#endif
-      if constexpr (WITH_GATE) {
-        if (s < 4 * RI && (s & 1)) gate_unit(s >> 1, bi, hr, hbw);
-      }
-      if ((s & 1) || !WITH_GATE) {
-        if constexpr (WITH_GATE && VAR == 1) {                // masks: 0x2 VALU, 0x8 MFMA, 0x100 DS read
-          if (s < 8) {
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-              __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-              }
-            }
-          }
+        for (int q = 0; q < 4; ++q) hw[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ff1_steps(base + lane16, I0{}, IA{}, hw, [&](int s) {
+        if (!(s & 1) && (s >> 1) < GPW) dma_group(ha + 2, s >> 1);                 // the refill goes out in the first k-steps
+        if constexpr (WITH_GATE) {                               // 2 RI gate units: behind k-steps 1, 3, 5, 6
+          const int u = s == SA - 1 ? 3 : (s & 1) ? (s >> 1) : -1;
+          if (u >= 0 && u < 2 * RI) gate_unit(u, bi, hr, hbw);
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = n[q];
+      });
     }
-    if constexpr (WITH_GATE) ff2(sl, hbw, tnext, std::false_type{});
+    if (ha == KS + 40) FF_MARK(6);
+    half_landed_barrier();                                    // half B landed
+    if (ha == KS + 40) FF_MARK(7);
+    {
+      const char* base = smem + ((ha + 1) & (NSLOT - 1)) * HALF_BYTES;
+      ff1_steps(base + lane16, IA{}, IK{}, hw, [&](int s) {
+        if ((s - SA) < GPW) dma_group(ha + 3, s - SA);
+      });
+      if (ha == KS + 40) FF_MARK(8);
+      if constexpr (WITH_GATE) ff2(base + lane16, hbw);
+      if (ha == KS + 40) FF_MARK(9);
+    }
   };
 
   f32x4 h0[RI][4], h1[RI][4];
-  dma_landed_barrier();                                            // stage 5 (chunk 0) landed
-  if (work) stage(smem + (PROJ_ST & 1) * STAGE_BYTES, h0, h1, std::false_type{}, PROJ_ST + 1);
-  else issue(PROJ_ST + 1);
+  FF_MARK(3);
+  chunk(KS, h0, h1, std::false_type{});
   for (int c = 1; c + 1 < CHUNKS; c += 2) {                  // chunks (1, 2), (3, 4), ..., (37, 38): pre-activation buffers alternate
-    const int t = PROJ_ST + c;
-    dma_landed_barrier();                                          // stage t landed; slot (t+1)&1 free: its refill is dealt out inside the stage
-    if (work) stage(smem + (t & 1) * STAGE_BYTES, h1, h0, std::true_type{}, t + 1);
-    else issue(t + 1);
-    dma_landed_barrier();
-    if (work) stage(smem + ((t + 1) & 1) * STAGE_BYTES, h0, h1, std::true_type{}, t + 2);
-    else issue(t + 2);
+    chunk(KS + 2 * c, h1, h0, std::true_type{});
+    chunk(KS + 2 * c + 2, h0, h1, std::true_type{});
   }
-  dma_landed_barrier();                                            // chunk 39
-  if (work) stage(smem + ((NSTAGE - 2) & 1) * STAGE_BYTES, h1, h0, std::true_type{}, NSTAGE - 1);
-  else issue(NSTAGE - 1);
-  dma_landed_barrier();                                            // last stage: gate + FF2 of chunk 39 only (reads pieces 40.. of its slot)
-  if (p.res != nullptr) {                                     // residual tile over the idle part of the ring: the LDS image is linear, every
-    const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);      // lane fetches the 16 B that belong at its place
-#pragma unroll 1
-    for (int q = wave; q < TILE_BYTES / PIECE; q += NW) {
-      const int off = q * PIECE + (int)lane16, row = off / TP;
-      const int col = min(off - row * TP, C_ * 2 - 16);         // (the 32 pad bytes of a row re-fetch its last chunk)
-      dma16v(src + row * (C_ * 2) + col, lds0 + q * PIECE);
-    }
-  }
-  if (work) {
-    const char* base = smem + ((NSTAGE - 1) & 1) * STAGE_BYTES;
-    f32x4 bi[4];
+  FF_MARK(10);
+  chunk(NHALF - 4, h1, h0, std::true_type{});                 // chunk 39: its refills are halves 90, 91 (bias / W2' of chunk 39 only)
+  {
     u32x4 hbw[RI];
-    load_consts(base, bi);
+    half_landed_barrier();                                    // half 90 landed (half 91 may still be in flight)
+    {
+      const char* base = smem + ((NHALF - 2) & (NSLOT - 1)) * HALF_BYTES;
+      f32x4 bi[4];
+      load_consts(base, bi);
 #pragma unroll
-    for (int u = 0; u < 2 * RI; ++u) gate_unit(u, bi, h1, hbw);
-    ff2(base + lane16, hbw, 0, std::false_type{});
+      for (int u = 0; u < 2 * RI; ++u) gate_unit(u, bi, h1, hbw);
+    }
+    dma_landed_barrier();                                     // half 91 landed; every wave is done with slots 0 .. 2 below the bias piece
+    if (p.res != nullptr) {                                   // residual tile over the idle part of the ring: the LDS image is linear, every
+      const char* src = reinterpret_cast<const char*>(p.res + row0 * C_);    // lane fetches the 16 B that belong at its place
+#pragma unroll 1
+      for (int q = wave; q < TILE_BYTES / PIECE; q += NW) {
+        const int off = q * PIECE + (int)lane16, row = off / TP;
+        const int col = min(off - row * TP, C_ * 2 - 16);       // (the 32 pad bytes of a row re-fetch its last chunk)
+        dma16v(src + row * (C_ * 2) + col, lds0 + q * PIECE);
+      }
+    }
+    ff2(smem + ((NHALF - 1) & (NSLOT - 1)) * HALF_BYTES + lane16, hbw);
   }
+  FF_MARK(11);
 
   // ---- epilogue -------------------------------------------------------------------------------------------------------------------
   dma_landed_barrier();                                            // residual tile landed; every wave is done with the ring
+  FF_MARK(12);
   const float* bias_out = p.b_out;
 #pragma unroll
   for (int i = 0; i < RI; ++i)
@@ -461,6 +467,7 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
       }
     }
   }
+  FF_MARK(13);
   }
 }
 
@@ -479,7 +486,13 @@ static void device_limits(int64_t& lds_cap, int64_t& n_cu) {
   n_cu = cus;
 }
 
-extern "C" int64_t fyc_ff_block_wstream_bytes(void) { return (int64_t)NSTAGE * STAGE_BYTES; }
+#ifdef FF_TIMING
+extern "C" int fyc_ff_timing(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ff_time), sizeof(unsigned long long) * n);
+}
+#endif
+
+extern "C" int64_t fyc_ff_block_wstream_bytes(void) { return (int64_t)NHALF * HALF_BYTES; }
 
 extern "C" int fyc_ff_block_supported(const fyc_ff_block_args* a) {
   if (a == nullptr || a->dtype != FYC_BF16 || a->C != C_ || a->hidden != HID || a->rows <= 0 || a->rows % ROWS != 0) return 0;
@@ -499,7 +512,7 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
               ((uintptr_t)a->residual % 16) == 0 && ((uintptr_t)a->chan_parts % 16) == 0, "fyc_ff_block: operands must be 16-byte aligned");
   FFP p;
   p.x = (const bf16_t*)a->x; p.res = (const bf16_t*)a->residual; p.out = (bf16_t*)a->out; p.ws = (const char*)a->wstream;
-  p.b_out = a->b_out; p.parts = a->chan_parts; p.eps = a->eps; p.tune = g_fyc_tuning[9]; p.ntiles = a->rows / ROWS;
+  p.b_out = a->b_out; p.parts = a->chan_parts; p.eps = a->eps; p.ntiles = a->rows / ROWS;
   {  // dynamic LDS above 64 KB needs the function attribute once per device; one process may drive several GPUs from several threads
     constexpr int kMaxDev = 64;
     static std::mutex mu;
@@ -508,17 +521,15 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) FYC_FAIL(-3, "fyc_ff_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
       if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
     }
   }
   const unsigned grid = (unsigned)p.ntiles;
-  if (g_fyc_tuning[8] == 2) hipLaunchKernelGGL((ff_block_kernel<0, 1>), dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
-  else if (g_fyc_tuning[8] == 1) hipLaunchKernelGGL((ff_block_kernel<1, 2>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((ff_block_kernel<0, 2>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  if (g_fyc_tuning[8] == 2) hipLaunchKernelGGL(ff_block_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ff_block_kernel<2>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_ff_block");
   return 0;
 }

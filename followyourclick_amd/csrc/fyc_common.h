@@ -142,6 +142,21 @@ __device__ __forceinline__ float gelu_erf_f(float g) {
 // clamp; max |error| of x * Phi(x) over all x: 9e-5, 20x below half a bf16 ulp at unit scale) - no v_rcp / v_exp, which are
 // quarter rate: 80 gates per lane and tile were ~5 us of the ~24 us a 256 x 320 tile of the K = 320 FF1 layer takes.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// the same gate on one value with scalar VALU (for kernels that run one wave per SIMD, where packed f32 beside MFMAs is slow)
+__device__ __forceinline__ float geglu_one(float h, float g) {
+  const float xc = __builtin_amdgcn_fmed3f(g, -4.2f, 4.2f);
+  const float u = xc * xc;
+  float r = -1.803605736e-09f;
+  r = __builtin_fmaf(r, u, 1.588336848e-07f);
+  r = __builtin_fmaf(r, u, -6.076054488e-06f);
+  r = __builtin_fmaf(r, u, 1.337840930e-04f);
+  r = __builtin_fmaf(r, u, -1.901335453e-03f);
+  r = __builtin_fmaf(r, u, 1.859653848e-02f);
+  r = __builtin_fmaf(r, u, -1.310565435e-01f);
+  r = __builtin_fmaf(r, u, 7.969318188e-01f);
+  const float phi = __builtin_fmaf(xc * r, 0.5f, 0.5f);       // Phi(g)
+  return h * (g * phi);
+}
 __device__ __forceinline__ f32x2 geglu_pair(f32x2 h, f32x2 g) {
   const f32x2 xc = {__builtin_amdgcn_fmed3f(g.x, -4.2f, 4.2f), __builtin_amdgcn_fmed3f(g.y, -4.2f, 4.2f)};
   const f32x2 u = xc * xc;

@@ -273,11 +273,12 @@ def pack_temporal_stream(w_qkv: Tensor, bias: Tensor, pe_bias: Optional[Tensor],
 
 
 def ff_block_layout(C: int, hidden: int):
-    """(stages, pieces per stage, projection stages, index of the constants piece) of the fyc_ff_block weight stream;
-    (46, 61, 5, 40) at the one shape csrc/ff_block.hip is built for (C = 320, hidden = 1280)"""
+    """(half-stages, pieces per half-stage, FF1 k-steps in half A) of the fyc_ff_block weight stream (include/fyc.h);
+    (92, 32, 7) at the one shape csrc/ff_block.hip is built for (C = 320, hidden = 1280)"""
     nb, ks, chunks = C // 16, C // 32, hidden // 32
-    pst = (ks + 1) // 2
-    return pst + chunks + 1, max(2 * nb, 4 * ks + 1 + nb), pst, 4 * ks
+    sa = (7 * ks + 9) // 10                                      # FF1 k-steps whose W1 pieces sit in half A (the rest, and W2', in half B)
+    hp = max(nb, 4 * sa + 1, 4 * (ks - sa) + nb)
+    return ks + 2 * chunks + 2, (hp + 3) // 4 * 4, sa
 
 
 def _mfma_fragments(w: Tensor) -> Tensor:
@@ -289,35 +290,36 @@ def _mfma_fragments(w: Tensor) -> Tensor:
 
 def pack_ff_block(ff: Packed) -> Tensor:
     """weight stream of fyc_ff_block (csrc/ff_block.hip) from a packed feed-forward (`_ff`) whose LayerNorm is folded into FF1:
-    stages x pieces x 512 elements (layout: include/fyc.h; 46 x 61 x 1 KiB at C = 320).  The first stages hold the projection of
-    the token half of the merged [Wp | Wp W2] weight (two k-steps each); stage pst + c: W1 rows of hidden chunk c, and of chunk
-    c - 1 the bias (f32) and the W2' columns in the k-slot order the kernel's GEGLU outputs have (slot 8 g + e = unit
-    4 g + e of the chunk's first 16 hidden units for e < 4, of its second 16 for e >= 4)."""
+    half-stages x pieces x 512 elements (layout: include/fyc.h; 92 x 32 x 1 KiB at C = 320).  Half t < ks: k-step t of the
+    projection of the token half of the merged [Wp | Wp W2] weight.  Chunk c of 32 hidden units: half ks + 2c ("A") = the W1
+    pieces of k-steps 0..sa-1 and the f32 bias of chunk c - 1; half ks + 2c + 1 ("B") = the remaining W1 pieces and the W2'
+    columns of chunk c - 1 in the k-slot order the kernel's GEGLU outputs have (slot 8 g + e = unit 4 g + e of the chunk's first
+    16 hidden units for e < 4, of its second 16 for e >= 4); the last two halves hold bias / W2' of the last chunk."""
     w1, b1, po = ff.w1, ff.b1, ff.po_w
     assert ff.cs1 is not None, "fyc_ff_block needs the LayerNorm folded into FF1"
     C = w1.shape[1]
     hid = w1.shape[0] // 2
     assert C % 32 == 0 and hid % 32 == 0 and tuple(po.shape) == (C, C + hid) and w1.dtype == po.dtype
     nb, ks, chunks = C // 16, C // 32, hid // 32
-    nst, npc, pst, pc = ff_block_layout(C, hid)
-    st = torch.zeros(nst, npc, 512, dtype=w1.dtype, device=w1.device)
-    # projection: piece s_local * nb + j of stage t = Wp[16 j .. +16][32 (2 t + s_local) .. +32]
-    wp = _mfma_fragments(po[:, :C].reshape(nb, 16, ks, 32).permute(2, 0, 1, 3))             # [s][j][512]
-    for s_ in range(ks):
-        st[s_ // 2, (s_ % 2) * nb: (s_ % 2 + 1) * nb] = wp[s_]
-    # FF1: piece s * 4 + q of stage pst + c = W1[64 c + 16 q .. +16][32 s .. +32]
-    f1 = _mfma_fragments(w1.reshape(chunks, 4, 16, ks, 32).permute(0, 3, 1, 2, 4))          # [c][s][q][512]
-    st[pst: pst + chunks, : 4 * ks] = f1.reshape(chunks, 4 * ks, 512)
-    # constants piece of stage pst + c + 1: f32 bias[64] (beta folded in) of chunk c's 64 W1 rows (bit pattern of the floats inside a
-    # bf16 stream) - the kernel gates a chunk one stage after its FF1, on LayerNorm-ed tokens: no colsum term is needed
+    nh, hp, sa = ff_block_layout(C, hid)
+    st = torch.zeros(nh, hp, 512, dtype=w1.dtype, device=w1.device)
+    # projection: piece j of half t = Wp[16 j .. +16][32 t .. +32]
+    st[:ks, :nb] = _mfma_fragments(po[:, :C].reshape(nb, 16, ks, 32).permute(2, 0, 1, 3))            # [t][j][512]
+    # FF1: W1[64 c + 16 q .. +16][32 s .. +32] = piece 4 s + q of half A (s < sa) / piece 4 (s - sa) + q of half B
+    f1 = _mfma_fragments(w1.reshape(chunks, 4, 16, ks, 32).permute(0, 3, 1, 2, 4))                  # [c][s][q][512]
+    ha = torch.arange(chunks, device=w1.device) * 2 + ks
+    st[ha, : 4 * sa] = f1[:, :sa].reshape(chunks, 4 * sa, 512)
+    st[ha + 1, : 4 * (ks - sa)] = f1[:, sa:].reshape(chunks, 4 * (ks - sa), 512)
+    # bias piece (index 4 sa) of the half A that FOLLOWS the chunk: f32 bias[64] (beta folded in) of chunk c's 64 W1 rows (bit
+    # pattern of the floats inside a bf16 stream) - the kernel gates a chunk one chunk after its FF1, on LayerNorm-ed tokens
     cst = torch.zeros(chunks, 512 * w1.element_size() // 4, dtype=torch.float32, device=w1.device)
     cst[:, :64] = b1.reshape(chunks, 64)
-    st[pst + 1: pst + 1 + chunks, pc] = cst.view(w1.dtype)
-    # FF2: pieces pc + 1 + j of stage pst + c + 1 = W2'[16 j .. +16][k-slots of chunk c]
+    st[ha + 2, 4 * sa] = cst.view(w1.dtype)
+    # FF2: pieces 4 (ks - sa) + j of the half B that follows the chunk = W2'[16 j .. +16][k-slots of chunk c]
     slot_unit = torch.tensor([(4 * (k // 8) + k % 8) if k % 8 < 4 else (16 + 4 * (k // 8) + k % 8 - 4) for k in range(32)], device=w1.device)
     w2 = po[:, C:].reshape(nb, 16, chunks, 32)[..., slot_unit]                               # [j][16][c][k-slot]
     f2 = _mfma_fragments(w2.permute(2, 0, 1, 3))                                             # [c][j][512]
-    st[pst + 1: pst + 1 + chunks, pc + 1: pc + 1 + nb] = f2
+    st[ha + 3, 4 * (ks - sa): 4 * (ks - sa) + nb] = f2
     return st.reshape(-1).contiguous()
 
 

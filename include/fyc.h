@@ -324,15 +324,17 @@ int fyc_temporal_block_supported(const fyc_temporal_block_args* a);
  *   out = residual + b_out + [x | h] [Wp | Wp W2]^T            [rows][C]        (FF2 merged with the block's output projection)
  * replaces fyc_row_stats + fyc_gemm(FYC_EPI_GEGLU, LayerNorm folded) + fyc_gemm(a2 = h) - the hidden activation never leaves
  * the CU, x is read once.  `wstream` is the pre-packed weight stream (fyc_ff_block_wstream_bytes() bytes, 16-byte aligned):
- * 46 stages x 61 pieces x 1 KiB, a piece = one MFMA operand fragment of a 16 x 32 weight block B in lane order (byte 16 l of
- * the piece = B[l & 15][8 (l >> 4) .. +8], bf16):
- *   stage t < 5      pieces s * 20 + j (s = 0, 1; j < 20): Wp rows 16 j .. +16, columns 32 (2 t + s) .. +32  (Wp = merged weight [:, :C])
- *   stage 5 + c      pieces s * 4 + q (s < 10; q < 4): rows 64 c + 16 q .. +16 of the GEGLU-packed W1 with the LayerNorm weight
- *                    folded in (W1 * gamma; fyc_pack_geglu order: 16 value rows, their 16 gate rows, ...), columns 32 s .. +32;
- *                    for c >= 1, of chunk c - 1: piece 40 = f32 bias[64] (b1 + W1 beta) of its 64 W1 rows (rest of the piece
- *                    unused), pieces 41 + j (j < 20) = rows 16 j .. +16 of W2' = merged weight [:, C:], k-slot 8 g + e =
- *                    hidden unit 32 (c - 1) + 4 g + e (e < 4) or 32 (c - 1) + 16 + 4 g + e - 4 (e >= 4)
- *   stage 45         piece 40 and pieces 41 + j: the same for hidden chunk 39.
+ * 92 half-stages x 32 pieces x 1 KiB (the kernel runs them through a 4-deep LDS ring, requesting half h + 2 while half h
+ * computes), a piece = one MFMA operand fragment of a 16 x 32 weight block B in lane order (byte 16 l of the piece =
+ * B[l & 15][8 (l >> 4) .. +8], bf16); unused pieces are zero:
+ *   half t < 10        pieces j < 20: Wp rows 16 j .. +16, columns 32 t .. +32  (Wp = merged weight [:, :C]; k-step t of the projection)
+ *   half 10 + 2 c      pieces 4 s + q (s < 7; q < 4): rows 64 c + 16 q .. +16 of the GEGLU-packed W1 of hidden chunk c (32 units) with
+ *                      the LayerNorm weight folded in (W1 * gamma; fyc_pack_geglu order: 16 value rows, their 16 gate rows, ...),
+ *                      columns 32 s .. +32; for c >= 1, piece 28 = f32 bias[64] (b1 + W1 beta) of the 64 W1 rows of chunk c - 1
+ *   half 11 + 2 c      pieces 4 (s - 7) + q (s = 7, 8, 9): the remaining W1 columns of chunk c; for c >= 1, pieces 12 + j (j < 20) =
+ *                      rows 16 j .. +16 of W2' = merged weight [:, C:], k-slot 8 g + e = hidden unit 32 (c - 1) + 4 g + e (e < 4) or
+ *                      32 (c - 1) + 16 + 4 g + e - 4 (e >= 4)
+ *   halves 90, 91      piece 28 / pieces 12 + j: the same for hidden chunk 39.
  * The kernel feeds FF1 the normalised tokens (x - mean) rstd rounded to bf16 (mean / variance over C in f32, two-pass).
  * (engine/weights.py::pack_ff_block builds it.)  chan_parts (optional): [rows / 128][C][2] f32 = per 128-row tile and channel
  * {sum, sum of squares} of the values as stored - fyc_gemm's chan_parts layout with tile_rows = 128 and one slot, for

@@ -295,9 +295,9 @@ class EmuOps:
         """inverse of the fyc_ff_block weight stream (include/fyc.h), written from the layout description: returns
         (Wp [C][C], W1 [2 hidden][C] GEGLU-packed with gamma folded in, bias [2 hidden] with beta folded in, W2' [C][hidden])"""
         nb, ks, chunks = C_ // 16, C_ // 32, hidden // 32
-        pst, pc = (ks + 1) // 2, 4 * ks
-        npc = max(2 * nb, pc + 1 + nb)
-        S = _flat(wstream).reshape(pst + chunks + 1, npc, 64, 8)                  # [stage][piece][lane][e]
+        sa = (7 * ks + 9) // 10
+        hp = (max(nb, 4 * sa + 1, 4 * (ks - sa) + nb) + 3) // 4 * 4
+        S = _flat(wstream).reshape(ks + 2 * chunks + 2, hp, 64, 8)                  # [half-stage][piece][lane][e]
         lane = torch.arange(64)
         r, gq = lane & 15, lane >> 4
 
@@ -309,17 +309,19 @@ class EmuOps:
         Wp = torch.zeros(C_, C_, dtype=wstream.dtype)
         for s_ in range(ks):
             for j in range(nb):
-                Wp[16 * j: 16 * j + 16, 32 * s_: 32 * s_ + 32] = block(S[s_ // 2, (s_ % 2) * nb + j])
+                Wp[16 * j: 16 * j + 16, 32 * s_: 32 * s_ + 32] = block(S[s_, j])
         W1 = torch.zeros(2 * hidden, C_, dtype=wstream.dtype)
         bi = torch.zeros(2 * hidden)
         W2 = torch.zeros(C_, hidden, dtype=wstream.dtype)
         for c in range(chunks):
+            ha = ks + 2 * c
             for s_ in range(ks):
                 for q in range(4):
-                    W1[64 * c + 16 * q: 64 * c + 16 * q + 16, 32 * s_: 32 * s_ + 32] = block(S[pst + c, 4 * s_ + q])
-            bi[64 * c: 64 * c + 64] = S[pst + c + 1, pc].reshape(-1).view(torch.float32)[:64]
+                    piece = S[ha, 4 * s_ + q] if s_ < sa else S[ha + 1, 4 * (s_ - sa) + q]
+                    W1[64 * c + 16 * q: 64 * c + 16 * q + 16, 32 * s_: 32 * s_ + 32] = block(piece)
+            bi[64 * c: 64 * c + 64] = S[ha + 2, 4 * sa].reshape(-1).view(torch.float32)[:64]
             for j in range(nb):
-                blk = block(S[pst + c + 1, pc + 1 + j])                          # columns = k-slots 8 g + e
+                blk = block(S[ha + 3, 4 * (ks - sa) + j])                          # columns = k-slots 8 g + e
                 for k in range(32):
                     g_, e = k // 8, k % 8
                     unit = 4 * g_ + e if e < 4 else 16 + 4 * g_ + e - 4

@@ -120,13 +120,13 @@ def test_ff_block_stream_round_trip():
     """weights.pack_ff_block against the layout description of include/fyc.h (the emulator's independent unpacker), at the
     kernel's widths and at a small one"""
     from followyourclick_amd.engine.weights import Packed, ff_block_layout, pack_ff_block
-    assert ff_block_layout(320, 1280) == (46, 61, 5, 40)
+    assert ff_block_layout(320, 1280) == (92, 32, 7)
     for C, hid, T in [(320, 1280, torch.bfloat16), (64, 256, torch.float32), (96, 384, torch.bfloat16)]:
         g = torch.Generator().manual_seed(C)
         ff = Packed(w1=torch.randn(2 * hid, C, generator=g).to(T), b1=torch.randn(2 * hid, generator=g), cs1=torch.randn(2 * hid, generator=g),
                     po_w=torch.randn(C, C + hid, generator=g).to(T), po_b=torch.randn(C, generator=g))
         st = pack_ff_block(ff)
-        nst, npc, _, _ = ff_block_layout(C, hid)
+        nst, npc, _ = ff_block_layout(C, hid)
         assert st.numel() == nst * npc * 512
         Wp, W1, bi, W2 = EmuOps._ff_unpack(st, C, hid)
         assert torch.equal(Wp, ff.po_w[:, :C]) and torch.equal(W1, ff.w1) and torch.equal(W2, ff.po_w[:, C:]) and torch.equal(bi, ff.b1)

@@ -58,8 +58,7 @@ def main():
 
         res = {}
         for rnd in range(3):                    # interleaved rounds: variants see the same clocks
-            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0), ("ff_block sched_group layout", fused, 1, 0), ("ff_block 8 waves x 16 rows", fused, 2, 0),
-                                      ("ABLATION no MFMA work (weight DMA only)", fused, 0, 4)):
+            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0), ("ff_block 8 waves x 16 rows", fused, 2, 0)):
                 if key is not None:
                     h.set_tuning(8, key)
                 h.set_tuning(9, k9)
@@ -69,7 +68,26 @@ def main():
         for name, v in res.items():
             us = min(v)
             print(f"rows={rows:7d}  {name:40s} {us:8.1f} us (min of {['%.1f' % t for t in v]})  {flops / us / 1e6:7.0f} TFLOP/s", flush=True)
+    return h, ws, ff
 
 
 if __name__ == "__main__":
-    main()
+    h, ws, ff = main()
+
+if hasattr(h.lib, "fyc_ff_timing"):                           # FF_TIMING build: phase timestamps (shader clock) of wave 0 of every workgroup
+    import ctypes
+    import numpy as np
+    nb, rows = 1, 131072
+    x, r, o = (torch.randn(rows, C, device=DEV).to(T) for _ in range(3))
+    h.ff_block(x, r, o, wstream=ws, b_out=ff.po_b, rows=rows, C_=C, hidden=HID); torch.cuda.synchronize()
+    n = 1024 * 16
+    buf = (ctypes.c_ulonglong * n)()
+    assert h.lib.fyc_ff_timing(buf, n) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16).astype(np.int64)
+    names = ["start", "x requested, halves 0/1 requested, LN statistics", "projection done (10 halves)", "tokens normalised", "chunk 20: before barrier A", "after barrier A",
+             "half A done (FF1 k 0-6 + gate of chunk 19)", "after barrier B", "FF1 k 7-9 done", "FF2 of chunk 19 done", "before chunk 39", "last FF2 done", "residual landed", "end"]
+    for sel, lab in ((slice(0, 256), "workgroups 0..255"), (slice(512, 768), "workgroups 512..767")):
+        d = t[sel]
+        print(lab)
+        for k in range(1, 14):
+            print(f"   {names[k]:52s} +{np.median(d[:, k] - d[:, 0]):9.0f} cycles   (step {np.median(d[:, k] - d[:, k - 1]):7.0f})")
