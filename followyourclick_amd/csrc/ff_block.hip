@@ -2,7 +2,7 @@
 // 819-821 GEGLU; called from animatediff/models/attention.py:489-564 BasicTransformerBlock and motion_module.py:270-283
 // TemporalTransformerBlock), merged with the output projection that follows it as engine/weights.py::_ff does:
 //
-//   h   = GEGLU( LN(tok) W1^T + b1 )                       [rows][4C]       (LayerNorm folded: rstd (tok W1'^T - mean colsum) + b1')
+//   h   = GEGLU( LN(tok) W1^T + b1 )                       [rows][4C]
 //   out = residual + b_out + [tok | h] [Wp | Wp W2]^T      [rows][C]
 //
 // The unfused schedule (fyc_row_stats, fyc_gemm GEGLU, fyc_gemm dual-K) writes and re-reads the 4C-wide hidden tensor (335 MB
@@ -13,21 +13,25 @@
 //     columns.  Its 32 x C tokens live in registers as MFMA operands for the whole kernel (80 VGPRs): they are the operand of
 //     the projection phase and of all 40 FF1 chunks and the source of the LayerNorm statistics - no statistics pass, no LDS
 //     traffic for the activation side.  The 32 x C output accumulators (160) sit in the accumulator half of the file;
-//   * the weights arrive as one pre-packed stream (engine/weights.py::pack_ff_block): 46 stages of <= 61 KiB, every 1-KiB piece
-//     already in MFMA fragment order (lane l holds W[16 j + (l & 15)][32 s + 8 (l >> 4) .. +8]), so a stage is ONE contiguous
-//     global -> LDS DMA (global_load_lds, 16 B / lane, lane-linear image = conflict-free ds_read_b128 at base + lane * 16) into a
-//     2-deep ring: stages 0-4 = the tok Wp^T projection (2 k-steps each), stage 5 + c = {W1 rows of hidden chunk c (32 units =
-//     2 x (16 value + 16 gate) rows), their colsum / bias, the W2' columns of chunk c - 1};
-//   * per chunk a wave runs 80 MFMAs of FF1 (K = C from registers), the GEGLU gate on its 32 x 32 results - which ARE the MFMA
-//     operand of FF2 as they stand (the k-slots of the W2' fragments are packed in the order the gate outputs sit in the lanes:
-//     no shuffle, no LDS round trip) - and 40 MFMAs of FF2 for the PREVIOUS chunk, so that the gate's VALU work has independent
-//     matrix work beside it.  One barrier per stage;
+//   * the matrix instruction is v_mfma_f32_32x32x16_bf16 (32 cycles), used as D^T = W x^T: a wave that is alone on its SIMD pays
+//     for every other instruction BETWEEN two matrix instructions (tools/exp/mfma_fill_bench.hip: ~8 cycles per instruction
+//     beside 16-cycle MFMAs, ~3 beside 32-cycle ones; the first version of this kernel on 16x16x32 ran 3.7 other instructions per
+//     MFMA at 37-42 % matrix-pipe occupancy, profiles/r03_rr_kernels_pmc.txt).  A lane holds ONE token (lane % 32) and 8
+//     consecutive k (lane / 32) of it per operand register, and of a 32-feature result block the features 8 b + 4 (lane / 32) + e;
+//   * the weights arrive as one pre-packed stream (engine/weights.py::pack_ff_block): half-stages of 32 KiB, every 1-KiB piece
+//     already the A operand of one MFMA in lane order (lane l holds W[32 j + l % 32][16 s + 8 (l / 32) .. +8]), so a half is a run
+//     of global -> LDS DMAs (global_load_lds, 16 B / lane, lane-linear image = conflict-free ds_read_b128 at base + lane * 16)
+//     into a 4-deep ring: half h + 2 is requested while half h computes;
+//   * per chunk of 32 hidden units a wave runs 40 MFMAs of FF1 (value block, gate block; K = C from registers), the GEGLU gate on
+//     its 32 x 32 results - which ARE the B operand of FF2 as they stand (the k-slots of the W2' fragments are packed in the
+//     order the gate outputs sit in the lanes: no shuffle, no LDS round trip) - and 20 MFMAs of FF2 for the PREVIOUS chunk, so
+//     that the gate's VALU work has independent matrix work beside it;
 //   * epilogue: residual tile by DMA into the (now idle) ring (row pitch padded against bank conflicts), + bias + accumulators
-//     in f32, one rounding to bf16 in LDS, the tile leaves in 640-B rows (16 B / lane); per-(row tile, channel) {sum, sum sq} of the stored values for the
-//     GroupNorm that consumes the block (fyc_gemm's chan_parts layout with tile_rows = 128, one slot).
+//     in f32, one rounding to bf16 in LDS, the tile leaves in 640-B rows (16 B / lane); per-(row tile, channel) {sum, sum sq} of
+//     the stored values for the GroupNorm that consumes the block (fyc_gemm's chan_parts layout with tile_rows = 128, one slot).
 //
 // Built for the level where it pays (C = 320, hidden 1280, bf16, rows % 128 == 0); other shapes keep the unfused schedule.
-// Compiled WITHOUT -amdgpu-mfma-vgpr-form (see _build.py): the accumulators must live in AGPRs for the 512-register budget.
+// Compiled WITHOUT -amdgpu-mfma-vgpr-form and with -fno-slp-vectorize (see _build.py).
 #include <mutex>
 #include <type_traits>
 
@@ -35,34 +39,37 @@
 
 namespace {
 
-constexpr int C_ = 320, HID = 1280, ROWS = 128;
-constexpr int KS = C_ / 32;                    // 10 MFMA k-steps over C
-constexpr int NB = C_ / 16;                    // 20 column blocks of the output
+constexpr int C_ = 320, HID = 1280, ROWS = 128, NW = 4, NT = 64 * NW;
+constexpr int KS = C_ / 16;                    // 20 MFMA k-steps (of 16) over C
+constexpr int NB = C_ / 32;                    // 10 feature blocks (of 32) of the output
 constexpr int CHUNKS = HID / 32;               // 40 hidden chunks of 32 units
-constexpr int PIECE = 1024;                    // one MFMA fragment for all 64 lanes
+constexpr int PIECE = 1024;                    // one MFMA A operand for all 64 lanes: a 32 x 16 weight block
 // The weight stream is cut into HALF-STAGES of HP = 32 pieces (32 KiB) that go through a 4-deep LDS ring: the pieces of half
-// h + 2 are requested while half h computes, i.e. a whole stage-time before they are needed.  (The first version had 46 stages
-// of 61 pieces in a 2-deep ring: the refill of a slot could only start when its previous stage was done, one stage before its
-// use, and a 61-KiB refill alone takes 1.4 us of the 2.1 us a stage took - profiles/r03_ff_block_ablation.txt, DMA-only run.)
-//   half t < 10           k-step t of the projection: pieces j < 20 = Wp rows 16 j .. +16, columns 32 t .. +32
-//   half 10 + 2 c  ("A")  pieces 4 s + q (s < 7): W1 rows 64 c + 16 q .. +16, columns 32 s .. +32; piece 28: f32 bias[64] of chunk c - 1
-//   half 11 + 2 c  ("B")  pieces 4 (s - 7) + q (s = 7, 8, 9): the rest of W1 of chunk c; pieces 12 + j (j < 20): W2' of chunk c - 1
-//   halves 90, 91         piece 28 / pieces 12 + j of the same for chunk 39
-constexpr int HP = 32, HALF_BYTES = HP * PIECE, NSLOT = 4;
-constexpr int SA = 7;                          // FF1 k-steps in half A
-constexpr int P_BIAS = 4 * SA, P_W2 = 4 * (KS - SA);
-constexpr int NHALF = KS + 2 * CHUNKS + 2;     // 92
-// the residual / output tile of the epilogue (overlays the ring).  Row pitch 672 B: consecutive rows are 168 dwords = 40 (mod 64
-// banks) apart, so the 16 rows x 4 quads x 8 B of one in-place add spread over all banks; at the natural 640 B (32 mod 64) they
-// met in two banks, 8-way (the same defect cost csrc/temporal_block_rr.hip a fifth of its tile time: profiles/r03_temporal_block_rr_phases.txt)
-constexpr int TP = C_ * 2 + 32;
-constexpr int TILE_BYTES = ROWS * TP;          // 86016 = 84 pieces
-constexpr int SCR_BYTES = 12 * 40 * 16 * 4;      // statistics partials of the epilogue: [row slice (6 or 12)][column group][8 sums | 8 sums of squares]
+// h + 2 are requested while half h computes, i.e. a whole stage-time before they are needed.
+//   half t < 10           k-steps 2 t, 2 t + 1 of the projection: pieces 10 s' + j (s' < 2, j < 10) = Wp rows 32 j .. +32, columns 16 (2 t + s') .. +16
+//   half 10 + 2 c  ("A")  pieces 2 s + v (s < 14; v = 0 value block, 1 gate block): the 32 value / 32 gate rows of W1 of chunk c,
+//                         columns 16 s .. +16; piece 28: f32 bias[32 value | 32 gate] of chunk c - 1
+//   half 11 + 2 c  ("B")  pieces 2 (s - 14) + v (s = 14 .. 19): the rest of W1 of chunk c; pieces 12 + 10 sg + j (sg < 2, j < 10): W2' of chunk c - 1
+//   halves 90, 91         piece 28 / pieces 12 + ... of the same for chunk 39
+constexpr int HP = 32, HALF_BYTES = HP * PIECE, NSLOT = 4, GPW = HP / 4 / NW;     // GPW: groups of four pieces per wave and half
+constexpr int SA = 14;                         // FF1 k-steps in half A
+constexpr int P_BIAS = 2 * SA, P_W2 = 2 * (KS - SA);
+constexpr int NPROJ = KS / 2;                  // 10 projection halves of two k-steps
+constexpr int NHALF = NPROJ + 2 * CHUNKS + 2;  // 92
+// the residual / output tile of the epilogue (overlays the ring).  Row pitch 656 B: consecutive rows are 164 dwords = 36 (mod 64
+// banks) apart, so the 32 rows x 2 lane halves x 8 B of one in-place add spread over all banks 2-way (the natural 640 B puts
+// them into 2 banks; that defect cost csrc/temporal_block_rr.hip a fifth of its tile time: profiles/r03_temporal_block_rr_phases.txt)
+constexpr int TP = C_ * 2 + 16;
+constexpr int TILE_BYTES = ROWS * TP;          // 83968 = 82 pieces
+constexpr int NSL = NT / 40;                   // row slices of the copy-out pass
+constexpr int SCR_BYTES = NSL * 40 * 16 * 4;   // statistics partials of the epilogue: [row slice][column group][8 sums | 8 sums of squares]
 constexpr int LDS_BYTES = NSLOT * HALF_BYTES;  // 131072
 static_assert(TILE_BYTES % PIECE == 0 && TILE_BYTES <= ((NHALF - 2) % NSLOT) * HALF_BYTES + P_BIAS * PIECE && (NHALF - 1) % NSLOT == 3,
               "the residual tile lands while the last two halves (slots 2 and 3) still hold the bias and W2' pieces of chunk 39");
 static_assert(TILE_BYTES + SCR_BYTES <= LDS_BYTES, "epilogue tile + statistics scratch overlay the ring");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct FFP {
   const bf16_t* x; const bf16_t* res; bf16_t* out;
@@ -73,22 +80,11 @@ struct FFP {
   float eps;
 };
 
-// 1 KiB global -> LDS by DMA, issued from inline asm: wave-uniform 64-bit base + one 32-bit lane offset, destination = wave-uniform
-// LDS byte address (+ 16 B per lane, implicit).  NOT the builtin: while a builtin LDS-DMA is outstanding hipcc turns every
-// counted lgkmcnt wait of the fragment reads into lgkmcnt(0) (it treats the DMA as a possible out-of-order LDS event), so each
-// k-step paid the full LDS round trip for fragments that were requested a k-step ahead (measured: 35 % of the wave's cycles in
-// s_waitcnt with and without the DMA).  The compiler does not count these loads: every stage barrier has its own vmcnt(0).
-__device__ __forceinline__ void dma16(const char* gbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
-}
-// Four consecutive pieces (4 KiB of the stream -> 4 KiB of the ring) by one wave: ONE M0 write, the instruction's immediate
-// offset moves the global and the LDS address together.  A wave alone on its SIMD issues one instruction per ~4 cycles, so
-// beside a 16-cycle MFMA only three other instructions are free; piece by piece the DMA cost 8 issue slots per KiB (M0 save /
-// set / restore, wait state, 64-bit address add, the load) = a quarter of a stage's issue budget (PMC: 49 % of the wave's
-// cycles issuing at 3.7 non-MFMA instructions per MFMA, profiles/r03_rr_kernels_pmc.txt); this form costs 1.75.
-// (M0 is not preserved: nothing else in these kernels uses it - hipcc treats it as reserved.)
+// Four consecutive pieces (4 KiB of the stream -> 4 KiB of the ring) by one wave, issued from inline asm: ONE M0 write, the
+// instruction's immediate offset moves the global and the LDS address together.  NOT the builtin: while a builtin LDS-DMA is
+// outstanding hipcc turns every counted lgkmcnt wait of the fragment reads into lgkmcnt(0) (it models the DMA as a FLAT access
+// that may touch LDS), so each k-step paid the full LDS round trip.  The compiler does not count these loads: the barriers of
+// this kernel carry their own s_waitcnt vmcnt.  (M0 is not preserved: nothing else here uses it - hipcc treats it as reserved.)
 __device__ __forceinline__ void dma16x4(const char* gbase, unsigned voff, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %0, %1\n\t"
@@ -97,35 +93,35 @@ __device__ __forceinline__ void dma16x4(const char* gbase, unsigned voff, unsign
                "global_load_lds_dwordx4 %0, %1 offset:3072"
                :: "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void dma16v(const void* gsrc, unsigned lds_dst) {                        // per-lane source address
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+__device__ __forceinline__ void dma16v(const void* gsrc, unsigned lds_dst) {                        // one piece, per-lane source address
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void dma_landed_barrier() {       // this wave's DMA pieces have landed, then the workgroup meets
+__device__ __forceinline__ void dma_landed_barrier() {       // all of this wave's DMA pieces have landed, then the workgroup meets
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
-
-// sum over the four 16-lane rows of a wave (every lane gets it): gfx950's v_permlane16_swap / v_permlane32_swap, plain VALU.
-// NOT __shfl_xor: that is ds_bpermute_b32, an LDS-queue instruction, and hipcc (which cannot see the asm DMAs above) waits for it
-// with a COUNTED lgkmcnt between the fragment reads of the projection stages it sinks this code into - with LDS-DMA writes in
-// flight the result was consumed early in ~12 % of the 16-row blocks (row statistics off by ~1e-3: tools/ff_stress.py found the
-// kernel's output changing from launch to launch; profiles/r03_ff_block_race.txt)
-__device__ __forceinline__ float rows_sum(float v) {
-  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+__device__ __forceinline__ void half_landed_barrier() {      // all but this wave's newest half (4 GPW loads) have landed, then the workgroup meets
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * GPW) : "memory");
+  __syncthreads();
 }
 
-__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// sum over the two lane halves of a wave (every lane gets it): gfx950's v_permlane32_swap, plain VALU.  NOT __shfl_xor: that is
+// ds_bpermute_b32, an LDS-queue instruction, and hipcc (which cannot see the asm DMAs above) waits for it with a COUNTED lgkmcnt
+// between the fragment reads of the projection stages it sinks this code into - with LDS-DMA writes in flight the result was
+// consumed early in ~12 % of the row blocks (row statistics off by ~1e-3: tools/ff_stress.py found the kernel's output changing
+// from launch to launch; profiles/r03_ff_block_race.txt).  -DFF_BPERMUTE rebuilds that form.
+__device__ __forceinline__ float halves_sum(float v) {
+#ifdef FF_BPERMUTE
+  return v + __shfl_xor(v, 32);
+#else
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+#endif
+}
 
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
 
-// RI: 16-row blocks per wave.  2 = four waves, one per SIMD with the whole 512-register file (32 rows per wave, every weight
-// fragment feeds two MFMAs);  1 = eight waves, TWO per SIMD at 256 registers (16 rows per wave, a fragment feeds one MFMA: twice the
-// LDS reads, but a second wave to issue while the first one waits).  fyc_set_tuning key 8 = 2 selects RI = 1.
 #ifdef FF_TIMING                                                // phase timestamps of wave 0 of every workgroup (tools/ff_probe.py prints them)
 __device__ unsigned long long g_ff_time[1024 * 16];
 #define FF_MARK(k) do { if (tid == 0) g_ff_time[(blockIdx.x & 1023) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -133,22 +129,18 @@ __device__ unsigned long long g_ff_time[1024 * 16];
 #define FF_MARK(k) do {} while (0)
 #endif
 
-template <int RI>
-__global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
-  constexpr int NW = 8 / RI, NT = 64 * NW, RW = 16 * RI;     // waves, threads, rows per wave
-  constexpr int NSL = NT / 40;                                 // row slices of the copy-out pass (6 or 12)
-  constexpr int GPW = HP / 4 / NW;                             // groups of four pieces per wave and half (2 or 1)
+__global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // One row tile per workgroup.  (A persistent loop over tiles was tried - with and without requesting the next tile's tokens
-  // during the last stage: inside an outer loop the register allocator spilled 85-95 registers of this 496-register kernel.)
+  // during the last stage: inside an outer loop the register allocator spilled 85-95 registers of this ~500-register kernel.)
   {
   const int tile = blockIdx.x;
   const long long row0 = (long long)tile * ROWS;
   const int lane = tid & 63;
-  const int g = lane >> 4, r16 = lane & 15;
+  const int kh = lane >> 5, tok = lane & 31;                  // lane = (k half, token of the wave's 32)
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the dynamic region
   // n-th group of four pieces of this wave of half h (n < GPW): group wave + NW n; every wave issues exactly 4 GPW loads per
@@ -160,84 +152,61 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
     const int grp = wave + NW * n;
     dma16x4(p.ws + (long long)h * HALF_BYTES + grp * (4 * PIECE), lane16, lds0 + (h & (NSLOT - 1)) * HALF_BYTES + grp * (4 * PIECE));
   };
-  auto half_landed_barrier = [&]() {                          // the oldest outstanding half of this wave has landed, then the workgroup meets
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * GPW) : "memory");
-    __syncthreads();
-  };
 
-  // ---- the wave's 32 token rows as MFMA operands: lane (row r16, quad g) holds x[row][32 s + 8 g .. +8] ---------------------
-  bf16x8 xa[RI][KS];
-  auto load_x = [&](int tile) {
-    const bf16_t* xr = p.x + ((long long)tile * ROWS + wave * RW + r16) * C_ + g * 8;
-#pragma unroll
-    for (int i = 0; i < RI; ++i)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const bf16x8*>(xr + i * 16 * C_ + s * 32);
-  };
+  // ---- the wave's 32 token rows as MFMA B operands: lane (token, k half) holds x[token][16 s + 8 kh .. +8] ----------------------
   FF_MARK(0);
-  load_x(tile);
+  bf16x8 xa[KS];
+  {
+    const bf16_t* xr = p.x + (row0 + wave * 32 + tok) * C_ + kh * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xa[s] = *reinterpret_cast<const bf16x8*>(xr + s * 16);
+  }
 #pragma unroll
   for (int n = 0; n < GPW; ++n) dma_group(0, n);
 #pragma unroll
   for (int n = 0; n < GPW; ++n) dma_group(1, n);
 
-  // LayerNorm statistics of the lane's two rows (two-pass, in registers; the four quads of a row meet through xor 16 / 32)
-  float mu[RI], rs[RI];
-#pragma unroll
-  for (int i = 0; i < RI; ++i) {
+  // LayerNorm statistics of the lane's row (two-pass, in registers; the two lanes of a row meet through the lane-half swap)
+  float mu, rs;
+  {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      const u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
+      const u32x4 t = __builtin_bit_cast(u32x4, xa[k]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s += __uint_as_float(t[e] << 16) + __uint_as_float(t[e] & 0xffff0000u);
     }
-#ifdef FF_BPERMUTE
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-#else
-    s = rows_sum(s);
-#endif
-    const float m = s * (1.0f / C_);
+    mu = halves_sum(s) * (1.0f / C_);
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      const u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
+      const u32x4 t = __builtin_bit_cast(u32x4, xa[k]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float a = __uint_as_float(t[e] << 16) - m, b = __uint_as_float(t[e] & 0xffff0000u) - m;
+        const float a = __uint_as_float(t[e] << 16) - mu, b = __uint_as_float(t[e] & 0xffff0000u) - mu;
         q = __builtin_fmaf(a, a, q);
         q = __builtin_fmaf(b, b, q);
       }
     }
-#ifdef FF_BPERMUTE
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-#else
-    q = rows_sum(q);
-#endif
-    mu[i] = m;
-    rs[i] = rsqrtf(q * (1.0f / C_) + p.eps);
+    rs = rsqrtf(halves_sum(q) * (1.0f / C_) + p.eps);
   }
 
-  f32x4 oacc[RI][NB];                                         // out rows 16 i + r16, columns 16 j + 4 g .. +4
+  f32x16 oacc[NB];                                            // out^T block j: features 32 j + 8 b + 4 kh + e (register 4 b + e) of token `tok`
 #pragma unroll
-  for (int i = 0; i < RI; ++i)
+  for (int j = 0; j < NB; ++j)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) oacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
 
   FF_MARK(1);
-  // ---- projection: out = tok Wp^T, half t = k-step t of all 20 column blocks ----------------------------------------------------
+  // ---- projection: out = tok Wp^T, half t = k-steps 2 t, 2 t + 1 of all 10 feature blocks -------------------------------------
 #pragma unroll
-  for (int t = 0; t < KS; ++t) {
+  for (int t = 0; t < NPROJ; ++t) {
     half_landed_barrier();                                    // half t landed; slot (t + 2) & 3 is free (half t - 2 is done): refill it
     const char* sl = smem + (t & (NSLOT - 1)) * HALF_BYTES + lane16;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const bf16x8 wf = frag(sl, j);
-#pragma unroll
-      for (int i = 0; i < RI; ++i) oacc[i][j] = mfma(wf, xa[i][t], oacc[i][j]);
-      if (j % 8 == 0 && j / 8 < GPW) dma_group(t + 2, j / 8);
+    for (int u = 0; u < 2 * NB; ++u) {
+      oacc[u % NB] = mfma(frag(sl, u), xa[2 * t + u / NB], oacc[u % NB]);
+      if (u % 8 == 0 && u / 8 < GPW) dma_group(t + 2, u / 8);
     }
   }
 
@@ -246,149 +215,125 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
   // (x - mean) rstd rounded to bf16 (what the reference's autocast feeds its Linear), so that no LayerNorm term is left in the
   // per-chunk gate (gamma is folded into W1, beta into b1: engine/weights.py::fold_layernorm)
 #pragma unroll
-  for (int i = 0; i < RI; ++i)
+  for (int k = 0; k < KS; ++k) {
+    u32x4 t = __builtin_bit_cast(u32x4, xa[k]);
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        t[e] = pack_bf16x2((__uint_as_float(t[e] << 16) - mu[i]) * rs[i], (__uint_as_float(t[e] & 0xffff0000u) - mu[i]) * rs[i]);
-      xa[i][k] = __builtin_bit_cast(bf16x8, t);
-    }
+    for (int e = 0; e < 4; ++e)
+      t[e] = pack_bf16x2((__uint_as_float(t[e] << 16) - mu) * rs, (__uint_as_float(t[e] & 0xffff0000u) - mu) * rs);
+    xa[k] = __builtin_bit_cast(bf16x8, t);
+  }
 
   // ---- hidden chunks -----------------------------------------------------------------------------------------------------------
-  // Chunk c:  half A = FF1(c) k-steps 0..6 -> hw (28 RI MFMAs)  ||  GEGLU gate of chunk c - 1 from hr (VALU) -> hb;
-  //           half B = FF1(c) k-steps 7..9 (12 RI)  then  FF2(c - 1) with hb (20 RI MFMAs).
-  // The gate of a chunk runs one chunk after its FF1 so that its ~250 VALU instructions have independent matrix work beside
-  // them: a wave overlaps VALU with the matrix pipe only where the two alternate in program order, so the gate is cut into
-  // units (row block, half) and one unit follows the MFMAs of a k-step.
-  // gate unit u = (row block i, half h) of the pre-activations hr -> two packed bf16 pairs of the FF2 operand (two independent
-  // polynomial chains: their dependent v_pk_fma steps fill each other's wait states): k-slots 8 g + e = hidden unit 4 g + e of
-  // half 0 (e < 4), of half 1 (e >= 4)
-  auto gate_unit = [&](int u, const f32x4 (&bi)[4], const f32x4 (&hr)[RI][4], u32x4 (&hbw)[RI]) {
-    const int i = u >> 1, h = u & 1;
-#ifdef FF_GATE_PACKED
-    const f32x4 v = hr[i][2 * h] + bi[2 * h], gt = hr[i][2 * h + 1] + bi[2 * h + 1];
-    const f32x2 lo = geglu_pair((f32x2){v[0], v[1]}, (f32x2){gt[0], gt[1]}), hi = geglu_pair((f32x2){v[2], v[3]}, (f32x2){gt[2], gt[3]});
-    unsigned p0 = pack_bf16x2(lo.x, lo.y), p1 = pack_bf16x2(hi.x, hi.y);
-#else
-    // four independent SCALAR chains: beside MFMAs a packed f32 VALU instruction costs a lone wave ~22 cycles more than the two
-    // scalar ones it replaces (MI355X_MICROARCH.md; half A of a chunk took 2 350 cycles for 900 cycles of MFMA with the packed gate)
-    float o4[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o4[e] = geglu_one(hr[i][2 * h][e] + bi[2 * h][e], hr[i][2 * h + 1][e] + bi[2 * h + 1][e]);
-    unsigned p0 = pack_bf16x2(o4[0], o4[1]), p1 = pack_bf16x2(o4[2], o4[3]);
-#endif
-    asm volatile("" : "+v"(p0), "+v"(p1));                    // the unit's result is "used" here: LLVM's sinking passes would otherwise move the whole
-    hbw[i][2 * h] = p0;                                       // unit down to FF2, its only real consumer, behind all the MFMAs it is meant to sit beside
-    hbw[i][2 * h + 1] = p1;
-  };
-  auto load_consts = [&](const char* base, f32x4 (&bi)[4]) {  // bias (beta folded in) of the PREVIOUS chunk's 64 W1 rows
-    const float* cst = reinterpret_cast<const float*>(base + P_BIAS * PIECE);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bi[q] = *reinterpret_cast<const f32x4*>(cst + q * 16 + g * 4);
-  };
-  // FF1 k-steps [S0, S1) of the chunk whose pieces start at `first` in the half at sl; the next k-step's fragments in flight;
-  // `after(s)` runs behind the MFMAs of k-step s (DMA groups of half hnext, gate units)
-  auto ff1_steps = [&](const char* sl, auto s0_, auto s1_, f32x4 (&hw)[RI][4], auto after) {
-    constexpr int S0 = decltype(s0_)::value, S1 = decltype(s1_)::value;
-    bf16x8 w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = frag(sl, q);
-#pragma unroll
-    for (int s = S0; s < S1; ++s) {
-      bf16x8 n[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) n[q] = (s + 1 < S1) ? frag(sl, (s + 1 - S0) * 4 + q) : w[q];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < RI; ++i) hw[i][q] = mfma(w[q], xa[i][s], hw[i][q]);
-      after(s);
-      if (((s - S0) & 1) || s + 1 == S1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = n[q];
+  // Chunk c:  half A = FF1(c) k-steps 0..13 -> hv, hg (28 MFMAs)  ||  elements 0..13 of the GEGLU gate of chunk c - 1 (VALU) -> hb;
+  //           half B = FF1(c) k-steps 14..19 (12)  ||  elements 14, 15;  then  FF2(c - 1) with hb (20 MFMAs).
+  // The gate of a chunk runs one chunk after its FF1 so that its VALU instructions have independent matrix work beside them.
+  // The gate is cut into its 16 elements per lane (register e of the value / gate results = hidden unit 8 (e / 4) + 4 kh + e % 4):
+  // ~18 VALU instructions each, ONE element behind the two MFMAs of a k-step and laid out between them by sched_group_barrier.
+  // A lone wave overlaps VALU with the matrix pipe only where the two alternate instruction by instruction: with a whole
+  // 75-instruction unit behind a k-step the phase times were exactly (MFMA cycles + 4 x other instructions), i.e. no overlap.
+  // Pairs of elements are packed to bf16: FF2 k-step sg = e / 8, k-slots 8 kh + e % 8.
+  f32x4 bv4, bg4;
+  float glo = 0.f;
+  auto gate_elem = [&](int e, const float* bias, const f32x16& hv, const f32x16& hg, u32x4 (&hbw)[2]) {
+    if (e % 4 == 0) { bv4 = *reinterpret_cast<const f32x4*>(bias + 2 * e); bg4 = *reinterpret_cast<const f32x4*>(bias + 32 + 2 * e); }
+    const float o = geglu_one(hv[e] + bv4[e % 4], hg[e] + bg4[e % 4]);
+    if (e & 1) {
+      unsigned pk = pack_bf16x2(glo, o);
+      asm volatile("" : "+v"(pk));                              // "used" here: LLVM's sinking passes would otherwise move the gate down to FF2, its only consumer
+      hbw[e >> 3][(e & 7) >> 1] = pk;
+    } else {
+      glo = o;
     }
   };
-  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[RI]) {
-    bf16x8 hb[RI];
+  // FF1 k-steps [S0, S1) from the pieces 2 (s - S0) + v of the half at sl; the next k-step's two fragments in flight;
+  // `after(s)` runs behind the MFMAs of k-step s (DMA groups, gate units)
+  auto ff1_steps = [&](const char* sl, auto s0_, auto s1_, f32x16& hv, f32x16& hg, auto after) {
+    constexpr int S0 = decltype(s0_)::value, S1 = decltype(s1_)::value;
+    bf16x8 wv = frag(sl, 0), wg = frag(sl, 1);
 #pragma unroll
-    for (int i = 0; i < RI; ++i) hb[i] = __builtin_bit_cast(bf16x8, hbw[i]);
-    bf16x8 w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = frag(sl, P_W2 + q);
-#pragma unroll
-    for (int jb = 0; jb < NB / 4; ++jb) {                     // four column blocks per step, the next four fragments in flight
-      bf16x8 n[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) n[q] = (jb + 1 < NB / 4) ? frag(sl, P_W2 + (jb + 1) * 4 + q) : w[q];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < RI; ++i) oacc[i][jb * 4 + q] = mfma(w[q], hb[i], oacc[i][jb * 4 + q]);
+    for (int s = S0; s < S1; ++s) {
+      bf16x8 nv = wv, ng = wg;
+      if (s + 1 < S1) { nv = frag(sl, 2 * (s + 1 - S0)); ng = frag(sl, 2 * (s + 1 - S0) + 1); }
+      hv = mfma(wv, xa[s], hv);
+      hg = mfma(wg, xa[s], hg);
+      after(s);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two fragment reads of the next k-step, then MFMA / VALU alternating
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
       __builtin_amdgcn_sched_barrier(0);
+      wv = nv; wg = ng;
+    }
+  };
+  auto ff2 = [&](const char* sl, const u32x4 (&hbw)[2]) {
+    const bf16x8 hb[2] = {__builtin_bit_cast(bf16x8, hbw[0]), __builtin_bit_cast(bf16x8, hbw[1])};
+    bf16x8 w[2] = {frag(sl, P_W2), frag(sl, P_W2 + 1)};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = n[q];
+    for (int u = 0; u < 2 * NB; u += 2) {                     // piece P_W2 + u: k-step u / NB, feature block u % NB; the next two in flight
+      bf16x8 n[2] = {w[0], w[1]};
+      if (u + 2 < 2 * NB) { n[0] = frag(sl, P_W2 + u + 2); n[1] = frag(sl, P_W2 + u + 3); }
+      oacc[u % NB] = mfma(w[0], hb[u / NB], oacc[u % NB]);
+      oacc[(u + 1) % NB] = mfma(w[1], hb[(u + 1) / NB], oacc[(u + 1) % NB]);
+      if ((u & 2) || u + 2 == 2 * NB) __builtin_amdgcn_sched_barrier(0);
+      w[0] = n[0]; w[1] = n[1];
     }
   };
   using I0 = std::integral_constant<int, 0>;
   using IA = std::integral_constant<int, SA>;
   using IK = std::integral_constant<int, KS>;
-  // one chunk = halves ha (A) and ha + 1 (B): FF1 -> hw; with_gate: gate + FF2 of the previous chunk from hr
-  auto chunk = [&](int ha, f32x4 (&hw)[RI][4], const f32x4 (&hr)[RI][4], auto with_gate) {
+  // one chunk = halves ha (A) and ha + 1 (B): FF1 -> hv, hg; with_gate: gate + FF2 of the previous chunk from pv, pg
+  auto chunk = [&](int ha, f32x16& hv, f32x16& hg, const f32x16& pv, const f32x16& pg, auto with_gate) {
     constexpr bool WITH_GATE = decltype(with_gate)::value;
-    u32x4 hbw[RI];
-    if (ha == KS + 40) FF_MARK(4);
+    u32x4 hbw[2];
+    if (ha == NPROJ + 40) FF_MARK(4);
     half_landed_barrier();                                    // half A landed; slot (ha + 2) & 3 free
-    if (ha == KS + 40) FF_MARK(5);
+    if (ha == NPROJ + 40) FF_MARK(5);
     {
       const char* base = smem + (ha & (NSLOT - 1)) * HALF_BYTES;
-      f32x4 bi[4];
-      if constexpr (WITH_GATE) load_consts(base, bi);
+      const float* bias = reinterpret_cast<const float*>(base + P_BIAS * PIECE) + 4 * kh;
 #pragma unroll
-      for (int i = 0; i < RI; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hw[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      ff1_steps(base + lane16, I0{}, IA{}, hw, [&](int s) {
-        if (!(s & 1) && (s >> 1) < GPW) dma_group(ha + 2, s >> 1);                 // the refill goes out in the first k-steps
-        if constexpr (WITH_GATE) {                               // 2 RI gate units: behind k-steps 1, 3, 5, 6
-          const int u = s == SA - 1 ? 3 : (s & 1) ? (s >> 1) : -1;
-          if (u >= 0 && u < 2 * RI) gate_unit(u, bi, hr, hbw);
-        }
+      for (int e = 0; e < 16; ++e) { hv[e] = 0.f; hg[e] = 0.f; }
+      ff1_steps(base + lane16, I0{}, IA{}, hv, hg, [&](int s) {
+        if (s % 4 == 0 && s / 4 < GPW) dma_group(ha + 2, s / 4);                   // the refill goes out in the first k-steps
+        if constexpr (WITH_GATE) gate_elem(s, bias, pv, pg, hbw);                  // gate elements 0 .. 13 of the previous chunk
       });
     }
-    if (ha == KS + 40) FF_MARK(6);
+    if (ha == NPROJ + 40) FF_MARK(6);
     half_landed_barrier();                                    // half B landed
-    if (ha == KS + 40) FF_MARK(7);
+    if (ha == NPROJ + 40) FF_MARK(7);
     {
       const char* base = smem + ((ha + 1) & (NSLOT - 1)) * HALF_BYTES;
-      ff1_steps(base + lane16, IA{}, IK{}, hw, [&](int s) {
-        if ((s - SA) < GPW) dma_group(ha + 3, s - SA);
+      const float* bias = reinterpret_cast<const float*>(smem + (ha & (NSLOT - 1)) * HALF_BYTES + P_BIAS * PIECE) + 4 * kh;   // (half A's slot is refilled only two halves later)
+      ff1_steps(base + lane16, IA{}, IK{}, hv, hg, [&](int s) {
+        if ((s - SA) % 2 == 0 && (s - SA) / 2 < GPW) dma_group(ha + 3, (s - SA) / 2);
+        if constexpr (WITH_GATE) {
+          if (s < 16) gate_elem(s, bias, pv, pg, hbw);                             // ... and 14, 15
+        }
       });
-      if (ha == KS + 40) FF_MARK(8);
+      if (ha == NPROJ + 40) FF_MARK(8);
       if constexpr (WITH_GATE) ff2(base + lane16, hbw);
-      if (ha == KS + 40) FF_MARK(9);
+      if (ha == NPROJ + 40) FF_MARK(9);
     }
   };
 
-  f32x4 h0[RI][4], h1[RI][4];
+  f32x16 v0, g0, v1, g1;
   FF_MARK(3);
-  chunk(KS, h0, h1, std::false_type{});
+  chunk(NPROJ, v0, g0, v1, g1, std::false_type{});
   for (int c = 1; c + 1 < CHUNKS; c += 2) {                  // chunks (1, 2), (3, 4), ..., (37, 38): pre-activation buffers alternate
-    chunk(KS + 2 * c, h1, h0, std::true_type{});
-    chunk(KS + 2 * c + 2, h0, h1, std::true_type{});
+    chunk(NPROJ + 2 * c, v1, g1, v0, g0, std::true_type{});
+    chunk(NPROJ + 2 * c + 2, v0, g0, v1, g1, std::true_type{});
   }
   FF_MARK(10);
-  chunk(NHALF - 4, h1, h0, std::true_type{});                 // chunk 39: its refills are halves 90, 91 (bias / W2' of chunk 39 only)
+  chunk(NHALF - 4, v1, g1, v0, g0, std::true_type{});         // chunk 39: its refills are halves 90, 91 (bias / W2' of chunk 39 only)
   {
-    u32x4 hbw[RI];
+    u32x4 hbw[2];
     half_landed_barrier();                                    // half 90 landed (half 91 may still be in flight)
     {
       const char* base = smem + ((NHALF - 2) & (NSLOT - 1)) * HALF_BYTES;
-      f32x4 bi[4];
-      load_consts(base, bi);
+      const float* bias = reinterpret_cast<const float*>(base + P_BIAS * PIECE) + 4 * kh;
 #pragma unroll
-      for (int u = 0; u < 2 * RI; ++u) gate_unit(u, bi, h1, hbw);
+      for (int e = 0; e < 16; ++e) gate_elem(e, bias, v1, g1, hbw);
     }
     dma_landed_barrier();                                     // half 91 landed; every wave is done with slots 0 .. 2 below the bias piece
     if (p.res != nullptr) {                                   // residual tile over the idle part of the ring: the LDS image is linear, every
@@ -396,7 +341,7 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
 #pragma unroll 1
       for (int q = wave; q < TILE_BYTES / PIECE; q += NW) {
         const int off = q * PIECE + (int)lane16, row = off / TP;
-        const int col = min(off - row * TP, C_ * 2 - 16);       // (the 32 pad bytes of a row re-fetch its last chunk)
+        const int col = min(off - row * TP, C_ * 2 - 16);       // (the 16 pad bytes of a row re-fetch its last chunk)
         dma16v(src + row * (C_ * 2) + col, lds0 + q * PIECE);
       }
     }
@@ -407,22 +352,24 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
   // ---- epilogue -------------------------------------------------------------------------------------------------------------------
   dma_landed_barrier();                                            // residual tile landed; every wave is done with the ring
   FF_MARK(12);
-  const float* bias_out = p.b_out;
+  {
+    char* rowp = smem + (wave * 32 + tok) * TP + kh * 8;
 #pragma unroll
-  for (int i = 0; i < RI; ++i)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      bf16_t* a = reinterpret_cast<bf16_t*>(smem + (wave * RW + i * 16 + r16) * TP) + j * 16 + g * 4;
-      const f32x4 bo = *reinterpret_cast<const f32x4*>(bias_out + j * 16 + g * 4);
-      float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
-      if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
+      for (int b = 0; b < 4; ++b) {
+        bf16_t* a = reinterpret_cast<bf16_t*>(rowp + (32 * j + 8 * b) * 2);
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(p.b_out + 32 * j + 8 * b + 4 * kh);
+        float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+        if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = oacc[i][j][r] + bo[r] + rr[r];
-      ElemIO<bf16_t>::st4(a, v);
-    }
+        for (int r = 0; r < 4; ++r) v[r] = oacc[j][4 * b + r] + bo[r] + rr[r];
+        ElemIO<bf16_t>::st4(a, v);
+      }
+  }
   dma_landed_barrier();
-  // flat pass over the finished tile: thread (column group cg of 8 channels, row slice rsl) copies rows rsl, rsl + 6, ... to HBM,
-  // 16 B per lane and 3840 contiguous bytes per step, and sums its 8 columns for the statistics of the values as stored
+  // pass over the finished tile: thread (column group cg of 8 channels, row slice rsl) copies rows rsl, rsl + 6, ... to HBM,
+  // 16 B per lane and 640 contiguous bytes per row, and sums its 8 columns for the statistics of the values as stored
   {
     const int cg = tid % 40, rsl = tid / 40;
     float cs8[8], cq8[8];
@@ -455,7 +402,7 @@ __global__ void __launch_bounds__(64 * 8 / RI) ff_block_kernel(const FFP p) {
         *reinterpret_cast<f32x4*>(d + 12) = (f32x4){cq8[4], cq8[5], cq8[6], cq8[7]};
       }
       __syncthreads();
-      if (tid < 160) {                                        // one thread per column pair: add the six row slices
+      if (tid < 160) {                                        // one thread per column pair: add the row slices
         const int c2 = tid >> 2, e2 = (tid & 3) * 2;
         float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
@@ -521,15 +468,12 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) FYC_FAIL(-3, "fyc_ff_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
       if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
     }
   }
-  const unsigned grid = (unsigned)p.ntiles;
-  if (g_fyc_tuning[8] == 2) hipLaunchKernelGGL(ff_block_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(ff_block_kernel<2>, dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(ff_block_kernel, dim3((unsigned)p.ntiles), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_ff_block");
   return 0;
 }

@@ -274,11 +274,26 @@ def pack_temporal_stream(w_qkv: Tensor, bias: Tensor, pe_bias: Optional[Tensor],
 
 def ff_block_layout(C: int, hidden: int):
     """(half-stages, pieces per half-stage, FF1 k-steps in half A) of the fyc_ff_block weight stream (include/fyc.h);
-    (92, 32, 7) at the one shape csrc/ff_block.hip is built for (C = 320, hidden = 1280)"""
-    nb, ks, chunks = C // 16, C // 32, hidden // 32
+    (92, 32, 14) at the one shape csrc/ff_block.hip is built for (C = 320, hidden = 1280).  k-steps are 16 wide, blocks 32 rows."""
+    nb, ks, chunks = C // 32, C // 16, hidden // 32
     sa = (7 * ks + 9) // 10                                      # FF1 k-steps whose W1 pieces sit in half A (the rest, and W2', in half B)
-    hp = max(nb, 4 * sa + 1, 4 * (ks - sa) + nb)
-    return ks + 2 * chunks + 2, (hp + 3) // 4 * 4, sa
+    hp = max(2 * nb, 2 * sa + 1, 2 * (ks - sa) + 2 * nb)
+    return ks // 2 + 2 * chunks + 2, (hp + 3) // 4 * 4, sa
+
+
+def ff_slot_unit(sg: int, k: int) -> int:
+    """hidden unit (within its chunk of 32) that k-slot k (0..15) of k-step sg (0, 1) of the FF2 operand carries in csrc/ff_block.hip:
+    a lane (token, k half kh) holds of a 32 x 32 result the rows 8 b + 4 kh + e (register 4 b + e); registers 8 sg .. 8 sg + 7 are
+    its operand of k-step sg"""
+    kh, e = k // 8, k % 8
+    return 16 * sg + 8 * (e // 4) + 4 * kh + e % 4
+
+
+def _mfma_fragments32(w: Tensor) -> Tensor:
+    """[..., 32, 16] weight blocks -> [..., 512]: the A operand of v_mfma_f32_32x32x16_bf16 in lane order - position
+    8 l + e = block[l % 32][8 (l // 32) + e] (include/fyc.h, fyc_ff_block)"""
+    lead = w.shape[:-2]
+    return w.reshape(*lead, 32, 2, 8).transpose(-3, -2).reshape(*lead, 512)
 
 
 def _mfma_fragments(w: Tensor) -> Tensor:
@@ -290,36 +305,42 @@ def _mfma_fragments(w: Tensor) -> Tensor:
 
 def pack_ff_block(ff: Packed) -> Tensor:
     """weight stream of fyc_ff_block (csrc/ff_block.hip) from a packed feed-forward (`_ff`) whose LayerNorm is folded into FF1:
-    half-stages x pieces x 512 elements (layout: include/fyc.h; 92 x 32 x 1 KiB at C = 320).  Half t < ks: k-step t of the
-    projection of the token half of the merged [Wp | Wp W2] weight.  Chunk c of 32 hidden units: half ks + 2c ("A") = the W1
-    pieces of k-steps 0..sa-1 and the f32 bias of chunk c - 1; half ks + 2c + 1 ("B") = the remaining W1 pieces and the W2'
-    columns of chunk c - 1 in the k-slot order the kernel's GEGLU outputs have (slot 8 g + e = unit 4 g + e of the chunk's first
-    16 hidden units for e < 4, of its second 16 for e >= 4); the last two halves hold bias / W2' of the last chunk."""
+    half-stages x pieces x 512 elements (layout: include/fyc.h; 92 x 32 x 1 KiB at C = 320), a piece = the A operand of one
+    v_mfma_f32_32x32x16_bf16 (a 32 x 16 weight block).  Half t < ks / 2: k-steps 2t, 2t + 1 of the projection of the token half
+    of the merged [Wp | Wp W2] weight.  Chunk c of 32 hidden units: half ks/2 + 2c ("A") = the value / gate blocks of W1 for
+    k-steps 0..sa-1 and the f32 bias of chunk c - 1; half ks/2 + 2c + 1 ("B") = the remaining W1 pieces and the W2' columns of
+    chunk c - 1 in the k-slot order the kernel's GEGLU outputs have (ff_slot_unit); the last two halves hold bias / W2' of the
+    last chunk."""
     w1, b1, po = ff.w1, ff.b1, ff.po_w
     assert ff.cs1 is not None, "fyc_ff_block needs the LayerNorm folded into FF1"
     C = w1.shape[1]
     hid = w1.shape[0] // 2
     assert C % 32 == 0 and hid % 32 == 0 and tuple(po.shape) == (C, C + hid) and w1.dtype == po.dtype
-    nb, ks, chunks = C // 16, C // 32, hid // 32
+    nb, ks, chunks = C // 32, C // 16, hid // 32
     nh, hp, sa = ff_block_layout(C, hid)
-    st = torch.zeros(nh, hp, 512, dtype=w1.dtype, device=w1.device)
-    # projection: piece j of half t = Wp[16 j .. +16][32 t .. +32]
-    st[:ks, :nb] = _mfma_fragments(po[:, :C].reshape(nb, 16, ks, 32).permute(2, 0, 1, 3))            # [t][j][512]
-    # FF1: W1[64 c + 16 q .. +16][32 s .. +32] = piece 4 s + q of half A (s < sa) / piece 4 (s - sa) + q of half B
-    f1 = _mfma_fragments(w1.reshape(chunks, 4, 16, ks, 32).permute(0, 3, 1, 2, 4))                  # [c][s][q][512]
-    ha = torch.arange(chunks, device=w1.device) * 2 + ks
-    st[ha, : 4 * sa] = f1[:, :sa].reshape(chunks, 4 * sa, 512)
-    st[ha + 1, : 4 * (ks - sa)] = f1[:, sa:].reshape(chunks, 4 * (ks - sa), 512)
-    # bias piece (index 4 sa) of the half A that FOLLOWS the chunk: f32 bias[64] (beta folded in) of chunk c's 64 W1 rows (bit
-    # pattern of the floats inside a bf16 stream) - the kernel gates a chunk one chunk after its FF1, on LayerNorm-ed tokens
-    cst = torch.zeros(chunks, 512 * w1.element_size() // 4, dtype=torch.float32, device=w1.device)
-    cst[:, :64] = b1.reshape(chunks, 64)
-    st[ha + 2, 4 * sa] = cst.view(w1.dtype)
-    # FF2: pieces 4 (ks - sa) + j of the half B that follows the chunk = W2'[16 j .. +16][k-slots of chunk c]
-    slot_unit = torch.tensor([(4 * (k // 8) + k % 8) if k % 8 < 4 else (16 + 4 * (k // 8) + k % 8 - 4) for k in range(32)], device=w1.device)
-    w2 = po[:, C:].reshape(nb, 16, chunks, 32)[..., slot_unit]                               # [j][16][c][k-slot]
-    f2 = _mfma_fragments(w2.permute(2, 0, 1, 3))                                             # [c][j][512]
-    st[ha + 3, 4 * (ks - sa): 4 * (ks - sa) + nb] = f2
+    npj = ks // 2
+    dev = w1.device
+    st = torch.zeros(nh, hp, 512, dtype=w1.dtype, device=dev)
+    # projection: piece s' nb + j of half t = Wp[32 j .. +32][16 (2 t + s') .. +16]
+    wp = _mfma_fragments32(po[:, :C].reshape(nb, 32, npj, 2, 16).permute(2, 3, 0, 1, 4))           # [t][s'][j][512]
+    st[:npj, : 2 * nb] = wp.reshape(npj, 2 * nb, 512)
+    # FF1: ff.w1 is GEGLU-packed in blocks of 16 (16 value rows, their 16 gate rows, ...); the kernel wants the 32 value rows and
+    # the 32 gate rows of a chunk as two 32-row blocks, units in natural order
+    vg = w1.reshape(chunks, 2, 2, 16, C).permute(0, 2, 1, 3, 4).reshape(chunks, 2, 32, C)             # [c][value | gate][unit][C]
+    f1 = _mfma_fragments32(vg.reshape(chunks, 2, 32, ks, 16).permute(0, 3, 1, 2, 4))                 # [c][s][v][512]
+    ha = torch.arange(chunks, device=dev) * 2 + npj
+    st[ha, : 2 * sa] = f1[:, :sa].reshape(chunks, 2 * sa, 512)
+    st[ha + 1, : 2 * (ks - sa)] = f1[:, sa:].reshape(chunks, 2 * (ks - sa), 512)
+    # bias piece (index 2 sa) of the half A that FOLLOWS the chunk: f32 [32 value | 32 gate] (beta folded in) - the kernel gates a
+    # chunk one chunk after its FF1, on LayerNorm-ed tokens (bit pattern of the floats inside a bf16 stream)
+    cst = torch.zeros(chunks, 512 * w1.element_size() // 4, dtype=torch.float32, device=dev)
+    cst[:, :64] = b1.reshape(chunks, 2, 2, 16).permute(0, 2, 1, 3).reshape(chunks, 64)
+    st[ha + 2, 2 * sa] = cst.view(w1.dtype)
+    # FF2: pieces 2 (ks - sa) + sg nb + j of the half B that follows the chunk = W2'[32 j .. +32][k-slots of k-step sg of chunk c]
+    slot = torch.tensor([[ff_slot_unit(sg, k) for k in range(16)] for sg in range(2)], device=dev)     # [sg][16]
+    w2 = po[:, C:].reshape(nb, 32, chunks, 32)[..., slot.reshape(-1)].reshape(nb, 32, chunks, 2, 16)   # [j][32][c][sg][slot]
+    f2 = _mfma_fragments32(w2.permute(2, 3, 0, 1, 4))                                        # [c][sg][j][512]
+    st[ha + 3, 2 * (ks - sa): 2 * (ks - sa) + 2 * nb] = f2.reshape(chunks, 2 * nb, 512)
     return st.reshape(-1).contiguous()
 
 

@@ -325,16 +325,16 @@ int fyc_temporal_block_supported(const fyc_temporal_block_args* a);
  * replaces fyc_row_stats + fyc_gemm(FYC_EPI_GEGLU, LayerNorm folded) + fyc_gemm(a2 = h) - the hidden activation never leaves
  * the CU, x is read once.  `wstream` is the pre-packed weight stream (fyc_ff_block_wstream_bytes() bytes, 16-byte aligned):
  * 92 half-stages x 32 pieces x 1 KiB (the kernel runs them through a 4-deep LDS ring, requesting half h + 2 while half h
- * computes), a piece = one MFMA operand fragment of a 16 x 32 weight block B in lane order (byte 16 l of the piece =
- * B[l & 15][8 (l >> 4) .. +8], bf16); unused pieces are zero:
- *   half t < 10        pieces j < 20: Wp rows 16 j .. +16, columns 32 t .. +32  (Wp = merged weight [:, :C]; k-step t of the projection)
- *   half 10 + 2 c      pieces 4 s + q (s < 7; q < 4): rows 64 c + 16 q .. +16 of the GEGLU-packed W1 of hidden chunk c (32 units) with
- *                      the LayerNorm weight folded in (W1 * gamma; fyc_pack_geglu order: 16 value rows, their 16 gate rows, ...),
- *                      columns 32 s .. +32; for c >= 1, piece 28 = f32 bias[64] (b1 + W1 beta) of the 64 W1 rows of chunk c - 1
- *   half 11 + 2 c      pieces 4 (s - 7) + q (s = 7, 8, 9): the remaining W1 columns of chunk c; for c >= 1, pieces 12 + j (j < 20) =
- *                      rows 16 j .. +16 of W2' = merged weight [:, C:], k-slot 8 g + e = hidden unit 32 (c - 1) + 4 g + e (e < 4) or
- *                      32 (c - 1) + 16 + 4 g + e - 4 (e >= 4)
- *   halves 90, 91      piece 28 / pieces 12 + j: the same for hidden chunk 39.
+ * computes), a piece = the A operand of one v_mfma_f32_32x32x16_bf16, i.e. a 32 x 16 weight block B in lane order (byte 16 l of
+ * the piece = B[l % 32][8 (l / 32) .. +8], bf16); unused pieces are zero:
+ *   half t < 10        pieces 10 s + j (s < 2, j < 10): Wp rows 32 j .. +32, columns 16 (2 t + s) .. +16  (Wp = merged weight [:, :C])
+ *   half 10 + 2 c      pieces 2 s + v (s < 14): the 32 value rows (v = 0) / the 32 gate rows (v = 1) of W1 of hidden chunk c (units
+ *                      32 c .. +32 in natural order; LayerNorm weight folded in: W1 * gamma), columns 16 s .. +16; for c >= 1,
+ *                      piece 28 = f32 bias (b1 + W1 beta) [32 value | 32 gate] of chunk c - 1
+ *   half 11 + 2 c      pieces 2 (s - 14) + v (s = 14 .. 19): the remaining W1 columns of chunk c; for c >= 1, pieces 12 + 10 sg + j
+ *                      (sg < 2, j < 10) = rows 32 j .. +32 of W2' = merged weight [:, C:], k-slot 8 kh + e (kh < 2, e < 8) of k-step sg =
+ *                      hidden unit 32 (c - 1) + 16 sg + 8 (e / 4) + 4 kh + e % 4
+ *   halves 90, 91      piece 28 / pieces 12 + ...: the same for hidden chunk 39.
  * The kernel feeds FF1 the normalised tokens (x - mean) rstd rounded to bf16 (mean / variance over C in f32, two-pass).
  * (engine/weights.py::pack_ff_block builds it.)  chan_parts (optional): [rows / 128][C][2] f32 = per 128-row tile and channel
  * {sum, sum of squares} of the values as stored - fyc_gemm's chan_parts layout with tile_rows = 128 and one slot, for

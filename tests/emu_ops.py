@@ -294,38 +294,46 @@ class EmuOps:
     def _ff_unpack(wstream, C_, hidden):
         """inverse of the fyc_ff_block weight stream (include/fyc.h), written from the layout description: returns
         (Wp [C][C], W1 [2 hidden][C] GEGLU-packed with gamma folded in, bias [2 hidden] with beta folded in, W2' [C][hidden])"""
-        nb, ks, chunks = C_ // 16, C_ // 32, hidden // 32
+        nb, ks, chunks = C_ // 32, C_ // 16, hidden // 32
         sa = (7 * ks + 9) // 10
-        hp = (max(nb, 4 * sa + 1, 4 * (ks - sa) + nb) + 3) // 4 * 4
-        S = _flat(wstream).reshape(ks + 2 * chunks + 2, hp, 64, 8)                  # [half-stage][piece][lane][e]
+        hp = (max(2 * nb, 2 * sa + 1, 2 * (ks - sa) + 2 * nb) + 3) // 4 * 4
+        npj = ks // 2
+        S = _flat(wstream).reshape(npj + 2 * chunks + 2, hp, 64, 8)                # [half-stage][piece][lane][e]
         lane = torch.arange(64)
-        r, gq = lane & 15, lane >> 4
+        r, kh = lane % 32, lane // 32
 
-        def block(piece):                                                          # [64][8] fragment -> [16][32] weight block
-            blk = torch.zeros(16, 32, dtype=piece.dtype)
+        def block(piece):                                                          # [64][8] A operand -> [32][16] weight block
+            blk = torch.zeros(32, 16, dtype=piece.dtype)
             for e in range(8):
-                blk[r, 8 * gq + e] = piece[:, e]
+                blk[r, 8 * kh + e] = piece[:, e]
             return blk
         Wp = torch.zeros(C_, C_, dtype=wstream.dtype)
         for s_ in range(ks):
             for j in range(nb):
-                Wp[16 * j: 16 * j + 16, 32 * s_: 32 * s_ + 32] = block(S[s_, j])
-        W1 = torch.zeros(2 * hidden, C_, dtype=wstream.dtype)
+                Wp[32 * j: 32 * j + 32, 16 * s_: 16 * s_ + 16] = block(S[s_ // 2, (s_ % 2) * nb + j])
+        W1 = torch.zeros(2 * hidden, C_, dtype=wstream.dtype)                      # back in the GEGLU-packed order of engine/weights.py::_ff
         bi = torch.zeros(2 * hidden)
         W2 = torch.zeros(C_, hidden, dtype=wstream.dtype)
         for c in range(chunks):
-            ha = ks + 2 * c
+            ha = npj + 2 * c
+            vg = torch.zeros(2, 32, C_, dtype=wstream.dtype)                       # [value | gate][unit][C]
             for s_ in range(ks):
-                for q in range(4):
-                    piece = S[ha, 4 * s_ + q] if s_ < sa else S[ha + 1, 4 * (s_ - sa) + q]
-                    W1[64 * c + 16 * q: 64 * c + 16 * q + 16, 32 * s_: 32 * s_ + 32] = block(piece)
-            bi[64 * c: 64 * c + 64] = S[ha + 2, 4 * sa].reshape(-1).view(torch.float32)[:64]
-            for j in range(nb):
-                blk = block(S[ha + 3, 4 * (ks - sa) + j])                          # columns = k-slots 8 g + e
-                for k in range(32):
-                    g_, e = k // 8, k % 8
-                    unit = 4 * g_ + e if e < 4 else 16 + 4 * g_ + e - 4
-                    W2[16 * j: 16 * j + 16, 32 * c + unit] = blk[:, k]
+                for v in range(2):
+                    piece = S[ha, 2 * s_ + v] if s_ < sa else S[ha + 1, 2 * (s_ - sa) + v]
+                    vg[v, :, 16 * s_: 16 * s_ + 16] = block(piece)
+            bvg = S[ha + 2, 2 * sa].reshape(-1).view(torch.float32)[:64].reshape(2, 32)
+            for half in range(2):                                                  # 16 value rows, their 16 gate rows, ...
+                W1[64 * c + 32 * half: 64 * c + 32 * half + 16] = vg[0, 16 * half: 16 * half + 16]
+                W1[64 * c + 32 * half + 16: 64 * c + 32 * half + 32] = vg[1, 16 * half: 16 * half + 16]
+                bi[64 * c + 32 * half: 64 * c + 32 * half + 16] = bvg[0, 16 * half: 16 * half + 16]
+                bi[64 * c + 32 * half + 16: 64 * c + 32 * half + 32] = bvg[1, 16 * half: 16 * half + 16]
+            for sg in range(2):
+                for j in range(nb):
+                    blk = block(S[ha + 3, 2 * (ks - sa) + sg * nb + j])            # columns = k-slots 8 kh + e of k-step sg
+                    for k in range(16):
+                        kh_, e = k // 8, k % 8
+                        unit = 16 * sg + 8 * (e // 4) + 4 * kh_ + e % 4
+                        W2[32 * j: 32 * j + 32, 32 * c + unit] = blk[:, k]
         return Wp, W1, bi, W2
 
     def ff_block(self, x, residual, out, *, wstream, b_out, rows, C_, hidden, eps=1e-5, chan_parts=None, cs_rows=0):

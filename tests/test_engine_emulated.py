@@ -120,7 +120,7 @@ def test_ff_block_stream_round_trip():
     """weights.pack_ff_block against the layout description of include/fyc.h (the emulator's independent unpacker), at the
     kernel's widths and at a small one"""
     from followyourclick_amd.engine.weights import Packed, ff_block_layout, pack_ff_block
-    assert ff_block_layout(320, 1280) == (92, 32, 7)
+    assert ff_block_layout(320, 1280) == (92, 32, 14)
     for C, hid, T in [(320, 1280, torch.bfloat16), (64, 256, torch.float32), (96, 384, torch.bfloat16)]:
         g = torch.Generator().manual_seed(C)
         ff = Packed(w1=torch.randn(2 * hid, C, generator=g).to(T), b1=torch.randn(2 * hid, generator=g), cs1=torch.randn(2 * hid, generator=g),

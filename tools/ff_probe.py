@@ -58,7 +58,7 @@ def main():
 
         res = {}
         for rnd in range(3):                    # interleaved rounds: variants see the same clocks
-            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0), ("ff_block 8 waves x 16 rows", fused, 2, 0)):
+            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0),):
                 if key is not None:
                     h.set_tuning(8, key)
                 h.set_tuning(9, k9)
@@ -85,7 +85,7 @@ if hasattr(h.lib, "fyc_ff_timing"):                           # FF_TIMING build:
     assert h.lib.fyc_ff_timing(buf, n) == 0
     t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16).astype(np.int64)
     names = ["start", "x requested, halves 0/1 requested, LN statistics", "projection done (10 halves)", "tokens normalised", "chunk 20: before barrier A", "after barrier A",
-             "half A done (FF1 k 0-6 + gate of chunk 19)", "after barrier B", "FF1 k 7-9 done", "FF2 of chunk 19 done", "before chunk 39", "last FF2 done", "residual landed", "end"]
+             "half A done (FF1 k 0-13 + gate of chunk 19)", "after barrier B", "FF1 k 14-19 done", "FF2 of chunk 19 done", "before chunk 39", "last FF2 done", "residual landed", "end"]
     for sel, lab in ((slice(0, 256), "workgroups 0..255"), (slice(512, 768), "workgroups 512..767")):
         d = t[sel]
         print(lab)
