@@ -420,12 +420,11 @@ def _ff_operands(seed=0):
                   po_w=(rnd((C, C + hid), torch.float32, seed + 3) * (C + hid) ** -0.5).to(T), po_b=rnd((C,), torch.float32, seed + 4) * 0.1)
 
 
-@pytest.mark.parametrize("variant", [0])
+@pytest.mark.parametrize("variant", [0])      # (round 3 had schedule variants behind fyc_set_tuning key 8; one kernel now)
 @pytest.mark.parametrize("rows,with_res,with_stats", [(128, True, True), (512, False, False), (4096, True, True), (131072, True, True)])
 def test_ff_block_fused(hip, emu, rows, with_res, with_stats, variant):
     """fyc_ff_block (LayerNorm statistics + FF1 + GEGLU + FF2 + merged output projection + residual + output statistics in one
-    kernel) against the torch specification on the weight stream of engine/weights.py::pack_ff_block; both instruction
-    schedules of the kernel (fyc_set_tuning key 8)"""
+    kernel) against the torch specification on the weight stream of engine/weights.py::pack_ff_block"""
     from followyourclick_amd.engine.weights import pack_ff_block
     T, C, hid = torch.bfloat16, 320, 1280
     ff = _ff_operands()
