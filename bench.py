@@ -280,6 +280,17 @@ def main():
             result["roofline_attention"] = {"kernel": "fyc_attn_kernel (spatial self-attention)", "bound": "mfma", "achieved": round(at, 1),
                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(at / PEAK_BF16_TFLOPS, 4)}
 
+        # the fused kernels that left the GEMM family this round, each against the same MFMA peak (algorithmic FLOPs of the
+        # sub-block they replace ÷ summed launch time)
+        for key, name in (("ff_block", "ff_block_kernel (fused GEGLU feed-forward block, C = 320)"),
+                          ("temporal_block", "tblock_rr_kernel (fused temporal attention sub-block, C = 320)")):
+            if key in summ and summ[key]["flops"] > 0 and args.dtype == "bf16":
+                a = summ[key]
+                at = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                result["roofline_" + key] = {"kernel": name, "bound": "mfma", "achieved": round(at, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": round(at / PEAK_BF16_TFLOPS, 4), "launches_per_ddim_step": a["launches"] // n_inst,
+                                             "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2)}
+
     if rank == 0 and args.vae:
         from followyourclick_amd.engine import VAEDecoderConfig
         from followyourclick_amd.engine.schema import vae_decoder_schema
