@@ -246,9 +246,10 @@ class UNet3DEngine(EngineBase):
         """fragment-ordered copy of a linear weight for fyc_panel_linear, packed once per weight tensor"""
         cache = self.__dict__.setdefault("_panel_ws", {})
         key = w.data_ptr()
-        if key not in cache:
-            cache[key] = pack_panel_linear(w)
-        return cache[key]
+        hit = cache.get(key)
+        if hit is None or hit[0] is not w:                      # the entry holds the weight tensor: an address alone can be recycled
+            hit = cache[key] = (w, pack_panel_linear(w))
+        return hit[1]
 
     def _norm_proj_in(self, x: Act, node: Packed, rows: int, rows_per_sample: int) -> Act:
         """GroupNorm -> proj_in of a transformer / motion module (reference attention.py:269-270, motion_module.py:188-191).  With the
