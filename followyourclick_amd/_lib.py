@@ -159,6 +159,7 @@ MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set
         "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
+FYC_VERSION = 200        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
 
 
 class FycError(RuntimeError):
@@ -175,11 +176,14 @@ def load() -> C.CDLL:
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     lib.fyc_version.restype = C.c_int
+    ab_build = bool(os.environ.get("FYC_LIB_PATH"))      # an older library for A/B timing (tools/): newer entry points may be absent
+    if lib.fyc_version() // 100 != FYC_VERSION // 100 and not ab_build:
+        raise FycError(f"{LIB_PATH} reports ABI version {lib.fyc_version()}, this binding was written against {FYC_VERSION}: argument structs differ "
+                       "between major versions - rebuild the library (`python -m followyourclick_amd._build`)")
     lib.fyc_last_error.restype = C.c_char_p
     lib.fyc_init.argtypes = [vp]
     lib.fyc_device_caps.argtypes = [C.POINTER(i64)]
     lib.fyc_set_tuning.argtypes = [C.c_int, C.c_int]
-    ab_build = bool(os.environ.get("FYC_LIB_PATH"))      # an older library for A/B timing (tools/): newer entry points may be absent
     if not ab_build or hasattr(lib, "fyc_gemm_row_parts"):
         lib.fyc_gemm_row_parts.argtypes = [C.POINTER(GemmArgs)]
         lib.fyc_gemm_row_parts.restype = C.c_int

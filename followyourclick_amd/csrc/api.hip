@@ -16,6 +16,12 @@ extern "C" int fyc_init(const void* zero_page) {
   return 0;
 }
 
+#ifdef FYC_TRACE
+unsigned long long* g_fyc_trace = nullptr;
+// timing builds only (not part of include/fyc.h): [blocks][2][128] u64, zeroed by the caller before each launch
+extern "C" int fyc_set_trace(void* buf) { g_fyc_trace = (unsigned long long*)buf; return 0; }
+#endif
+
 extern "C" int fyc_set_tuning(int key, int value) {
   FYC_REQUIRE(key >= 0 && key < 16, "fyc_set_tuning: key %d", key);
   g_fyc_tuning[key] = value;

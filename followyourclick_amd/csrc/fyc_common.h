@@ -23,6 +23,9 @@ extern const void* g_fyc_zero_page;
 int64_t fyc_temporal_block_rr_wstream_bytes();
 int64_t fyc_temporal_block_rr_lds_bytes();
 int fyc_temporal_block_rr_launch(const fyc_temporal_block_args* a, void* stream);
+#ifdef FYC_TRACE
+extern unsigned long long* g_fyc_trace;   // timing builds: device buffer for the GEMM kernels' s_memtime stamps (fyc_set_trace)
+#endif
 extern int g_fyc_tuning[16];  // [1] forced GEMM tile config, [2] forced ring depth, [3] attention variant, [4] GEMM tile-order strip width (-1 = row-major)
 
 #define FYC_FAIL(code, ...)                                   \

@@ -1,6 +1,6 @@
 // Host entry of the GEMM family: argument validation, tile/ring selection, dispatch.
 // Kernel template: gemm_kernel.h; instantiations: gemm_bf16_plain.hip, gemm_bf16_conv.hip, gemm_f32.hip.
-#include "gemm_kernel.h"
+#include "gemm_pp_kernel.h"
 
 using fycg::GemmP;
 
@@ -74,14 +74,24 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // GEGLU pairs 16-column value / gate blocks inside a wave: config 6 gives a wave 5 column blocks (128x320 over 2x4 waves) and
   // used to leave the output unwritten (found by tools/gemm_diag.py at M = 4096 / 8192, N = 2560 - shapes the UNet never issued)
   if (cfg == 6 && p.epilogue == FYC_EPI_GEGLU) cfg = 5;
+  if (cfg == 22 && p.epilogue == FYC_EPI_GEGLU) cfg = 21;
+  // ping-pong main loop (gemm_pp_kernel.h) for the 8-wave tiles: fyc_set_tuning key 9 = 1 keeps the one-phase loop, 2 forces the
+  // ping-pong one wherever it is built; fyc_gemm() falls back to the one-phase twin when the problem does not qualify
+  if (g_fyc_tuning[9] == 2 && tile <= 0 && g_fyc_tuning[1] <= 0) {
+    if (cfg == 5) cfg = 21;
+    else if (cfg == 6) cfg = 22;
+    else if (cfg == 7) cfg = 23;
+  }
   if (cfg != 1 || ns != 3) ns = 2;   // only config 1 is also built 3-deep
 }
+// the one-phase twin of a ping-pong tile config (same tile, same wave grid)
+int pp_twin(int cfg) { return cfg == 21 ? 5 : cfg == 22 ? 6 : cfg == 23 ? 7 : cfg; }
 // column-tile width / row-tile height of a tile config (gemm_kernel.h::dispatch_cfg)
 int tile_bn(int cfg) {
-  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: return 320; case 7: return 256; default: return 128; }
+  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: case 21: case 22: return 320; case 7: case 23: return 256; default: return 128; }
 }
 int tile_bm(int cfg) {
-  switch (cfg) { case 3: case 4: case 5: case 7: return 256; default: return 128; }
+  switch (cfg) { case 3: case 4: case 5: case 7: case 21: case 23: return 256; default: return 128; }
 }
 // sample slots a row tile of bm rows can touch when a sample has cs_rows rows
 int stat_slots(int bm, int cs_rows) {
@@ -253,13 +263,23 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int cfg = 1, ns = 2;
   pick(a, cfg, ns, a->chan_parts != nullptr || a->row_parts != nullptr);
+  // the ping-pong main loop is built for bf16 problems with the 16-byte epilogues, whole 64-element K tiles (at least two) and no batch
+  // (its loaders keep 32-bit element offsets: every operand below 2^32 elements)
+  const long long lim = 0xffffffffll;
+  const bool pp_small = (long long)a->N * a->ldw < lim &&
+                        (a->mode == FYC_GEMM_PLAIN ? ((long long)a->M * a->lda < lim && (a->a2 == nullptr || (long long)a->M * a->lda2 < lim))
+                                                   : ((long long)a->M / (a->Hout * a->Wout) * a->Hin * a->Win * a->Cin < lim));
+  const bool pp_ok = a->dtype == FYC_BF16 && p.wide && batch == 1 && a->act == FYC_ACT_NONE && a->K % 64 == 0 && a->K >= 128 && pp_small;
+  if (fycg::pp_cfg(cfg) && !pp_ok) cfg = pp_twin(cfg);
   {
     int scfg = 0;
     const int sk = split_of(a, scfg);
     if (sk > 1 && p.wide && a->workspace != nullptr && a->workspace_bytes >= (int64_t)sk * a->M * a->N * 4 && ((uintptr_t)a->workspace % 16) == 0) {
       GemmP q = p;
       q.splitk = sk; q.ws = (float*)a->workspace;
-      const int rc = (a->mode == FYC_GEMM_PLAIN) ? fycg::run_bf16_plain(q, batch, scfg, 2, st) : fycg::run_bf16_conv(q, batch, scfg, 2, st);
+      if (scfg == 6 && g_fyc_tuning[9] == 2 && pp_ok) scfg = 22;
+      const int rc = fycg::pp_cfg(scfg) ? (a->mode == FYC_GEMM_PLAIN ? fycg::run_pp_plain(q, scfg, st) : fycg::run_pp_conv(q, scfg, st))
+                     : (a->mode == FYC_GEMM_PLAIN) ? fycg::run_bf16_plain(q, batch, scfg, 2, st) : fycg::run_bf16_conv(q, batch, scfg, 2, st);
       if (rc != 0) return rc;
       const long long items = (long long)a->M * (a->N / 8);
       const int blocks = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
@@ -276,6 +296,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(a->mode == FYC_GEMM_PLAIN, "fyc_gemm: act needs the PLAIN mode");
     return fycg::run_bf16_act(p, batch, cfg, st);
   }
+  if (fycg::pp_cfg(cfg)) return a->mode == FYC_GEMM_PLAIN ? fycg::run_pp_plain(p, cfg, st) : fycg::run_pp_conv(p, cfg, st);
   if (a->mode == FYC_GEMM_PLAIN) return fycg::run_bf16_plain(p, batch, cfg, ns, st);
   return fycg::run_bf16_conv(p, batch, cfg, ns, st);
 }

@@ -56,7 +56,23 @@ struct GemmP {
   int stagger; // 8-wave tiles: the upper half of the waves issues its DMAs between its two MFMA k-steps (fyc_set_tuning key 5 = 1: off)
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
+  unsigned long long* trace;   // timing builds (-DFYC_TRACE, tools/gemm_phase_probe.py): per-block s_memtime stamps; nullptr otherwise
 };
+
+// timing builds: waves 0 and 4 of a block append the shader clock to their list ([block][2][128] u64, zeroed by the host; the
+// count lives in a register so that a stamp is one store and no load)
+#ifdef FYC_TRACE
+#define FYC_STAMP_DECL int fyc_trace_n = 0
+#define FYC_STAMP(p, wave, lane)                                                                                         \
+  do {                                                                                                                   \
+    if ((p).trace != nullptr && ((wave) & 3) == 0 && (lane) == 0 && fyc_trace_n < 128)                                   \
+      (p).trace[((size_t)blockIdx.x * 2 + ((wave) >> 2)) * 128 + fyc_trace_n] = __builtin_amdgcn_s_memtime();            \
+    ++fyc_trace_n;                                                                                                       \
+  } while (0)
+#else
+#define FYC_STAMP_DECL
+#define FYC_STAMP(p, wave, lane) do { } while (0)
+#endif
 
 // Linear tile index (after the XCD remap) -> tile coordinates.  The 32 CUs of an XCD work on ~32 consecutive indices at
 // any time.  With plain row-major order (n fastest) and many column tiles that window is 1-2 tile rows x 16-32 columns:
@@ -742,6 +758,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   };
 
   f32x4 acc[WTM][WTN];
+  FYC_STAMP_DECL;
 
   const int g = lane >> 4, r16 = lane & 15;
   const int sw = swz_key<RB>(r16);   // all fragment rows are r16 + multiples of 16: same key
@@ -806,6 +823,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    FYC_STAMP(p, wave, lane);
     const int kt_hi = kt_end(tile);
     for (int kt = kt_begin(tile); kt < kt_hi; ++kt) {
       // the oldest in-flight element must have landed; up to NS-2 younger ones may stay in flight
@@ -828,6 +846,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       compute(st_c, 1, KSTEPS);
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     }
+    FYC_STAMP(p, wave, lane);
     const int t = remap(tile / S);
     int tile_m, tile_n;
     tile_coords(p, t, tile_m, tile_n);
@@ -847,6 +866,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     }
 
     gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE, WIDE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
+    FYC_STAMP(p, wave, lane);
   }  // tile stream
 }
 
@@ -879,6 +899,9 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   q.tiles_n = (p.N + BN - 1) / BN;
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
   q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
+#ifdef FYC_TRACE
+  q.trace = g_fyc_trace;
+#endif
   q.strip = (q.tiles_n > 4 && g_fyc_tuning[4] >= 0) ? (g_fyc_tuning[4] > 0 ? g_fyc_tuning[4] : (q.tiles_n >= 16 ? 8 : 4)) : 0;   // measured: profiles/r01_gemm_strip_order.txt
   // persistent grid: as many blocks as stay resident (LDS-limited), each walks a strided tile list
   int occ = (160 * 1024) / smem;

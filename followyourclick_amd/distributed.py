@@ -22,7 +22,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    # under a launcher (torch.distributed.run sets TORCHELASTIC_RUN_ID) the group is opened even for ONE rank: a 1-GPU box then
+    # exercises the same RCCL init / broadcast / barrier / all-reduce calls an 8-GPU node will make (tests/test_distributed_gpu.py)
+    launched = "TORCHELASTIC_RUN_ID" in os.environ and "RANK" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -56,11 +59,21 @@ def packed_tensors(P: Packed) -> List[tuple]:
     return list(_leaves(P))
 
 
+def _staging_device() -> Optional[torch.device]:
+    """RCCL ("nccl") moves device memory only: host-resident tensors (a model that was loaded but not yet moved - the reference
+    calls `unet.load_state_dict` at scripts/inference.py:178 and `.to("cuda")` at :213) are staged through the current GPU."""
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return None
+
+
 def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> int:
     """Broadcast every tensor of the tree from `src`.  Small tensors are coalesced into flat buckets
-    (xGMI is point-to-point: few large transfers beat ~3000 tiny ones).  Returns bytes moved."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    (xGMI is point-to-point: few large transfers beat ~3000 tiny ones).  Tensors may live on the host or on the GPU, in any
+    mix: under the nccl backend each bucket is assembled on the current GPU, broadcast, and copied back.  Returns bytes moved."""
+    if not dist.is_initialized():
         return 0
+    stage = _staging_device()
     total = 0
     groups = {}
     for name, t in packed_tensors(P):
@@ -71,7 +84,8 @@ def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> 
             nonlocal bucket, size
             if not bucket:
                 return
-            flat = torch.cat([t.reshape(-1) for t in bucket])
+            dev = stage if stage is not None else bucket[0].device
+            flat = torch.cat([t.detach().reshape(-1).to(dev) for t in bucket])
             dist.broadcast(flat, src=src)
             off = 0
             for t in bucket:
@@ -84,7 +98,12 @@ def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> 
             total += nbytes
             if nbytes >= bucket_bytes:
                 flush()
-                dist.broadcast(t, src=src)
+                if stage is not None and t.device != stage:
+                    big = t.detach().to(stage)
+                    dist.broadcast(big, src=src)
+                    t.copy_(big)
+                else:
+                    dist.broadcast(t, src=src)
                 continue
             if size + nbytes > bucket_bytes:
                 flush()
@@ -100,7 +119,7 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 
     the module holds - UNet3D / UNet2D (with `image_proj_model`), both halves of AutoencoderKL, Resampler, ImageProjModel,
     the CLIP wrappers - because it moves the state dict itself, not a packed engine tree; the engines re-pack at the next
     forward (in-place copies bump the tensor versions they key on).  Returns bytes moved (0 without a process group)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return 0
     tree = Packed({k: v for k, v in module.state_dict(keep_vars=True).items() if isinstance(v, torch.Tensor)})
     with torch.no_grad():
@@ -116,20 +135,34 @@ def load_on_rank0(module, loader=None, *args, **kwargs):
     covered only part of the modules and could deadlock rank-divergent scripts.)"""
     if loader is None or not isinstance(module, torch.nn.Module):
         raise TypeError("load_on_rank0(module, loader, *args): pass the nn.Module whose weights the loader fills, then the loader")
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return loader(*args, **kwargs)
-    out = loader(*args, **kwargs) if dist.get_rank() == 0 else None
+    # rank 0's loader may raise (missing file, key mismatch): the others must not be left waiting in the weight broadcast, so a
+    # status word goes first and every rank raises together
+    out, err = None, None
+    if dist.get_rank() == 0:
+        try:
+            out = loader(*args, **kwargs)
+        except Exception as e:           # noqa: BLE001 - re-raised below, on every rank
+            err = e
+    dev = _staging_device() or torch.device("cpu")
+    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+    dist.broadcast(flag, src=0)
+    if int(flag.item()) != 0:
+        if err is not None:
+            raise err
+        raise RuntimeError("load_on_rank0: the loader failed on rank 0 (see its traceback); no weights were broadcast")
     broadcast_module(module, src=0)
     return out
 
 
 def barrier() -> None:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

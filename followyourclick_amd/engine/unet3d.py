@@ -256,7 +256,7 @@ class UNet3DEngine(EngineBase):
         producer's channel sums at hand the norm is applied to fyc_panel_linear's operand registers: no normalised tensor in HBM."""
         C = node.C
         if (FUSE_PANEL and isinstance(x, Act) and x.cs is not None and not self.fuse_rows and rows_per_sample % x.cs_rows == 0
-                and self.ops.panel_linear_supported(self.dtype, rows=rows, N=C, K=C, gn_rows_per_sample=rows_per_sample)):
+                and self.ops.panel_linear_supported(self.dtype, rows=rows, N=C, K=C, gn_rows_per_sample=rows_per_sample, gn_groups=self.groups)):
             out = self.new(rows, C)
             self.ops.panel_linear(x.t, out, wstream=self._panel_stream(node.pin_w), rows=rows, N=C, K=C, bias=node.pin_b, gn_cs=x.cs,
                                   gn_gamma=node.norm_g, gn_beta=node.norm_b, gn_rows_per_sample=rows_per_sample,

@@ -283,17 +283,17 @@ class HipOps:
         a.rows, a.C, a.hidden, a.eps, a.dtype = rows, C_, hidden, eps, _dt(x)
         self._call("fyc_ff_block", a)
 
-    def panel_linear_supported(self, dtype: torch.dtype, *, rows: int, N: int, K: int, gn_rows_per_sample: int = 0) -> bool:
+    def panel_linear_supported(self, dtype: torch.dtype, *, rows: int, N: int, K: int, gn_rows_per_sample: int = 0, gn_groups: int = 32) -> bool:
         """does fyc_panel_linear (row-panel linear, optionally with the input's GroupNorm on the operand registers) cover this shape?"""
         if not hasattr(self.lib, "fyc_panel_linear_supported"):
             return False
-        key = ("pls", dtype, rows, N, K, gn_rows_per_sample)
+        key = ("pls", dtype, rows, N, K, gn_rows_per_sample, gn_groups)
         if key not in self._q_cache:
             a = L.PanelLinearArgs()
             a.rows, a.N, a.K = rows, N, K
             a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
             if gn_rows_per_sample > 0:
-                a.gn_cs, a.gn_rows_per_sample, a.gn_stat_samples, a.gn_groups = 16, gn_rows_per_sample, 1, 32     # pointer only tested for null
+                a.gn_cs, a.gn_rows_per_sample, a.gn_stat_samples, a.gn_groups = 16, gn_rows_per_sample, 1, gn_groups     # pointer only tested for null
             self._q_cache[key] = bool(self.lib.fyc_panel_linear_supported(C.byref(a)))
         return self._q_cache[key]
 
@@ -304,7 +304,10 @@ class HipOps:
         """out = [GroupNorm](x) W^T + bias (+ residual) in one kernel (csrc/panel_linear.hip); `wstream` from
         engine/weights.py::pack_panel_linear; gn_cs = the f64 per-(statistics sample, channel) sums of x"""
         self.ensure_init(x.device)
-        need = int(self.lib.fyc_panel_linear_wstream_bytes(N, K))
+        key = ("plw", N, K)
+        if key not in self._q_cache:
+            self._q_cache[key] = int(self.lib.fyc_panel_linear_wstream_bytes(N, K))
+        need = self._q_cache[key]
         if wstream.numel() * wstream.element_size() != need:
             raise ValueError(f"panel_linear: wstream has {wstream.numel() * wstream.element_size()} bytes, expected {need}")
         if gn_cs is not None and gn_cs.dtype != torch.float64:

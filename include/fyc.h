@@ -26,7 +26,11 @@
 extern "C" {
 #endif
 
-#define FYC_VERSION 100
+/* ABI version = major * 100 + minor.  A host compiled against this header MUST compare fyc_version() with FYC_VERSION before its first
+ * call and refuse a library whose MAJOR differs: argument structs grow at the end between majors (round 3 appended `wstream` to
+ * fyc_temporal_block_args and widened the tuning table to 16 keys without bumping the number: a round-2 host would have passed a short
+ * struct whose missing tail the library reads as a pointer).  History: 100 = rounds 1-3 (see above), 200 = round 4 (structs as of this file). */
+#define FYC_VERSION 200
 
 typedef enum { FYC_F32 = 0, FYC_BF16 = 1 } fyc_dtype;
 
@@ -41,8 +45,9 @@ int fyc_device_caps(int64_t* caps);
 /* tuning knobs for A/B measurements (0 = automatic): key 0 = 1 disables split-K, key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
  * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
  * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one,
- * key 8 = 1: fyc_ff_block with the sched_group_barrier layout of the gate / MFMA interleave (0: the compiler's own); key 9 = fyc_ff_block measurement
- * bits (1: per-block piece order of the burst-issued weight DMA stages, 4: no MFMA work in the chunk stages - wrong results); keys 10..15 reserved */
+ * key 8 = 1: no s_setprio around the MFMA phases of the ping-pong GEMM loop; key 9 = main loop of the 8-wave GEMM tiles (0: the library's per-shape choice,
+ * 1: always the one-phase loop, 2: the ping-pong loop wherever it is built; tile configs 21 / 22 / 23 = ping-pong 256x320 / 128x320 / 256x256);
+ * keys 10..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------

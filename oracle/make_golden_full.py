@@ -9,6 +9,9 @@ production precision, by executing the REAL reference (container only; TEST INFR
     python -m oracle.make_golden_full cfg2       # BASELINE configs[1]: 16 frames 512x512, 25 DDIM steps (~1.5 h on 8 cores)
     python -m oracle.make_golden_full cfg4       # BASELINE configs[3] paths: F=32 forward (24x24 latent) and a 96x96-latent forward, max_len 32
     python -m oracle.make_golden_full cfg5       # BASELINE configs[4]: 5-step IP-Adapter + rectangle-mask trajectory (4 frames 128x128)
+    python -m oracle.make_golden_full cfg4full   # BASELINE configs[3] at its REAL shape: one forward, F=32, 96x96 latent, max_len 32 (~25 min on 8 cores)
+    python -m oracle.make_golden_full cfg5full   # BASELINE configs[4] at its REAL shape: one CFG-pair forward, 16f@512^2, 16 IP tokens + rectangle mask (~10 min)
+    python -m oracle.make_golden_full cfg5yard   # bf16-autocast drift of the NO-quirk oracle along the cfg5 trajectory (the engine's yardstick)
 
 Every UNet golden exists twice: `*_f32` = the reference as the CPU runs it (fp32), `*_bf16` = the same
 reference code under the CUDA-autocast cast policy with bfloat16 (oracle/autocast_emul.py), i.e. the
@@ -292,6 +295,119 @@ def cfg5():
     np.savez_compressed(os.path.join(OUT, "cfg5_trajectory.npz"), **d)
 
 
+CFG4_KEEP = (0, 5, 10, 15, 20, 25, 31)     # frames of the full-shape forward that are stored whole (every frame's norm is stored)
+
+
+def cfg4full():
+    """BASELINE configs[3] at the shape the bench line runs: ONE forward of the real reference at F = 32 frames on a 96x96 latent with the
+    32-row positional table - 18 432 pixels x 8 heads of 32x32 temporal scores together with 64 frames of 9 216-token spatial attention
+    (motion_module.py:286-304, 371-464; diffusers/models/attention.py:649-678).  181 TFLOP per forward: f32, then bf16-autocast.
+    Stored: the frames CFG4_KEEP of both outputs (the f32 one in f32, the bf16 one in f16 - 5e-4 relative, 25x below the drift), the
+    per-frame L2 norms of every frame of the f32 output, and the drift over the whole tensor."""
+    cfg, unet = full_unet(max_len=32)
+    F, lat, seed = 32, 96, 64
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    kw = dict(use_fps_condition=True, fps_tensor=fps, flow_control=flow)
+    inp = W.seeded_inputs(cfg, 1, F, lat, lat, seed=seed)
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    keep = list(CFG4_KEEP)
+    with torch.no_grad():
+        t0 = time.time()
+        y32 = unet(x9, torch.tensor(961), inp["text"], **kw).sample
+        log(f"cfg4full f32 forward {time.time() - t0:.0f}s")
+        np.savez_compressed(os.path.join(OUT, "cfg4_full_shape.partial.npz"), out_f32=y32[:, :, keep].numpy())
+        t0 = time.time()
+        with CudaAutocastOnCpu(torch.bfloat16):
+            y16 = unet(x9, torch.tensor(961), inp["text"], **kw).sample.float()
+        log(f"cfg4full bf16-autocast forward {time.time() - t0:.0f}s")
+    dr = rel(y16, y32)
+    dr_keep = rel(y16[:, :, keep], y32[:, :, keep])
+    log(f"cfg4full: drift bf16-autocast vs f32 = {dr:.3e} (on the stored frames {dr_keep:.3e})")
+    np.savez_compressed(os.path.join(OUT, "cfg4_full_shape.npz"), out_f32=y32[:, :, keep].numpy(), out_bf16=y16[:, :, keep].numpy().astype(np.float16),
+                        frame_norms_f32=y32.pow(2).sum(dim=(1, 3, 4)).sqrt().numpy(), keep=np.array(keep), drift=np.float64(dr), drift_keep=np.float64(dr_keep),
+                        timestep=np.int64(961), fps=fps.numpy(), flow=flow.numpy(), weight_seed=np.int64(0), input_seed=np.int64(seed), max_len=np.int64(32),
+                        frames=np.int64(F), lat=np.int64(lat))
+    os.remove(os.path.join(OUT, "cfg4_full_shape.partial.npz"))
+
+
+def _ip_setup(quirk: bool):
+    cfg = Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7, ip_reference_cpu_scale_quirk=quirk)
+    sd = W.make_weights(W.unet_state_shapes(cfg), seed=0)
+    return cfg, sd
+
+
+def cfg5full():
+    """BASELINE configs[4] at its REAL shape: one CFG-pair forward at 16 frames on a 64x64 latent with 16 IP tokens, the rectangle region mask
+    and the first-frame latent concat (pipeline_animation.py:676-680, 716-723; animatediff/models/attention.py:49-127).  Four forwards:
+    the real reference (its CPU path carries the attn2 temperature quirk), oracle.functional WITH the quirk (must reproduce it - asserted
+    here, the value is stored), oracle.functional WITHOUT it (= the deployed xformers semantics the engine implements) in f32 and under
+    bf16-autocast: that last pair's distance is the yardstick for the engine's bf16 mode."""
+    F, lat, seed = 16, 64, 65
+    cfg, sd = _ip_setup(True)
+    unet = ref_unet(cfg).eval()
+    unet.load_state_dict(sd, strict=True)
+    for m in unet.modules():
+        if m.__class__.__name__ == "BasicTransformerBlock" and hasattr(m, "attn1"):
+            m.attn1._slice_size = 8
+
+    class Proj(torch.nn.Module):
+        def forward(self, feat):
+            return feat
+    unet.image_proj_model = Proj()
+    inp = W.seeded_inputs(cfg, 1, F, lat, lat, seed=seed)
+    mask = torch.zeros(1, 1, 1, lat, lat)
+    mask[..., lat // 4: 3 * lat // 4, lat // 4: 3 * lat // 4] = 1.0
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], mask)] * 2)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    kw = dict(use_fps_condition=True, fps_tensor=fps, flow_control=flow, use_ip_cross_attention=True, reference_images_clip_feat=inp["ip_tokens"])
+    with torch.no_grad():
+        t0 = time.time()
+        yref = unet(x9, torch.tensor(961), inp["text"], **kw).sample
+        log(f"cfg5full reference f32 forward {time.time() - t0:.0f}s")
+        del unet
+        t0 = time.time()
+        yq = Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961), inp["text"], fps, flow, ip_tokens=inp["ip_tokens"])
+        log(f"cfg5full oracle (quirk) forward {time.time() - t0:.0f}s: vs reference {rel(yq, yref):.3e}")
+        assert rel(yq, yref) < 1e-4
+        ocfg, _ = _ip_setup(False)
+        yo = Fn.unet3d_forward(sd, ocfg, x9, torch.tensor(961), inp["text"], fps, flow, ip_tokens=inp["ip_tokens"])
+        with CudaAutocastOnCpu(torch.bfloat16):
+            yo16 = Fn.unet3d_forward(sd, ocfg, x9, torch.tensor(961), inp["text"], fps, flow, ip_tokens=inp["ip_tokens"]).float()
+    dr = rel(yo16, yo)
+    log(f"cfg5full: oracle(no quirk) vs reference(CPU quirk) {rel(yo, yref):.3e}; drift of the no-quirk oracle bf16-autocast vs f32 = {dr:.3e}")
+    np.savez_compressed(os.path.join(OUT, "cfg5_full_shape.npz"), out_ref_f32=yref.numpy(), out_oracle_noquirk=yo.numpy(), out_oracle_noquirk_bf16=yo16.numpy().astype(np.float16),
+                        oracle_quirk_vs_ref=np.float64(rel(yq, yref)), drift_noquirk=np.float64(dr), first_images_mask=mask.numpy(), timestep=np.int64(961),
+                        fps=fps.numpy(), flow=flow.numpy(), weight_seed=np.int64(0), input_seed=np.int64(seed), frames=np.int64(F), lat=np.int64(lat),
+                        ip_scale=np.float64(0.7), ip_num_tokens=np.int64(16))
+
+
+def cfg5yard():
+    """The yardstick the cfg5 TRAJECTORY's bf16 bound was missing: the reference's stored drift is of its CPU path (wrong attn2 temperature),
+    so here the NO-quirk oracle runs the same 5 steps under bf16-autocast; drift_noquirk{i} = rel-L2 to its own f32 run (which must
+    reproduce cfg5_trajectory.npz's `step{i}_oracle_noquirk` - asserted)."""
+    g = np.load(os.path.join(OUT, "cfg5_trajectory.npz"))
+    frames, lat, steps, seed = int(g["frames"]), int(g["lat"]), int(g["steps"]), int(g["input_seed"])
+    ocfg, sd = _ip_setup(False)
+    inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
+    text_emb, mask = torch.from_numpy(g["text_embeddings"]), torch.from_numpy(g["first_images_mask"])
+
+    def run():
+        tr = {}
+        Fn.denoise(sd, ocfg, Fn.DDIMConfig(), inp["latents"].clone(), text_emb, steps, 8.0, inp["first_image_latents"], mask,
+                   torch.tensor([2]), torch.tensor([4]), ip_tokens=inp["ip_tokens"], callback=lambda i, t, l: tr.__setitem__(i, l.clone().float()))
+        return tr
+    with torch.no_grad():
+        t32 = run()
+        with CudaAutocastOnCpu(torch.bfloat16):
+            t16 = run()
+    d = dict(steps=np.int64(steps))
+    for i in range(steps):
+        assert rel(t32[i], torch.from_numpy(g[f"step{i}_oracle_noquirk"])) < 1e-5
+        d[f"drift_noquirk{i}"] = np.float64(rel(t16[i], t32[i]))
+        log(f"cfg5yard step {i}: no-quirk oracle bf16-autocast vs f32 {d[f'drift_noquirk{i}']:.3e} (reference CPU-path drift {float(g[f'drift{i}']):.3e})")
+    np.savez_compressed(os.path.join(OUT, "cfg5_yardstick.npz"), **d)
+
+
 def cfg1():
     _trajectory("cfg1", 8, 32, 5, {0, 1, 2, 3, 4}, seed=51)
 
@@ -305,6 +421,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     for part in sys.argv[1:]:
         log("==", part)
-        dict(small=small, ip=ip, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2, cfg4=cfg4, cfg5=cfg5)[part]()
+        dict(small=small, ip=ip, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2, cfg4=cfg4, cfg5=cfg5, cfg4full=cfg4full, cfg5full=cfg5full, cfg5yard=cfg5yard)[part]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -367,7 +367,7 @@ class EmuOps:
             t = y.double().reshape(rows // 128, 128, C_)
             _flat(chan_parts)[: (rows // 128) * C_ * 2].reshape(rows // 128, C_, 2).copy_(torch.stack([t.sum(1), (t * t).sum(1)], dim=-1).float())
 
-    def panel_linear_supported(self, dtype, *, rows, N, K, gn_rows_per_sample=0):
+    def panel_linear_supported(self, dtype, *, rows, N, K, gn_rows_per_sample=0, gn_groups=32):
         """the shapes libfyc_hip.so's kernel is built for (csrc/panel_linear.hip)"""
         return (dtype == torch.bfloat16 and rows % 128 == 0 and K in (320, 640) and N in (320, 640)
                 and (gn_rows_per_sample == 0 or (gn_rows_per_sample % 128 == 0 and rows % gn_rows_per_sample == 0)))

@@ -18,7 +18,10 @@ import numpy as np
 import torch
 import yaml
 
-REF_ROOT = "/root/reference"
+# the reference tree itself (build container), or the byte copies of its entry scripts + YAMLs that oracle/stage_ref_scripts.py
+# puts under the git-ignored oracle/_ref/ (they travel to the GPU box with the repo snapshot; /root/reference does not)
+_STAGED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+REF_ROOT = "/root/reference" if os.path.exists("/root/reference/scripts/inference.py") else _STAGED
 REF_SCRIPT = os.path.join(REF_ROOT, "scripts", "inference.py")
 REF_INFERENCE_CFG = os.path.join(REF_ROOT, "configs", "inference", "inference_img_embed_mask_condition_zero_snr_.yaml")
 

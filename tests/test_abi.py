@@ -31,6 +31,20 @@ def lib():
     return _lib.load()
 
 
+def _header_version():
+    return int(re.search(r"#define FYC_VERSION (\d+)", open(HEADER).read()).group(1))
+
+
+def test_binding_refuses_a_library_of_another_major_version(monkeypatch):
+    """argument structs grow between majors: a binding must not call into a library whose major differs"""
+    from followyourclick_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "FYC_VERSION", _lib.FYC_VERSION + 100)
+    with pytest.raises(_lib.FycError, match="ABI version"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
 def declared_functions():
     src = open(HEADER).read()
     return sorted(set(re.findall(r"\b(fyc_[a-z0-9_]+)\s*\(", src)))
@@ -41,7 +55,8 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fyc.h but not exported by libfyc_hip.so"
-    assert lib.fyc_version() == 100
+    from followyourclick_amd import _lib
+    assert lib.fyc_version() == _lib.FYC_VERSION == _header_version()
 
 
 def test_binding_tables_cover_header():

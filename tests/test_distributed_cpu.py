@@ -102,6 +102,16 @@ def _dropin_worker(rank, world, port, tmp):
         raise AssertionError("load_on_rank0(loader) without a module was accepted")
     except TypeError:
         pass
+    # a loader that fails on rank 0 must fail EVERY rank (a status word precedes the weight broadcast), not leave the others waiting
+    def bad_loader():
+        raise FileNotFoundError("no such checkpoint")
+    try:
+        D.load_on_rank0(unet, bad_loader)
+        raise AssertionError("a failing loader was swallowed")
+    except FileNotFoundError:
+        assert rank == 0
+    except RuntimeError as e:
+        assert rank != 0 and "rank 0" in str(e)
     # anything with a state dict is covered, buffers included (the VAE encoder half, Resampler, ImageProjModel were not in round 2)
     extra = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.BatchNorm1d(8))
     extra[1].running_mean.fill_(float(rank + 1))
