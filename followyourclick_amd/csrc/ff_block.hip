@@ -84,17 +84,22 @@ struct FFP {
 // instruction's immediate offset moves the global and the LDS address together.  NOT the builtin: while a builtin LDS-DMA is
 // outstanding hipcc turns every counted lgkmcnt wait of the fragment reads into lgkmcnt(0) (it models the DMA as a FLAT access
 // that may touch LDS), so each k-step paid the full LDS round trip.  The compiler does not count these loads: the barriers of
-// this kernel carry their own s_waitcnt vmcnt.  (M0 is not preserved: nothing else here uses it - hipcc treats it as reserved.)
+// this kernel carry their own s_waitcnt vmcnt.  M0 is saved and restored inside the statement (as in panel_linear.hip and
+// temporal_block_rr.hip): it is compiler-reserved, and an "m0" clobber is only a warning, so a statement must leave it as it found it.
 __device__ __forceinline__ void dma16x4(const char* gbase, unsigned voff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %0, %1\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-               "global_load_lds_dwordx4 %0, %1 offset:3072"
-               :: "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void dma16v(const void* gsrc, unsigned lds_dst) {                        // one piece, per-lane source address
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void dma_landed_barrier() {       // all of this wave's DMA pieces have landed, then the workgroup meets
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,6 +1,7 @@
 // Host entry of the GEMM family: argument validation, tile/ring selection, dispatch.
 // Kernel template: gemm_kernel.h; instantiations: gemm_bf16_plain.hip, gemm_bf16_conv.hip, gemm_f32.hip.
 #include "gemm_pp_kernel.h"
+#include "gemm_ov_kernel.h"
 
 using fycg::GemmP;
 
@@ -82,13 +83,16 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
     else if (cfg == 6) cfg = 22;
     else if (cfg == 7) cfg = 23;
   }
+  // overlapped-epilogue kernel (gemm_ov_kernel.h, tile config 31 = 128x320): key 9 = 3 takes it for every N = 320 k problem the
+  // library would give a 256x320 / 128x320 tile; fyc_gemm() falls back to 6 when the problem does not qualify
+  if (g_fyc_tuning[9] == 3 && tile <= 0 && g_fyc_tuning[1] <= 0 && (cfg == 5 || cfg == 6) && p.epilogue == FYC_EPI_LINEAR) cfg = 31;
   if (cfg != 1 || ns != 3) ns = 2;   // only config 1 is also built 3-deep
 }
 // the one-phase twin of a ping-pong tile config (same tile, same wave grid)
-int pp_twin(int cfg) { return cfg == 21 ? 5 : cfg == 22 ? 6 : cfg == 23 ? 7 : cfg; }
+int pp_twin(int cfg) { return cfg == 21 ? 5 : cfg == 22 ? 6 : cfg == 23 ? 7 : cfg == 31 ? 6 : cfg; }
 // column-tile width / row-tile height of a tile config (gemm_kernel.h::dispatch_cfg)
 int tile_bn(int cfg) {
-  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: case 21: case 22: return 320; case 7: case 23: return 256; default: return 128; }
+  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: case 21: case 22: case 31: return 320; case 7: case 23: return 256; default: return 128; }
 }
 int tile_bm(int cfg) {
   switch (cfg) { case 3: case 4: case 5: case 7: case 21: case 23: return 256; default: return 128; }
@@ -285,6 +289,15 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   // the ping-pong main loop is built for bf16 problems with the 16-byte epilogues, whole 64-element K tiles (at least two) and no batch
   const bool pp_ok = a->dtype == FYC_BF16 && p.wide && batch == 1 && a->act == FYC_ACT_NONE && a->K % 64 == 0 && a->K >= 128;
   if (fycg::pp_cfg(cfg) && !pp_ok) cfg = pp_twin(cfg);
+  if (fycg::ov_cfg(cfg)) {
+    const int bm = tile_bm(cfg);
+    int scfg0 = 0;
+    const bool ov_ok = pp_ok && a->epilogue == FYC_EPI_LINEAR && a->K >= 5 * 64 && a->M % 2 == 0 && a->ln_nparts == 0 && a->row_parts == nullptr &&
+                       !(a->ln_stats != nullptr && a->residual != nullptr) && (a->chan_parts == nullptr || a->cs_rows % bm == 0) &&
+                       (a->rowbias == nullptr || p.rows_per_batch % bm == 0 || fycg::rowbias_slots(bm, p.rows_per_batch) > 0) && split_of(a, scfg0) <= 1;
+    if (!ov_ok) cfg = pp_twin(cfg);
+  }
+  if (cfg == 6 && a->epilogue == FYC_EPI_GEGLU) cfg = 5;      // (a fallback above may land on the one tile GEGLU is not built for)
   {
     int scfg = 0;
     const int sk = split_of(a, scfg);
@@ -310,6 +323,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(a->mode == FYC_GEMM_PLAIN, "fyc_gemm: act needs the PLAIN mode");
     return fycg::run_bf16_act(p, batch, cfg, st);
   }
+  if (fycg::ov_cfg(cfg)) return fycg::run_ov(p, cfg, st);
   if (fycg::pp_cfg(cfg)) return a->mode == FYC_GEMM_PLAIN ? fycg::run_pp_plain(p, cfg, st) : fycg::run_pp_conv(p, cfg, st);
   if (a->mode == FYC_GEMM_PLAIN) return fycg::run_bf16_plain(p, batch, cfg, ns, st);
   return fycg::run_bf16_conv(p, batch, cfg, ns, st);

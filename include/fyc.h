@@ -46,7 +46,8 @@ int fyc_device_caps(int64_t* caps);
  * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
  * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one,
  * key 8 = 1: no s_setprio around the MFMA phases of the ping-pong GEMM loop; key 9 = main loop of the 8-wave GEMM tiles (0: the library's per-shape choice,
- * 1: always the one-phase loop, 2: the ping-pong loop wherever it is built; tile configs 21 / 22 / 23 = ping-pong 256x320 / 128x320 / 256x256);
+ * 1: always the one-phase loop, 2: the ping-pong loop wherever it is built, 3: the overlapped-epilogue kernel wherever it is built; tile configs
+ * 21 / 22 / 23 = ping-pong 256x320 / 128x320 / 256x256, 31 = 128x320 with the epilogue under the next tile's K loop);
  * keys 10..15 reserved */
 int fyc_set_tuning(int key, int value);
 

@@ -87,6 +87,19 @@ def install_absent_packages(monkeypatch):
             om.__spec__ = _M.ModuleSpec("omegaconf", None)
             monkeypatch.setitem(sys.modules, "omegaconf", om)
     try:
+        import pytorch_lightning  # noqa: F401
+    except ImportError:          # scripts/inference_w_image_cond.py:36 imports seed_everything from it
+        import importlib.machinery as _M
+        import random
+        pl = types.ModuleType("pytorch_lightning")
+
+        def seed_everything(seed, *a, **k):
+            random.seed(seed); np.random.seed(seed % (2 ** 32)); torch.manual_seed(seed)
+            return seed
+        pl.seed_everything = seed_everything
+        pl.__spec__ = _M.ModuleSpec("pytorch_lightning", None)
+        monkeypatch.setitem(sys.modules, "pytorch_lightning", pl)
+    try:
         import torchvision.transforms  # noqa: F401
     except ImportError:
         tv, tr = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
@@ -163,8 +176,12 @@ def _bytes_to_unicode():
     return [chr(c) for c in cs]
 
 
-def fabricate_model_dir(root: str, seed: int = 0) -> dict:
-    """stable-diffusion-v1-5-shaped directory at tiny widths; returns the state dicts that went into it"""
+def fabricate_model_dir(root: str, seed: int = 0, inference_cfg: str = None, wrap_state_dict: bool = True) -> dict:
+    """stable-diffusion-v1-5-shaped directory at tiny widths; returns the paths of the checkpoints that go with it.
+    inference_cfg: the YAML whose `unet_additional_kwargs` shape the 3-D UNet (default: the reference's shipped one);
+    wrap_state_dict: the motion-module checkpoint as `{"state_dict": {"module.<key>": ...}}` (what scripts/inference.py strips) or as
+    a bare state dict (scripts/inference_org.py / inference_w_image_cond.py load the wrapped form with strict=True, i.e. expect a
+    FULL model there; the bare form goes through strict=False)"""
     from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
     from animatediff.models.unet import UNet3DConditionModel
     from diffusers import AutoencoderKL, UNet2DConditionModel
@@ -215,7 +232,7 @@ def fabricate_model_dir(root: str, seed: int = 0) -> dict:
         json.dump(dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
                        clip_sample=False, set_alpha_to_one=False), f)
     # motion module checkpoint: the temporal / fps / flow tensors of the 3-D model, saved from a DDP-wrapped training run ("module.")
-    with open(REF_INFERENCE_CFG) as f:
+    with open(inference_cfg or REF_INFERENCE_CFG) as f:
         extra = yaml.safe_load(f)["unet_additional_kwargs"]
     unet3d = UNet3DConditionModel.from_pretrained_2d(root, subfolder="unet", unet_additional_kwargs=extra)
     mm = {}
@@ -228,8 +245,17 @@ def fabricate_model_dir(root: str, seed: int = 0) -> dict:
             else:
                 mm["module." + k] = torch.randn_like(v) * 0.05 + (1.0 if "norm" in k and k.endswith("weight") else 0.0)
     ckpt = os.path.join(root, "motion_module.ckpt")
-    torch.save({"state_dict": mm}, ckpt)
-    return dict(motion_ckpt=ckpt, unet_extra=extra)
+    torch.save({"state_dict": mm} if wrap_state_dict else {k[len("module."):]: v for k, v in mm.items()}, ckpt)
+    # spatial weights of the 2-D UNet as a training checkpoint (inference_w_image_cond.py: `.ckpt`, "state_dict", `module.` prefix)
+    sd2d_b = {k: torch.randn_like(v) * 0.02 + v for k, v in sd2d.items()}
+    unet2d_ckpt = os.path.join(root, "unet2d_finetuned.ckpt")
+    torch.save({"state_dict": {"module." + k: v for k, v in sd2d_b.items()}}, unet2d_ckpt)
+    # a tiny CLIP vision model with projection (image_pretrained_model_path of the image-conditioned scripts)
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    vdir = os.path.join(root, "clip_vision")
+    CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=224,
+                                                   patch_size=32, projection_dim=CTX)).save_pretrained(vdir)
+    return dict(motion_ckpt=ckpt, unet_extra=extra, unet2d_ckpt=unet2d_ckpt, clip_vision_dir=vdir)
 
 
 def write_run_files(root: str, motion_ckpt: str, steps: int, size: int):

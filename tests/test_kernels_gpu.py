@@ -45,8 +45,8 @@ def close(hip_t, emu_t, tag, rtol):
 
 
 # ---------------------------------------------------------------------------------------------
-PLAIN_TILES = [(0, 0), (1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (21, 2), (22, 2), (23, 2)]
-CONV_TILES = [(0, 0), (1, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (21, 2), (22, 2), (23, 2)]
+PLAIN_TILES = [(0, 0), (1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (21, 2), (22, 2), (23, 2), (31, 2)]
+CONV_TILES = [(0, 0), (1, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (21, 2), (22, 2), (23, 2), (31, 2)]
 
 
 def _dt_tiles(tiles):
@@ -864,7 +864,7 @@ def test_ddim_three_way_guidance(hip, emu, dt):
 
 
 # ---- statistics fused into the producing epilogue (fyc_gemm chan_stats / row_parts, fyc_gn_apply_cs) --------------------------
-STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 21, 22, 23]
+STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 21, 22, 23, 31]
 
 
 @pytest.mark.parametrize("dt,tile", [("bf16", t) for t in STAT_TILES] + [("f32", 0)])
@@ -981,7 +981,7 @@ def test_groupnorm_apply_from_channel_sums(hip, emu, dt, samples, rps, C1, C2, s
 
 
 # ---- ping-pong main loop (csrc/gemm_pp_kernel.h: tile configs 21 / 22 / 23) -------------------------------------------------------
-PP_TILES = [21, 22, 23]
+PP_TILES = [21, 22, 23, 31]       # 31: the overlapped-epilogue kernel (csrc/gemm_ov_kernel.h) takes the same streams
 
 
 @pytest.mark.parametrize("tile", PP_TILES)
@@ -997,8 +997,8 @@ PP_TILES = [21, 22, 23]
 def test_gemm_pingpong_plain(hip, emu, tile, M, N, K, feat):
     """the ping-pong K loop against the specification on streams of many tiles per workgroup, every epilogue family"""
     T = torch.bfloat16
-    if feat == "geglu" and tile == 22:
-        pytest.skip("tile 22 gives a wave an odd number of column blocks: GEGLU falls back to 21")
+    if feat == "geglu" and tile in (22, 31):
+        pytest.skip("tiles 22 / 31 give a wave an odd number of column blocks: GEGLU runs on the 256x320 tile")
     a, w = rnd((M, K), T, 1), rnd((N, K), T, 2, 1 / math.sqrt(K))
     bias = rnd((N,), torch.float32, 3)
     kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N)
@@ -1065,6 +1065,68 @@ def test_gemm_pingpong_conv(hip, emu, tile, mode, stride, frames, H, W, Cin, Cou
     o_e = torch.zeros(M, Cout, dtype=T)
     emu.gemm(x, w, o_e, bias=bias, rowbias=rowb, residual=res, **kw)
     close(o_h, o_e, f"pp conv mode={mode} s={stride} {frames}x{H}x{W} {Cin}->{Cout} tile {tile}", RTOL["bf16"])
+
+
+@pytest.mark.parametrize("tile", [31, 6, 5])
+@pytest.mark.parametrize("kind,M,N,K,feat", [
+    ("gemm", 40064, 640, 640, "res+stats"),            # 313 row tiles x 2 column tiles: several tiles per workgroup, statistics published under the next tile
+    ("gemm", 33000, 1920, 640, "ln+rb256"),            # LayerNorm fold + a per-frame row bias that is uniform per tile
+    ("gemm", 8192, 3840, 1280, "ln+rb64"),             # ... and one that changes inside a tile (two rows per 128-row tile)
+    ("gemm", 20096, 320, 1600, "dual+res+stats"),      # merged FF2 | proj_out: dual-source K
+    ("conv", 36864, 320, 576, "res+rb+stats"),         # 3x3 conv, time-embedding row + residual + statistics (9 K tiles)
+    ("gemm", 2050, 320, 320, "res+stats"),             # exactly 5 K tiles (the shortest stream the kernel takes), ragged last row tile
+])
+def test_gemm_overlapped_epilogue(hip, emu, tile, kind, M, N, K, feat):
+    """csrc/gemm_ov_kernel.h (tile config 31): the previous tile's epilogue - pack, four store steps, statistics reduction and
+    publication - runs under the K loop of the next tile.  Same inputs through the one-phase kernels (tiles 6 / 5) as a cross-check
+    of the test itself; outputs against the specification, statistics against sums of the stored values."""
+    T = torch.bfloat16
+    w, bias = rnd((N, K), T, 2, 1 / math.sqrt(K)), rnd((N,), torch.float32, 3)
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N)
+    ex = {}
+    cs_rows = 0
+    if kind == "conv":
+        Cin, side = K // 9, 64
+        a = rnd((M, Cin), T, 1)
+        kw.update(lda=Cin, mode=1, conv=dict(Hout=side, Wout=side, Hin=side, Win=side, Cin=Cin, stride=1))
+    elif "dual" in feat:
+        k2 = 320
+        a = rnd((M, K - k2), T, 1)
+        ex.update(a2=rnd((M, k2), T, 7), k_split=K - k2, lda2=k2)
+        kw["lda"] = K - k2
+    else:
+        a = rnd((M, K), T, 1)
+    if "res" in feat:
+        ex["residual"] = rnd((M, N), T, 4)
+    if "ln" in feat:
+        ex["ln_stats"] = torch.stack([rnd((M,), torch.float32, 8) * 0.1, rnd((M,), torch.float32, 9).abs() + 0.5], dim=1).contiguous()
+        ex["ln_colsum"] = rnd((N,), torch.float32, 10)
+    for key, rpb in (("rb256", 256), ("rb64", 64), ("rb+", 4096)):
+        if key in feat:
+            ex.update(rowbias=rnd(((M + rpb - 1) // rpb, N), torch.float32, 5), rows_per_batch=rpb)
+    dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in ex.items()}
+    parts = None
+    if "stats" in feat:
+        cs_rows = 128 if M % 128 == 0 else 0
+        if cs_rows == 0:                      # ragged M: statistics samples must tile the rows; use the largest divisor that is a multiple of 16
+            cs_rows = next(c for c in (2048, 1024, 512, 256, 128, 64, 32, 16) if M % c == 0) if any(M % c == 0 for c in (2048, 1024, 512, 256, 128, 64, 32, 16)) else 0
+    o_h = torch.full((M, N), float("nan"), dtype=T, device="cuda")
+    if cs_rows:
+        nt, tile_rows, slots = hip.gemm_stat_layout(T, M=M, N=N, K=K, cs_rows=cs_rows, mode=kw.get("mode", 0), tile=tile)
+        if not 1 <= slots <= 4:
+            cs_rows = 0
+        else:
+            parts = torch.full((nt * slots * N * 2,), float("nan"), device="cuda")
+    hip.gemm(a.cuda(), w.cuda(), o_h, bias=bias.cuda(), tile=tile, chan_parts=parts, cs_rows=cs_rows, **dev, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(M, N, dtype=T)
+    emu.gemm(a, w, o_e, bias=bias, **ex, **kw)
+    close(o_h, o_e, f"ov {kind} {feat} {M}x{N}x{K} tile {tile}", RTOL["bf16"])
+    if cs_rows:
+        cs = torch.zeros(M // cs_rows, N, 2, dtype=torch.float64, device="cuda")
+        hip.chan_stats_reduce(parts, cs, rows=M, N=N, cs_rows=cs_rows, tile_rows=tile_rows, slots=slots)
+        v = o_h.double().reshape(M // cs_rows, cs_rows, N)
+        close(cs, torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], dim=-1).cpu(), f"ov chan stats {kind} {feat} tile {tile}", 2e-6)
 
 
 def test_gemm_pingpong_is_repeatable(hip):

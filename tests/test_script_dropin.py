@@ -10,7 +10,12 @@ checkpoint with its `module.` prefix (:170-181), `DistributedSampler` under --dd
 The latents the script's pipeline call hands to the VAE decoder are then compared with the oracle's denoising loop on the same
 weights, noise, text states and conditioning (captured at the pipeline's own method boundaries).
 
-Runs where the reference tree exists (the build container); the GPU box has no /root/reference, so the `gpu` variant is skipped there.
+Runs from the reference tree (build container) or, on the GPU box, from the byte copies `oracle/stage_ref_scripts.py` puts under the
+git-ignored oracle/_ref/ (`__graft_entry__.build()` stages them; they travel with the repo snapshot): the `gpu` variants execute
+the scripts on the HIP kernels.  Round 4 adds `scripts/inference_org.py` (plain text-to-video: prompt file, `PromptDataset`,
+motion-module checkpoint without the `state_dict` wrapper, `video_scale`) and `scripts/inference_w_image_cond.py` (first image from
+the 2-D `StableDiffusionPipeline` at its hard-coded 448x768 / 50 steps, `.ckpt` spatial weights, CLIP vision model + image
+processor construction) - unmodified, through the same scaffolding.
 """
 import os
 import runpy
@@ -133,3 +138,160 @@ def test_reference_inference_script_runs_unmodified_on_mi355x(tmp_path, monkeypa
     """the same on the HIP kernels (only where the reference tree and a GPU are on one box)"""
     seen, out_dir, run = _run_script(tmp_path, monkeypatch, device_is_gpu=True, port=29762)
     _check(seen, out_dir, run, tol=6e-2)
+
+
+# ---- scripts/inference_org.py and scripts/inference_w_image_cond.py ----------------------------------------------------------------
+def _run_t2v_script(script, tmp_path, monkeypatch, device_is_gpu: bool, port: int, extra_args, first_image: bool):
+    """both scripts: text-to-video pipeline call without first-frame conditioning (a 4-channel UNet3D); `first_image`: the script
+    also builds a 2-D StableDiffusionPipeline and synthesises a first image with it (inference_w_image_cond.py)"""
+    import followyourclick_amd
+    import yaml
+    from followyourclick_amd import ops as ops_mod
+    monkeypatch.setattr(sys, "path", list(sys.path))
+    saved_modules = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")}
+    if not device_is_gpu:
+        from emu_ops import EmuOps
+        monkeypatch.setattr(ops_mod, "impl", EmuOps())
+        E.alias_cuda_to_cpu(monkeypatch)
+    followyourclick_amd.install_dropin(force=True)
+    E.install_absent_packages(monkeypatch)
+    root = str(tmp_path)
+    # an inference YAML for plain text-to-video: the shipped one minus the mask / first-frame concat (4 input channels)
+    with open(E.REF_INFERENCE_CFG) as f:
+        icfg = yaml.safe_load(f)
+    icfg["unet_additional_kwargs"]["use_first_frame_mask_condition_concat"] = False
+    icfg_path = os.path.join(root, "inference_t2v.yaml")
+    with open(icfg_path, "w") as f:
+        yaml.safe_dump(icfg, f)
+    fab = E.fabricate_model_dir(root, inference_cfg=icfg_path, wrap_state_dict=False)
+    steps, size, frames = 2, 64, 2
+    cfg = {"TinyModel": dict(base="", path=fab["unet2d_ckpt"] if first_image else "", motion_module=[fab["motion_ckpt"]], seed=[1], steps=steps,
+                             guidance_scale=8.0, lora_alpha=0.8)}
+    cfg_path = os.path.join(root, "prompts.yaml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    prompt_file = os.path.join(root, "prompts.txt")
+    with open(prompt_file, "w") as f:
+        f.write(PROMPT + "\n")
+    for k, v in dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+
+    from animatediff.pipelines.pipeline_animation import AnimationPipeline
+    from diffusers import StableDiffusionPipeline
+    seen = {}
+    real_encode, real_prep, real_decode, real_call = (AnimationPipeline._encode_prompt, AnimationPipeline.prepare_latents,
+                                                       AnimationPipeline.decode_latents, AnimationPipeline.__call__)
+    monkeypatch.setattr(AnimationPipeline, "_encode_prompt", lambda self, *a, **k: _keep(seen, "text", real_encode(self, *a, **k)))
+    monkeypatch.setattr(AnimationPipeline, "prepare_latents", lambda self, *a, **k: _keep(seen, "noise", real_prep(self, *a, **k)))
+
+    def decode(self, latents):
+        seen["final"] = latents.detach().float().cpu().clone()
+        seen["unet_sd"] = {k: v.detach().float().cpu().clone() for k, v in self.unet.state_dict().items()}
+        return real_decode(self, latents)
+    monkeypatch.setattr(AnimationPipeline, "decode_latents", decode)
+
+    def call(self, *a, **k):
+        seen["call"] = dict(k)
+        return real_call(self, *a, **k)
+    monkeypatch.setattr(AnimationPipeline, "__call__", call)
+    if first_image:
+        real_sd_call = StableDiffusionPipeline.__call__
+
+        def sd_call(self, *a, **k):
+            seen["sd_call"] = dict(k)
+            out = real_sd_call(self, *a, **k)
+            seen["first_image_size"] = out.images[0].size
+            return out
+        monkeypatch.setattr(StableDiffusionPipeline, "__call__", sd_call)
+    if not device_is_gpu:
+        for cls in (AnimationPipeline, StableDiffusionPipeline):
+            real_to = cls.to
+            monkeypatch.setattr(cls, "to", lambda self, device, _r=real_to: _r(self, "cpu"))
+    out_dir = os.path.join(root, "out")
+    argv = [script, "--config", cfg_path, "--prompt", prompt_file, "--pretrained_model_path", root, "--inference_config", icfg_path,
+            "--L", str(frames), "--W", str(size), "--H", str(size), "--seed", "1", "--ddp"] + extra_args(root, out_dir, fab)
+    monkeypatch.setattr(sys, "argv", argv)
+    monkeypatch.chdir(root)
+    try:
+        runpy.run_path(script, run_name="__main__")
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        for k in [k for k in sys.modules if k.split(".")[0] in ("animatediff", "diffusers", "ip_adapter")]:
+            del sys.modules[k]
+        sys.modules.update(saved_modules)
+    return seen, root, out_dir, dict(steps=steps, size=size, frames=frames)
+
+
+def _keep(seen, name, value):
+    seen[name] = value.detach().float().cpu().clone()
+    return value
+
+
+def _check_t2v(seen, run, tol, video_scale=0.0):
+    from oracle import functional as Fn
+    c = seen["call"]
+    assert c["video_length"] == run["frames"] and c["num_inference_steps"] == run["steps"] and c["width"] == run["size"]
+    assert float(c.get("video_scale", 0.0)) == video_scale
+    cfg = Fn.tiny_unet_config(use_first_frame_mask_condition_concat=False)
+    with torch.no_grad():
+        ref = Fn.denoise(seen["unet_sd"], cfg, Fn.DDIMConfig(), seen["noise"], seen["text"], run["steps"], float(c["guidance_scale"]), video_scale=video_scale)
+    r = ((seen["final"] - ref).norm() / ref.norm()).item()
+    assert r < tol, r
+
+
+def _org_args(root, out_dir, fab):
+    return ["--output_path", out_dir, "--video_scale", "0.5"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(E.REF_ROOT, "scripts", "inference_org.py")), reason="scripts/inference_org.py is not on this box")
+def test_reference_inference_org_script_runs_unmodified_on_emulator(tmp_path, monkeypatch):
+    """scripts/inference_org.py (the text-to-video driver): prompt file -> PromptDataset + DistributedSampler, plain pipeline call with
+    `video_scale` (the per-frame unconditional pass and three-way guidance), GIFs + config written - on the op emulator"""
+    seen, root, out_dir, run = _run_t2v_script(os.path.join(E.REF_ROOT, "scripts", "inference_org.py"), tmp_path, monkeypatch, False, 29763, _org_args, False)
+    _check_t2v(seen, run, tol=6e-2, video_scale=0.5)
+    runs = os.listdir(out_dir)
+    assert len(runs) == 1 and os.path.getsize(os.path.join(out_dir, runs[0], "sample", f"0_{PROMPT}.gif")) > 1000
+    assert os.path.exists(os.path.join(out_dir, runs[0], "config.yaml")) and os.path.exists(os.path.join(out_dir, runs[0], "prompts.txt"))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(E.REF_ROOT, "scripts", "inference_org.py")), reason="scripts/inference_org.py is not on this box")
+def test_reference_inference_org_script_runs_unmodified_on_mi355x(tmp_path, monkeypatch):
+    seen, root, out_dir, run = _run_t2v_script(os.path.join(E.REF_ROOT, "scripts", "inference_org.py"), tmp_path, monkeypatch, True, 29764, _org_args, False)
+    _check_t2v(seen, run, tol=6e-2, video_scale=0.5)
+
+
+def _image_cond_args(root, out_dir, fab):
+    return ["--use_local_image", "--image_pretrained_model_path", fab["clip_vision_dir"]]
+
+
+def _check_image_cond(seen, root, run, tol):
+    _check_t2v(seen, run, tol=tol)
+    assert seen["sd_call"]["height"] == 448 and seen["sd_call"]["width"] == 768 and seen["sd_call"]["num_inference_steps"] == 50
+    assert seen["first_image_size"] == (768, 448)
+    assert seen["call"]["use_ip_cross_attention"] is False and tuple(seen["call"]["condition_images"].shape) == (1, 3, 224, 224)
+    runs = os.listdir(os.path.join(root, "samples"))
+    assert len(runs) == 1 and os.path.getsize(os.path.join(root, "samples", runs[0], "sample", f"0_{PROMPT}.gif")) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(E.REF_ROOT, "scripts", "inference_w_image_cond.py")), reason="scripts/inference_w_image_cond.py is not on this box")
+def test_reference_inference_w_image_cond_script_runs_unmodified_on_mi355x(tmp_path, monkeypatch):
+    script = os.path.join(E.REF_ROOT, "scripts", "inference_w_image_cond.py")
+    seen, root, out_dir, run = _run_t2v_script(script, tmp_path, monkeypatch, True, 29766, _image_cond_args, True)
+    _check_image_cond(seen, root, run, tol=6e-2)
+
+
+@pytest.mark.skipif(os.environ.get("FYC_SLOW_TESTS") != "1", reason="6 minutes on the op emulator (the script hard-codes a 50-step 768x448 first image): FYC_SLOW_TESTS=1; "
+                                                                      "the `gpu` variant above runs it on every GPU box")
+@pytest.mark.skipif(not os.path.exists(os.path.join(E.REF_ROOT, "scripts", "inference_w_image_cond.py")), reason="scripts/inference_w_image_cond.py is not on this box")
+def test_reference_inference_w_image_cond_script_runs_unmodified_on_emulator(tmp_path, monkeypatch):
+    """scripts/inference_w_image_cond.py without --use_ip: the 2-D UNet gets its weights from a `.ckpt` (with the `module.` prefix
+    the script strips), StableDiffusionPipeline synthesises the first image at the script's hard-coded 768x448 / 50 steps,
+    CLIPImageProcessor + CLIPVisionModelWithProjection are constructed and the image is pre-processed, then the video pipeline runs
+    (its `condition_images` are ignored without `use_ip_cross_attention`, as in the reference).  `samples/` is the script's own
+    hard-coded output directory (relative to the working directory)."""
+    script = os.path.join(E.REF_ROOT, "scripts", "inference_w_image_cond.py")
+    seen, root, out_dir, run = _run_t2v_script(script, tmp_path, monkeypatch, False, 29765, _image_cond_args, True)
+    _check_image_cond(seen, root, run, tol=6e-2)
