@@ -394,28 +394,34 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
 // the residual tile into the accumulators (MFMA layout: a lane holds 4 consecutive channels of a row), before the K loop
 template <typename T, int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n, int wave, int lane) {
-  // every load is issued (rows / columns outside the problem read the zero page) so that the loads of a row block are in flight
-  // together: behind a per-element `if (inside)` hipcc waited for each load before issuing the next - 20 dependent round trips,
-  // 21 000 cycles per 128x320 tile (profiles/r04_gemm_phase_trace.txt, column `gap`)
+  // ALL loads of the wave are issued before the first one is converted (the accumulators are free: the raw words need no registers
+  // of their own), and every load is issued - rows / columns outside the problem read the zero page.  History (profiles/
+  // r04_gemm_phase_trace.txt, column `gap`): behind a per-element `if (inside)` hipcc waited for each load before issuing the next
+  // (21 000 cycles per 128x320 tile); one batch per row block still meant four dependent round trips (14 600 / 24 800 cycles).
+  // (Spreading the chunks over the first K-tile iterations instead - tried - makes the accumulator index a run-time value: hipcc
+  // merges the per-chunk cases into one body with a computed address and moves the accumulator array to scratch.)
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
   const int wm = wave / WGN, wn = wave % WGN;
   const int g = lane >> 4, r16 = lane & 15;
   const T* R = reinterpret_cast<const T*>(p.residual);
   const T* zero = reinterpret_cast<const T*>(p.zero);
+  u32x2 raw[WTM][WTN];
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
     const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
-    u32x2 raw[WTN];
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
       const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
       const T* ptr = (m < p.M && n < p.N) ? R + ((long long)m * p.ldr + n) : zero;
-      raw[j] = *reinterpret_cast<const u32x2*>(ptr);
+      raw[i][j] = *reinterpret_cast<const u32x2*>(ptr);
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int j = 0; j < WTN; ++j)
-      acc[i][j] = (f32x4){__uint_as_float(raw[j][0] << 16), __uint_as_float(raw[j][0] & 0xffff0000u), __uint_as_float(raw[j][1] << 16), __uint_as_float(raw[j][1] & 0xffff0000u)};
-  }
+      acc[i][j] = (f32x4){__uint_as_float(raw[i][j][0] << 16), __uint_as_float(raw[i][j][0] & 0xffff0000u), __uint_as_float(raw[i][j][1] << 16), __uint_as_float(raw[i][j][1] & 0xffff0000u)};
 }
 
 // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j).
