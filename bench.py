@@ -14,8 +14,11 @@ scaling : weak - every rank denoises its own clips; the only collective is the o
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
 Adds to the JSON line: "roofline" (dominant kernel = the MFMA GEMM/implicit-conv family, timed per launch
-with HIP events in an instrumented extra pass) and "cpu_baseline" (the CPU oracle, one of the 25 steps at
-the same shape on the host cores; rank 0, N=1 only).
+with HIP events in an instrumented extra pass; on every configuration's line), with --vae "roofline_vae"
+(the same family inside the VAE decode) and "cpu_baseline" (the CPU oracle, one DDIM step at the same
+resolution on a bounded number of frames, threads bound to one NUMA node; rank 0, N=1 only).
+`metric` and `config.workload` are derived from the arguments: only the default arguments produce BASELINE.json's
+configs[1] line.
 """
 import argparse
 import json
@@ -50,54 +53,89 @@ def synthetic_inputs(cfg, frames, h, w, seed, device):
     return dict(latents=lat.to(device), first=first.to(device), mask=mask.to(device), text=text.to(device))
 
 
-def physical_cores() -> int:
-    """host cores without SMT siblings (the oracle's matmuls do not gain from hyper-threads; 128 logical threads on the round-2
-    box ran a 2-frame forward slower per frame than 8 cores run the 16-frame one)"""
+def numa_node_cores(node: int = 0):
+    """(logical cpu ids of the physical cores of one NUMA node - one SMT sibling each -, logical cpus of the host).  The oracle's
+    fp32 matmuls gain nothing from hyper-threads and LOSE from threads spread over sockets: on the round-3 box 128 threads took
+    10.9 s per frame where BASELINE.md's 8 cores take 6.5 s."""
+    def parse(txt):
+        out = []
+        for part in txt.strip().split(","):
+            if "-" in part:
+                lo, hi = part.split("-")
+                out.extend(range(int(lo), int(hi) + 1))
+            elif part:
+                out.append(int(part))
+        return out
     try:
-        seen = set()
-        for d in os.listdir("/sys/devices/system/cpu"):
-            if d.startswith("cpu") and d[3:].isdigit():
-                with open(f"/sys/devices/system/cpu/{d}/topology/thread_siblings_list") as f:
-                    seen.add(f.read().strip())
-        if seen:
-            return len(seen)
+        allowed = set(os.sched_getaffinity(0))
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = [c for c in parse(f.read()) if c in allowed]
+        firsts = []
+        for c in cpus:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                if min(parse(f.read())) == c:
+                    firsts.append(c)
+        if firsts:
+            return firsts, os.cpu_count() or len(cpus)
     except OSError:
         pass
-    return max(1, (os.cpu_count() or 2) // 2)
+    n = os.cpu_count() or 2
+    return list(range(max(1, n // 2))), n
 
 
-def cpu_baseline(sd, frames, h, w, ddim_steps, sample_frames=2, timed=1):
-    """The oracle (CPU port of the reference math, fp32) per BASELINE.md 3, threads pinned to the physical cores: 1 warm-up + `timed`
-    timed CFG-pair UNet3D forwards (= DDIM steps) at the benchmark resolution, on a BOUNDED sample of `sample_frames` of the clip's
-    frames (the conv / spatial-attention cost is linear in the frame count; a full 16-frame step takes minutes), extrapolated
-    x frames x ddim_steps."""
+CPU_THREADS_MAX = 32          # past ~32 threads the oracle's many small ops stop scaling (see DESIGN.md, measurement)
+CPU_BUDGET_S = 30.0           # bounded sample: about this much timed CPU work
+REFERENCE_CPU_S_PER_FRAME = 6.5   # BASELINE.md 3: the reference's own CPU path, 8 cores, seconds per frame per DDIM step at 512^2
+
+
+def cpu_baseline(sd, frames, h, w, ddim_steps):
+    """The oracle (CPU port of the reference math, fp32) per BASELINE.md 3: CFG-pair UNet3D forwards (= DDIM steps) at the benchmark
+    resolution with the threads BOUND to the physical cores of NUMA node 0 (at most CPU_THREADS_MAX).  A 1-frame forward warms up
+    and calibrates; the timed forward then runs on as many of the clip's frames as fit ~CPU_BUDGET_S (the conv / spatial-attention
+    cost is linear in the frame count, the temporal attention is < 1 % of it), and frames/s = frames_timed / (ddim_steps x time)."""
     from oracle import functional as Fn  # test infrastructure: used only as the reported CPU baseline
     cfg = Fn.UNetConfig()
     g = torch.Generator().manual_seed(1)
-    total_frames, frames = frames, min(frames, sample_frames)
-    x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g)
     text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
-    before = torch.get_num_threads()
-    cores = min(physical_cores(), before) if before > 0 else physical_cores()
-    torch.set_num_threads(cores)
-    times = []
+    cores, logical = numa_node_cores(0)
+    cores = cores[:CPU_THREADS_MAX]
+    before_threads = torch.get_num_threads()
+    before_aff = os.sched_getaffinity(0)
     try:
-        with torch.no_grad():
-            for i in range(1 + timed):
-                t0 = time.time()
+        os.sched_setaffinity(0, set(cores))
+        torch.set_num_threads(len(cores))
+
+        def fwd(n, i):
+            x9 = torch.randn(2, cfg.conv_in_channels, n, h, w, generator=g)
+            t0 = time.time()
+            with torch.no_grad():
                 Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961 - 40 * i), text, fps, flow)
-                times.append(time.time() - t0)
+            return time.time() - t0
+        t1 = fwd(1, 0)
+        n = max(1, min(frames, int(CPU_BUDGET_S / max(t1, 1e-3))))
+        dt = fwd(n, 1)
     finally:
-        torch.set_num_threads(before)
-    dt = sum(times[1:]) / timed
-    return dict(value=frames / (ddim_steps * dt), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 warm-up ({times[0]:.1f}s) + {timed} timed DDIM step(s) (mean {dt:.1f}s) on {frames} of the {total_frames} frames: CFG-pair "
-                       f"UNet3D forward at {h * 8}x{w * 8}, fp32 oracle, torch.set_num_threads({cores}) = physical cores of {os.cpu_count()} logical; "
-                       f"frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
+        os.sched_setaffinity(0, before_aff)
+        torch.set_num_threads(before_threads)
+    return dict(value=n / (ddim_steps * dt), unit="frames/s", cores=len(cores), kind="port", s_per_frame_per_ddim_step=round(dt / n, 2),
+                reference_cpu_s_per_frame_per_ddim_step=REFERENCE_CPU_S_PER_FRAME,
+                sample=f"1 DDIM step (CFG-pair UNet3D forward at {h * 8}x{w * 8}, fp32 oracle) on {n} of the {frames} frames in {dt:.1f}s = {dt / n:.2f} s/frame "
+                       f"(BASELINE.md: the reference's CPU path, 8 cores, {REFERENCE_CPU_S_PER_FRAME} s/frame), after a 1-frame warm-up ({t1:.1f}s); {len(cores)} threads bound to "
+                       f"physical cores of NUMA node 0 ({logical} logical cpus on the host); frames/s = {n} / ({ddim_steps} x {dt:.1f}s)")
 
 
-def main():
+def workload_label(args):
+    """BASELINE.json's configs entry these arguments reproduce, or 'custom'"""
+    key = (args.frames, args.size, args.ddim_steps, args.ip_tokens)
+    names = {(8, 256, 5, 0): "configs[0]", (16, 512, 25, 0): "configs[1]", (32, 768, 50, 0): "configs[3]", (16, 512, 25, 16): "configs[4]"}
+    return names.get(key, "custom (no BASELINE.json config)")
+
+
+def main(argv=None, emulation=None):
+    """emulation: None in the product.  tests/bench_emulated.py passes {"ops": <op emulator>, "cfg": <tiny UNet3DConfig>} to drive
+    this same entry point (rendezvous, barrier, max-over-ranks timing, JSON line) with gloo on CPU ranks; its line says
+    "data": "emulated" and is no measurement."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed clips per GPU (one step = one 25-step DDIM clip)")
@@ -111,21 +149,16 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay DDIM steps 1..n-1 from one captured hipGraph (A/B vs eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     rank, world, local = D.init_from_env()
     if world != args.gpus:
         if rank == 0 and world > 1:
             print(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
-    # FYC_BENCH_EMULATE=1 is a TEST switch (tests/test_distributed_cpu.py only): the same entry point, rendezvous, barrier and
-    # max-over-ranks timing with gloo on the CPU and the op emulator under tests/ at tiny widths - so that the N > 1 launch path is
-    # exercised before the first multi-GPU node sees it.  Its line is marked "data": "emulated" and is no measurement.
-    emulate = os.environ.get("FYC_BENCH_EMULATE") == "1"
+    emulate = emulation is not None
     if emulate:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from emu_ops import EmuOps
         from followyourclick_amd import ops as ops_mod
-        ops_mod.impl = EmuOps()
+        ops_mod.impl = emulation["ops"]
         device = torch.device("cpu")
         sync = lambda: None      # noqa: E731
     else:
@@ -138,7 +171,7 @@ def main():
 
     cfg = UNet3DConfig(use_ip_cross_attention=args.ip_tokens > 0, ip_num_tokens=max(args.ip_tokens, 4))
     if emulate:
-        cfg = UNet3DConfig(block_out_channels=(64, 128, 256, 256), cross_attention_dim=64, sample_size=8)
+        cfg = emulation["cfg"]
     if args.frames > cfg.temporal_position_encoding_max_len:
         cfg.temporal_position_encoding_max_len = args.frames
     schema = unet_schema(cfg)
@@ -190,15 +223,16 @@ def main():
     if rank == 0:
         value = world * args.frames * args.steps / elapsed
         result = {
-            "metric": "denoised frames/sec, 16f x 512^2 clip @ 25 DDIM steps", "value": round(value, 3), "unit": "frames/s",
+            "metric": f"denoised frames/sec, {args.frames}f x {args.size}^2 clip @ {args.ddim_steps} DDIM steps", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "emulated" if emulate else "synthetic",
             "clips_per_sec": round(world * args.steps / elapsed, 4),
             "host_launch_ms_per_ddim_step": round(host_ms, 2), "gpu_ms_per_ddim_step": round(1000 * elapsed / (args.steps * args.ddim_steps), 2),
-            "config": {"workload": f"configs[1]: AnimationPipeline DDIM loop, SD-1.5 UNet3D + mm_sd_v15-shaped motion modules "
+            "config": {"workload": f"{workload_label(args)}: AnimationPipeline DDIM loop, SD-1.5 UNet3D + mm_sd_v15-shaped motion modules "
                                    f"(random init), 1 clip/GPU of {args.frames} frames {args.size}x{args.size}, {args.ddim_steps} DDIM steps, "
-                                   f"CFG 8.0, mask + first-frame concat, fps/flow conditioning",
-                       "frames": args.frames, "height": args.size, "width": args.size, "ddim_steps": args.ddim_steps,
+                                   f"CFG 8.0, mask + first-frame concat, fps/flow conditioning"
+                                   + (f", IP-Adapter decoupled cross-attention with {args.ip_tokens} image tokens" if args.ip_tokens > 0 else ""),
+                       "frames": args.frames, "height": args.size, "width": args.size, "ddim_steps": args.ddim_steps, "ip_tokens": args.ip_tokens,
                        "parallelism": f"dp{world} (independent clips, weight broadcast {moved / 2**30:.2f} GiB in {t_b:.2f}s)"},
         }
 
@@ -305,6 +339,24 @@ def main():
         torch.cuda.synchronize()
         result["vae_decode_ms"] = round(1000 * (time.time() - tv), 1)
         result["end_to_end_frames_per_sec"] = round(args.frames / (elapsed / args.steps + result["vae_decode_ms"] / 1000), 3)
+        if not args.no_roofline:     # the decode's dominant kernel = the same GEMM / implicit-conv family, timed per launch
+            tvae = TimedOps(vae.ops)
+            vae.ops = tvae
+            torch.cuda._sleep(100_000_000)
+            vae.decode_video(out)
+            torch.cuda.synchronize()
+            vs = tvae.summary()
+            vae.ops = tvae.inner
+            vm = {k: v for k, v in vs.items() if k in ("gemm", "conv3x3")}
+            vfl, vms, vl = sum(v["flops"] for v in vm.values()), sum(v["ms"] for v in vm.values()), sum(v["launches"] for v in vm.values())
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            result["roofline_vae"] = {"kernel": "fyc_gemm_kernel inside VAEDecoderEngine.decode_video (implicit-GEMM conv3x3 + 1x1 / attention linears)",
+                                      "bound": "mfma", "achieved": round(vfl / (vms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                                      "frac": round(vfl / (vms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                                      "launches_per_decode": vl, "avg_launch_us": round(1e3 * vms / vl, 2), "family_ms_per_decode": round(vms, 2),
+                                      "algorithmic_tflop_per_decode": round(vfl / 1e12, 3),
+                                      "algorithmic_bytes_per_launch": round(sum(v["bytes"] for v in vm.values()) / vl),
+                                      "kernel_families": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in sorted(vs.items(), key=lambda kv: -kv[1]["ms"])}}
         assert torch.isfinite(vid).all()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emulate and os.environ.get("FYC_BENCH_CPU", "1") != "0":

@@ -45,7 +45,8 @@ class TAttnArgs(C.Structure):
 
 
 class GnStatsArgs(C.Structure):
-    _fields_ = [("x", vp), ("stats", vp), ("rows", i32), ("C", i32), ("groups", i32), ("rows_per_sample", i32), ("dtype", i32)]
+    _fields_ = [("x", vp), ("stats", vp), ("rows", i32), ("C", i32), ("groups", i32), ("rows_per_sample", i32), ("dtype", i32),
+                ("pad_", i32), ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class GnApplyArgs(C.Structure):
@@ -155,7 +156,7 @@ OPS = {
     "fyc_pack_conv3x3": PackConv3x3Args, "fyc_pack_geglu": PackGegluArgs, "fyc_temporal_block": TemporalBlockArgs,
     "fyc_ff_block": FFBlockArgs, "fyc_panel_linear": PanelLinearArgs,
 }
-MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_temporal_block_supported", "fyc_temporal_block_wstream_bytes",
+MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set_tuning", "fyc_gemm_row_parts", "fyc_gemm_stat_layout", "fyc_gemm_workspace_bytes", "fyc_gn_stats_workspace", "fyc_temporal_block_supported", "fyc_temporal_block_wstream_bytes",
         "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
@@ -191,6 +192,8 @@ def load() -> C.CDLL:
         lib.fyc_gemm_stat_layout.restype = C.c_int
         lib.fyc_gemm_workspace_bytes.argtypes = [C.POINTER(GemmArgs)]
         lib.fyc_gemm_workspace_bytes.restype = i64
+        lib.fyc_gn_stats_workspace.argtypes = [C.POINTER(GnStatsArgs)]
+        lib.fyc_gn_stats_workspace.restype = i64
     if not ab_build or hasattr(lib, "fyc_temporal_block_supported"):
         lib.fyc_temporal_block_supported.argtypes = [C.POINTER(TemporalBlockArgs)]
         lib.fyc_temporal_block_supported.restype = C.c_int

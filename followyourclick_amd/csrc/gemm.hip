@@ -86,7 +86,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // overlapped-epilogue kernel (gemm_ov_kernel.h, tile config 31 = 128x320): key 9 = 3 takes it for every N = 320 k problem the
   // library would give a 256x320 / 128x320 tile; fyc_gemm() falls back to 6 when the problem does not qualify
   if (g_fyc_tuning[9] == 3 && tile <= 0 && g_fyc_tuning[1] <= 0 && (cfg == 5 || cfg == 6) && p.epilogue == FYC_EPI_LINEAR) cfg = 31;
-  if (cfg != 1 || ns != 3) ns = 2;   // only config 1 is also built 3-deep
+  if (!((cfg == 1 && ns == 3) || (cfg == 2 && (ns == 3 || ns == 4) && p.mode == FYC_GEMM_PLAIN))) ns = 2;   // deeper rings: config 1 (3) and, for linears, config 2 (3, 4)
 }
 // the one-phase twin of a ping-pong tile config (same tile, same wave grid)
 int pp_twin(int cfg) { return cfg == 21 ? 5 : cfg == 22 ? 6 : cfg == 23 ? 7 : cfg == 31 ? 6 : cfg; }
@@ -188,7 +188,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   FYC_REQUIRE(a->ln_nparts >= 0 && (a->ln_nparts == 0 || (a->ln_stats != nullptr && a->a2 == nullptr)), "fyc_gemm: ln_nparts=%d needs ln_stats (and no a2)", a->ln_nparts);
   p.chan_parts = a->chan_parts; p.cs_rows = a->cs_rows; p.row_parts = a->row_parts; p.row_nparts = a->row_nparts;
   if (a->chan_parts != nullptr || a->row_parts != nullptr) {
-    FYC_REQUIRE(a->epilogue == FYC_EPI_LINEAR && (a->batch <= 1), "fyc_gemm: output statistics need the LINEAR epilogue without batch");
+    FYC_REQUIRE(a->epilogue == FYC_EPI_LINEAR && (a->batch <= 1) && (a->dtype == FYC_F32 || a->act == FYC_ACT_NONE), "fyc_gemm: output statistics need the LINEAR epilogue without batch (bf16: without activation)");
     int32_t bm = 0, slots = 0;
     if (a->chan_parts != nullptr) (void)fyc_gemm_stat_layout(a, &bm, &slots);
     p.cs_slots = slots;

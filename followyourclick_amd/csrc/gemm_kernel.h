@@ -133,32 +133,56 @@ template <int RB> __device__ __forceinline__ int swz_key(int row) {
 }
 
 // ---- output statistics (fused GroupNorm / LayerNorm statistics passes) ----------------------------------------------------
-// LDS accumulators of one output tile, placed behind the column constants: cacc[STAT_SLOTS][BN][2] per (sample slot, column)
-// and racc[BM][2] per row.  A tile of BM rows touches at most STAT_SLOTS samples (host: cs_rows % 16 == 0 and 64 or >= 128).
+// LDS accumulators of one output tile, placed behind the column constants: cacc[stat_arrays][BN][2] per column and racc[BM][2]
+// per row.  A tile of BM rows touches at most STAT_SLOTS samples (host: cs_rows % 16 == 0, fyc_gemm_stat_layout).
+//
+// The column sums are ORDER-FREE (bitwise repeatable, no atomics): every (wave row wm, sample slot) pair that occurs in a tile
+// owns one accumulator array, index wm + slot (rows, hence both wm and slot, only grow, so the sum is unique; at most
+// WGM + STAT_SLOTS - 1 pairs), ONE wave writes a given (array, column) with plain stores in program order, and stats_flush adds
+// the arrays of a slot in wave-row order.  (Round 3 used LDS float atomics here: the order the waves arrived in moved the last
+// bits of the GroupNorm statistics from run to run.)  The per-row sums (row_parts, off in the engine) still use LDS atomics.
 constexpr int STAT_SLOTS = 4;
 constexpr int RB_SLOTS = 4;     // rowbias rows a tile may touch in the packed LINEAR epilogue (GemmP::rb_slots)
-template <int BM, int BN> constexpr int stat_bytes() { return (STAT_SLOTS * BN * 2 + BM * 2) * 4; }
+template <int WGM> constexpr int stat_arrays() { return WGM + STAT_SLOTS - 1; }
+template <int BM, int BN, int WGM> constexpr int stat_bytes() { return (stat_arrays<WGM>() * BN * 2 + BM * 2) * 4; }
 
 __device__ __forceinline__ void lds_add(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int BM, int BN, int NT>
+template <int BM, int BN, int WGM, int NT>
 __device__ __forceinline__ void stats_zero(float* cacc, int tid) {
-  for (int i = tid; i < STAT_SLOTS * BN * 2 + BM * 2; i += NT) cacc[i] = 0.f;
+  for (int i = tid; i < stat_arrays<WGM>() * BN * 2 + BM * 2; i += NT) cacc[i] = 0.f;
 }
 
-// after every wave finished accumulating: plain stores of the tile's partial sums (no atomics: 640 device-scope f64 atomics per
-// tile, 327 K per launch, cost the 64x64 convs +77 us each); fyc_chan_stats_reduce adds the row tiles of a sample up
-template <int BM, int BN, int NT>
+// after every wave finished accumulating: the arrays of a sample slot are added in wave-row order and stored as the tile's partial
+// sums with plain stores (no device atomics: 640 f64 atomics per tile, 327 K per launch, cost the 64x64 convs +77 us each);
+// fyc_chan_stats_reduce adds the row tiles of a sample up
+template <int BM, int BN, int WGM, int NT>
 __device__ __forceinline__ void stats_flush(const GemmP& p, const float* cacc, int tile_m, int tile_n, int tid) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  const float* racc = cacc + STAT_SLOTS * BN * 2;
+  const float* racc = cacc + stat_arrays<WGM>() * BN * 2;
   if (p.chan_parts != nullptr) {
+    constexpr int R = BM / WGM;
+    const int first = (tile_m * BM) / p.cs_rows;
+    int lo[WGM], hi[WGM];                              // sample slots wave row w touches
+#pragma unroll
+    for (int w = 0; w < WGM; ++w) {
+      lo[w] = (tile_m * BM + w * R) / p.cs_rows - first;
+      hi[w] = (tile_m * BM + w * R + R - 1) / p.cs_rows - first;
+    }
     for (int i = tid; i < p.cs_slots * BN; i += NT) {
       const int slot = i / BN, col = i - slot * BN, n = tile_n * BN + col;
-      if (n < p.N) *reinterpret_cast<float2*>(p.chan_parts + (((long long)tile_m * p.cs_slots + slot) * p.N + n) * 2) = *reinterpret_cast<const float2*>(cacc + 2 * i);
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) {
+        if (slot >= lo[w] && slot <= hi[w]) {
+          const float2 v = *reinterpret_cast<const float2*>(cacc + ((w + slot) * BN + col) * 2);
+          s += v.x; q += v.y;
+        }
+      }
+      if (n < p.N) *reinterpret_cast<float2*>(p.chan_parts + (((long long)tile_m * p.cs_slots + slot) * p.N + n) * 2) = make_float2(s, q);
     }
   }
   if (p.row_parts != nullptr) {
@@ -232,7 +256,7 @@ __device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc,
 //     256x320 tile instead of 8 half-width f32 ones) and stores / accumulates the statistics from 16-byte row segments as before.
 template <typename T, int BM, int BN, int WGM, int WGN, int STG_BYTES, int MODE>
 __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
-                                                       char* stg_stage, int wave, int lane) {
+                                                       long long bz, char* stg_stage, int wave, int lane) {
   static_assert(sizeof(T) == 2, "bf16 only");
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
   constexpr bool LN = (MODE == FYC_GEMM_PLAIN);
@@ -243,20 +267,20 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   // a wave's staging slice: 16 staged rows, and at least the 64 lanes x 8 floats the column-statistics reduction parks in it
   constexpr int SLICE = 16 * PITCH > 2048 ? 16 * PITCH : 2048;
   static_assert(WGM * WGN * SLICE + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
-  constexpr bool STATS_FIT = WGM * WGN * SLICE + 2 * BN * 4 + stat_bytes<BM, BN>() <= STG_BYTES;
+  constexpr bool STATS_FIT = WGM * WGN * SLICE + 2 * BN * 4 + stat_bytes<BM, BN, WGM>() <= STG_BYTES;
   const int wm = wave / WGN, wn = wave % WGN;
   const int g = lane >> 4, r16 = lane & 15;
-  T* O = reinterpret_cast<T*>(p.out);
+  T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;   // batched problems (materialised attention of the VAE): one output per batch element
   __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
   char* stg = stg_stage + wave * SLICE;
   float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * SLICE);   // [2][BN], see stage_col_constants
   float* cacc = colc + 2 * BN;
-  float* racc = cacc + STAT_SLOTS * BN * 2;
+  float* racc = cacc + stat_arrays<WGM>() * BN * 2;
   const bool do_cs = STATS_FIT && p.chan_parts != nullptr, do_rp = STATS_FIT && p.row_parts != nullptr;
   // rowbias rows that change inside the tile (per-frame rows at the 8x8 level): behind the statistics accumulators
-  constexpr bool RB_FIT = WGM * WGN * SLICE + 2 * BN * 4 + stat_bytes<BM, BN>() + RB_SLOTS * BN * 4 <= STG_BYTES;
+  constexpr bool RB_FIT = WGM * WGN * SLICE + 2 * BN * 4 + stat_bytes<BM, BN, WGM>() + RB_SLOTS * BN * 4 <= STG_BYTES;
   float* rbc = (RB_FIT && p.rb_slots > 0) ? racc + BM * 2 : nullptr;
-  if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);
+  if (do_cs || do_rp) stats_zero<BM, BN, WGM, WGM * WGN * 64>(cacc, wave * 64 + lane);
   stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane, rbc);
   const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
   const int nl_w0 = wn * WTN * 16;                   // ... inside the tile
@@ -316,23 +340,44 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   float cs8[8], cq8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
-  int cur_slot = -1;
-  auto flush_cols = [&]() {                           // tiles that span statistics samples (8x8 frames): per-lane LDS atomics, few and small launches
-    if (do_cs && lact && cur_slot >= 0) {
-      float* dst = cacc + ((cur_slot * BN) + nl_w0 + lch * 8) * 2;
+  int cur_slot = one_slot ? 0 : -1;
+  // The wave's column sums of one sample slot go to the accumulator array this (wave row, slot) pair owns (see stats_flush): lanes
+  // park their 8 sums in the idle staging slice ([lrow][lch][8] = lane * 8 floats), then one lane per column adds the rows of its
+  // column in order and stores the total - no atomics, a handful of registers (round 2: a shuffle tree cost the K loop its registers).
+  // Called where the slot changes (tiles that span samples: 8x8 / 12x12 / 24x24 frames) and after the last row block.
+  auto flush_tree = [&](int slot) __attribute__((always_inline)) {
+    float* red = reinterpret_cast<float*>(stg);
+    float* own = cacc + (wm + slot) * (BN * 2);
+    constexpr int NCOL = CPR * 8, ROWS_LIVE = RPP < 16 ? RPP : 16;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { lds_add(dst + 2 * e, cs8[e]); lds_add(dst + 2 * e + 1, cq8[e]); cs8[e] = cq8[e] = 0.f; }
+    for (int ph = 0; ph < 2; ++ph) {
+      if (lact) {
+        const float* src = ph ? cq8 : cs8;
+        *reinterpret_cast<f32x4*>(red + lane * 8) = (f32x4){src[0], src[1], src[2], src[3]};
+        *reinterpret_cast<f32x4*>(red + lane * 8 + 4) = (f32x4){src[4], src[5], src[6], src[7]};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+      for (int c = lane; c < NCOL; c += 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROWS_LIVE; ++r) t += red[r * NCOL + c];
+        own[(nl_w0 + c) * 2 + ph] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
   };
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
+    if (do_cs && !one_slot) {                          // sample slot of this 16-row block (wave-uniform); the staging slice is idle here
+      const int slot = (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample;
+      if (slot != cur_slot) { if (cur_slot >= 0) flush_tree(cur_slot); cur_slot = slot; }
+    }
 #pragma unroll
     for (int j = 0; j < WTN; ++j) *reinterpret_cast<u32x2*>(stg + r16 * PITCH + j * 32 + g * 8) = pk[i][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (do_cs && !one_slot) {                          // sample slot of this 16-row block (wave-uniform)
-      const int slot = (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample;
-      if (slot != cur_slot) { flush_cols(); cur_slot = slot; }
-    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int row = q * RPP + lrow;
@@ -361,34 +406,8 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  if (do_cs) {
-    if (one_slot) {
-      // the wave's staging slice is idle: lanes park their 8 sums in it ([lrow][lch][8] = lane * 8 floats), then one lane per column adds
-      // the rows of its column - no same-address atomics, a handful of registers (round 2: a shuffle tree cost the K loop its registers)
-      float* red = reinterpret_cast<float*>(stg);
-      constexpr int NCOL = CPR * 8, ROWS_LIVE = RPP < 16 ? RPP : 16;
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        if (lact) {
-          const float* src = ph ? cq8 : cs8;
-          *reinterpret_cast<f32x4*>(red + lane * 8) = (f32x4){src[0], src[1], src[2], src[3]};
-          *reinterpret_cast<f32x4*>(red + lane * 8 + 4) = (f32x4){src[4], src[5], src[6], src[7]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 1
-        for (int c = lane; c < NCOL; c += 64) {
-          float t = 0.f;
-#pragma unroll
-          for (int r = 0; r < ROWS_LIVE; ++r) t += red[r * NCOL + c];
-          lds_add(cacc + (nl_w0 + c) * 2 + ph, t);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    } else {
-      flush_cols();
-    }
-  }
-  if (do_cs || do_rp) stats_flush<BM, BN, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
+  if (do_cs) flush_tree(cur_slot);
+  if (do_cs || do_rp) stats_flush<BM, BN, WGM, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
 }
 
 // the residual tile into the accumulators (MFMA layout: a lane holds 4 consecutive channels of a row), before the K loop
@@ -514,7 +533,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     return;
   }
   if constexpr (WIDE && EPI == FYC_EPI_LINEAR) {
-    epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, stg_stage, wave, lane);
+    epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, bz, stg_stage, wave, lane);
     return;
   }
   if constexpr (WIDE && EPI != FYC_EPI_HEADS && EPI != FYC_EPI_LINEAR) {
@@ -527,7 +546,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     constexpr int OT = GLU ? WTN / 2 : WTN;            // 16-column output tiles per wave
     constexpr int JG = (OT + 1) / 2;                   // output tiles per pass
     constexpr int PITCH = JG * 64 + 16;                // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
-    constexpr bool STATS_FIT = WGM * WGN * 16 * PITCH + 2 * BN * 4 + stat_bytes<BM, BN>() <= STG_BYTES;
     static_assert(WGM * WGN * 16 * PITCH + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
     char* stg = stg_stage + wave * (16 * PITCH);
@@ -535,13 +553,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     const int o_w0 = GLU ? (n_w0 >> 1) : n_w0;         // first output column of this wave
     const int n_out = GLU ? (p.N >> 1) : p.N;
     float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * 16 * PITCH);   // [2][BN], see stage_col_constants
-    // output statistics (LINEAR): per-(sample, column) and per-row {sum, sum sq} of the values as stored, see stats_flush
-    float* cacc = colc + 2 * BN;
-    float* racc = cacc + STAT_SLOTS * BN * 2;
-    const bool do_cs = !GLU && STATS_FIT && p.chan_parts != nullptr, do_rp = !GLU && STATS_FIT && p.row_parts != nullptr;
-    if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);
+    // (no output statistics here: fyc_gemm() only takes chan_parts / row_parts with the plain LINEAR epilogue)
     stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
-    const int first_sample = do_cs ? (tile_m * BM) / p.cs_rows : 0;
     float ln_mu[WTM], ln_rs[WTM];
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
@@ -561,47 +574,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
       const int rpp = 64 / cpr;                         // rows per store instruction
       const int lrow = lane / cpr, lch = lane - lrow * cpr;
       const bool lact = lrow < rpp;
-      float cs8[8], cq8[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cs8[e] = cq8[e] = 0.f;
-      int cur_slot = -1;
-      // Same-address LDS float atomics serialise at the latency of the add (measured: 16 atomics per lane with rpp lanes per
-      // address cost the N = 320 layers +60 us per launch).  A tile inside ONE sample (the common case: cs_rows % BM == 0)
-      // keeps its sums in registers for the whole pass and adds the rpp lanes that hold one chunk through the wave's staging
-      // slice (flush_tree); a shuffle tree did the same but its 16 live values pushed loader state of the K loop into scratch.  Tiles that span samples (8x8 frames) flush per sample
-      // with the plain per-lane atomics: few, small launches, and the code stays compact (it is inlined per 16-row block).
-      const bool one_slot = p.cs_slots == 1;
-      const int rows_live = rpp < 16 ? rpp : 16;        // lanes with lrow >= 16 never store
-      auto flush_cols = [&]() {                         // spanning tiles
-        if (do_cs && lact && cur_slot >= 0) {
-          float* dst = cacc + ((cur_slot * BN) + nl_w0 + j0 * 16 + lch * 8) * 2;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { lds_add(dst + 2 * e, cs8[e]); lds_add(dst + 2 * e + 1, cq8[e]); cs8[e] = cq8[e] = 0.f; }
-        }
-      };
-      auto flush_tree = [&]() {                         // once per pass; every lane of the wave gets here
-        // the wave's staging slice is idle here: lanes park their 8 sums in it ([lrow][lch][8] = lane * 8 floats), then one
-        // lane per column adds the rows_live entries of its column - no same-address atomics, a handful of registers
-        float* red = reinterpret_cast<float*>(stg);
-        const int ncol = cpr * 8;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-          if (lact && lrow < rows_live) {
-            const float* src = ph ? cq8 : cs8;
-            *reinterpret_cast<f32x4*>(red + lane * 8) = (f32x4){src[0], src[1], src[2], src[3]};
-            *reinterpret_cast<f32x4*>(red + lane * 8 + 4) = (f32x4){src[4], src[5], src[6], src[7]};
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 1
-          for (int c = lane; c < ncol; c += 64) {
-            float t = 0.f;
-#pragma unroll 1
-            for (int r = 0; r < rows_live; ++r) t += red[r * ncol + c];
-            lds_add(cacc + (nl_w0 + j0 * 16 + c) * 2 + ph, t);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      };
       // residual rows of a 16-row block are fetched one block ahead (the kernel has one workgroup per CU: nothing else would
       // hide the HBM round trip, and 8 exposed round trips per tile were most of the time of the K = 320 layers)
       constexpr int NP = 3;                             // store instructions per 16-row block: ceil(16 / rpp) <= 3
@@ -666,10 +638,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           *reinterpret_cast<f32x4*>(stg + r16 * PITCH + (jj * 16 + g * 4) * 4) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (do_cs && !one_slot) {                        // sample slot of this 16-row block (wave-uniform)
-          const int slot = (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample;
-          if (slot != cur_slot) { flush_cols(); cur_slot = slot; }
-        }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
           const int r0 = q * rpp;
@@ -677,7 +645,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
           const int row = r0 + lrow, ch = lch;
           const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
           const int n = o_w0 + j0 * 16 + ch * 8;
-          float rs = 0.f, rq = 0.f;                      // this lane's share of row `row` (row statistics)
           if (lact && row < 16 && m < p.M && n < n_out) {
             float v[8];
             *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
@@ -696,45 +663,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
 #pragma unroll
             for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n) = pk;
-            if (do_cs) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float x0 = __uint_as_float(pk[e] << 16), x1 = __uint_as_float(pk[e] & 0xffff0000u);
-                cs8[2 * e] += x0; cq8[2 * e] = __builtin_fmaf(x0, x0, cq8[2 * e]);
-                cs8[2 * e + 1] += x1; cq8[2 * e + 1] = __builtin_fmaf(x1, x1, cq8[2 * e + 1]);
-              }
-            }
-            if (do_rp) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float x0 = __uint_as_float(pk[e] << 16), x1 = __uint_as_float(pk[e] & 0xffff0000u);
-                rs += x0 + x1; rq = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, rq));
-              }
-            }
-          }
-          if (do_rp && lact && row < 16 && m < p.M && n < n_out) {
-            float* dst = racc + ((wm * WTM + i) * 16 + row) * 2;
-            lds_add(dst, rs); lds_add(dst + 1, rq);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      if (do_cs) {
-        if (one_slot) flush_tree(); else flush_cols();
-      }
     }
-    if (do_cs || do_rp) stats_flush<BM, BN, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
     return;
   }
   if constexpr (!WIDE) {
   float* colc = reinterpret_cast<float*>(stg_stage);
-  constexpr bool STATS_OK = (EPI == FYC_EPI_LINEAR || EPI == EPI_LINEAR_ACT) && 2 * BN * 4 + stat_bytes<BM, BN>() <= STG_BYTES;
+  constexpr bool STATS_OK = (EPI == FYC_EPI_LINEAR || EPI == EPI_LINEAR_ACT) && 2 * BN * 4 + stat_bytes<BM, BN, WGM>() <= STG_BYTES;
   float* cacc = colc + 2 * BN;
-  float* racc = cacc + STAT_SLOTS * BN * 2;
+  float* racc = cacc + stat_arrays<WGM>() * BN * 2;
   const bool do_cs = STATS_OK && p.chan_parts != nullptr, do_rp = STATS_OK && p.row_parts != nullptr;
   if (p.colc || do_cs || do_rp) {
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
-    if (do_cs || do_rp) stats_zero<BM, BN, WGM * WGN * 64>(cacc, wave * 64 + lane);
+    if (do_cs || do_rp) stats_zero<BM, BN, WGM, WGM * WGN * 64>(cacc, wave * 64 + lane);
     if (p.colc) stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
     else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
   }
@@ -742,9 +686,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
     const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
-    if (m >= p.M) continue;
-    float st_rs = 0.f, st_rq = 0.f;                    // row statistics of this lane's columns
+    // values as stored, for the column statistics: summed over the 16 rows of the block by a fixed xor tree AFTER the row-divergent
+    // part (every lane takes part; rows / columns outside the problem stay 0), then added to the array this (wave row, slot) owns
+    float xs[STATS_OK ? WTN : 1][4];
+    if constexpr (STATS_OK) {
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) xs[j][0] = xs[j][1] = xs[j][2] = xs[j][3] = 0.f;
+    }
     const int st_slot = do_cs ? (tile_m * BM + (wm * WTM + i) * 16) / p.cs_rows - first_sample : 0;
+    if (m < p.M) {
+    float st_rs = 0.f, st_rq = 0.f;                    // row statistics of this lane's columns
     float ln_mu = 0.f, ln_rs = 1.f;
     if (LN && p.ln_stats) ln_row(p, m, ln_mu, ln_rs);
     if (EPI == FYC_EPI_GEGLU) {
@@ -818,13 +769,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
             for (int r = 0; r < 4 && n + r < p.N; ++r) ElemIO<T>::st(O + (long long)m * p.ldo + n + r, v[r]);
           }
           if (do_cs || do_rp) {
-            const int nl = (wn * WTN + j) * 16 + g * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               if (full || n + r < p.N) {
                 const float x = round_to<T>(v[r]);
                 st_rs += x; st_rq = __builtin_fmaf(x, x, st_rq);
-                if (do_cs) { float* dst = cacc + ((st_slot * BN) + nl + r) * 2; lds_add(dst, x); lds_add(dst + 1, x * x); }
+                if constexpr (STATS_OK) { if (do_cs) xs[j][r] = x; }
               }
             }
           }
@@ -846,8 +796,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
       }
       if (do_rp) { float* dst = racc + ((wm * WTM + i) * 16 + r16) * 2; lds_add(dst, st_rs); lds_add(dst + 1, st_rq); }
     }
+    }  // m < p.M
+    if constexpr (STATS_OK) {
+      if (do_cs) {
+        float* own = cacc + (wm + st_slot) * (BN * 2) + ((wn * WTN) * 16 + g * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sx = xs[j][r], sq = xs[j][r] * xs[j][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { sx += __shfl_xor(sx, o); sq += __shfl_xor(sq, o); }
+            if (r16 == 0) { own[(j * 16 + r) * 2] += sx; own[(j * 16 + r) * 2 + 1] += sq; }
+          }
+        }
+      }
+    }
   }
-  if (do_cs || do_rp) stats_flush<BM, BN, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
+  if (do_cs || do_rp) stats_flush<BM, BN, WGM, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
   }  // !WIDE
 }
 
@@ -1178,7 +1144,11 @@ int dispatch_cfg(int cfg, int ns, const GemmP& p, int batch, hipStream_t st) {
     switch (cfg) {
       case 1: if (ns == 3) return launch<T, 128, 128, 2, 2, MODE, EPI, 3, 128, true>(p, batch, st);
               return launch<T, 128, 128, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
-      case 2: return launch<T, 128, 64, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
+      case 2: if constexpr (MODE == FYC_GEMM_PLAIN) {   // deeper rings for the latency-bound small-M linears (8x8 latent level): see gemm.hip::choose
+                if (ns == 4) return launch<T, 128, 64, 2, 2, MODE, EPI, 4, 128, true>(p, batch, st);
+                if (ns == 3) return launch<T, 128, 64, 2, 2, MODE, EPI, 3, 128, true>(p, batch, st);
+              }
+              return launch<T, 128, 64, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
       case 3: return launch<T, 256, 128, 4, 2, MODE, EPI, 2, 128, true>(p, batch, st);
       case 4: return launch<T, 256, 64, 4, 1, MODE, EPI, 2, 128, true>(p, batch, st);
       // N = 320*k (every layer width of SD-1.5): 320-wide tiles read the A panel once per 320 columns

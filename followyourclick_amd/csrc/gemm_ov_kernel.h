@@ -50,7 +50,7 @@ struct OvLayout {
   static constexpr int OFF_RB = OFF_CSUM + CP;
   static constexpr int OFF_LN = OFF_RB + RB_SLOTS * CP;
   static constexpr int OFF_CACC = OFF_LN + LNP;
-  static constexpr int TOTAL = OFF_CACC + BN * 2 * 4;
+  static constexpr int TOTAL = OFF_CACC + WGM * BN * 2 * 4;     // one accumulator array per wave row: plain stores, added in order
 };
 
 template <int BM, int BN, int WGM, int WGN, int MODE>
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(512) fyc_gemm_ov_kernel(const GemmP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   // the wave's column sums -> the tile's LDS accumulator (lanes park their 8 sums in the idle staging slice, one lane per column adds
-  // the RPP rows of its column, one LDS atomic per column and wave)
+  // the RPP rows of its column and stores the total in the array of its wave row: no atomics, see gemm_kernel.h::stats_flush)
   auto reduce_stats = [&]() __attribute__((always_inline)) {
     float* red = reinterpret_cast<float*>(stg);
     constexpr int NCOL = SCPR * 8, ROWS_LIVE = RPP < 16 ? RPP : 16;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(512) fyc_gemm_ov_kernel(const GemmP p) {
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < ROWS_LIVE; ++r) t += red[r * NCOL + c];
-        lds_add(cacc + (nl_w0 + c) * 2 + ph, t);
+        cacc[(wm * BN + nl_w0 + c) * 2 + ph] = t;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -313,9 +313,10 @@ __global__ void __launch_bounds__(512) fyc_gemm_ov_kernel(const GemmP p) {
   auto publish_stats = [&](int tm, int tn) __attribute__((always_inline)) {
     for (int c = tid; c < BN; c += NT) {
       const int n = tn * BN + c;
-      const float2 v = *reinterpret_cast<const float2*>(cacc + 2 * c);
+      float2 v = *reinterpret_cast<const float2*>(cacc + 2 * c);
+#pragma unroll
+      for (int w = 1; w < WGM; ++w) { const float2 u = *reinterpret_cast<const float2*>(cacc + (w * BN + c) * 2); v.x += u.x; v.y += u.y; }
       if (n < p.N) *reinterpret_cast<float2*>(p.chan_parts + ((long long)tm * p.N + n) * 2) = v;
-      *reinterpret_cast<float2*>(cacc + 2 * c) = make_float2(0.f, 0.f);
     }
   };
 
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(512) fyc_gemm_ov_kernel(const GemmP p) {
   };
 
   // ---- the stream -----------------------------------------------------------------------------------------------------------
-  for (int c = tid; c < BN * 2; c += NT) cacc[c] = 0.f;
+  for (int c = tid; c < WGM * BN * 2; c += NT) cacc[c] = 0.f;
   int i_tile = blockIdx.x, i_kt = 0;
   int st_c = 0, st_i = 0;
   auto issue_next = [&]() __attribute__((always_inline)) {

@@ -6,17 +6,20 @@ namespace {
 
 // ---- GroupNorm statistics ------------------------------------------------------------------
 // grid = (row_chunks, samples).  A block walks `rows_per_block` rows of one sample; thread t owns the
-// 8-channel chunk (t % C8) of rows (t / C8), (t / C8) + RPI, ...  Per-channel partial sums are folded
-// per group through LDS, then one f64 atomicAdd pair per (block, group).
+// 8-channel chunk (t % C8) of rows (t / C8), (t / C8) + RPI, ...
+// The sums are ORDER-FREE (bitwise repeatable; round 3 folded them with LDS float atomics and f64 device atomics, whose arrival
+// order moved the last bits from run to run): the threads park their 16 partial sums in LDS, one thread per channel adds the
+// row lanes of its channel in order, one thread per group adds its channels in order, and the block stores its {sum, sum sq}
+// per group - straight into `stats` when one block covers the sample, else into part[sample][chunk][2][groups] (f32) that
+// gn_stats_finish_kernel adds up chunk by chunk in f64.
 template <typename T>
-__global__ void __launch_bounds__(512) gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int C,
-                                                       int groups, int rows_per_sample, int rows_per_block) {
-  extern __shared__ float sh[];  // [2][groups]
+__global__ void __launch_bounds__(512) gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, float* __restrict__ part,
+                                                       int C, int groups, int rows_per_sample, int rows_per_block) {
+  extern __shared__ float sh[];  // [nthr][16] parked sums, then [2][C] per channel
   const int tid = threadIdx.x, C8 = C >> 3, cpg = C / groups;
   const int sample = blockIdx.y;
   const int nthr = blockDim.x;
-  for (int i = tid; i < 2 * groups; i += nthr) sh[i] = 0.f;
-  __syncthreads();
+  float* chan = sh + nthr * 16;
   const int rpi = nthr / C8;  // rows per iteration (host guarantees blockDim >= C/8)
   const int row_begin = blockIdx.x * rows_per_block;
   const int row_end = min(row_begin + rows_per_block, rows_per_sample);
@@ -46,24 +49,42 @@ __global__ void __launch_bounds__(512) gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
     }
-    // fold the 8 channels into their groups (a chunk spans at most 8 groups; usually 1-2)
-    int gcur = (c8 * 8) / cpg;
-    float gs = 0.f, gq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int gi = (c8 * 8 + i) / cpg;
-      if (gi != gcur) {
-        atomicAdd(&sh[gcur], gs); atomicAdd(&sh[groups + gcur], gq);
-        gcur = gi; gs = 0.f; gq = 0.f;
-      }
-      gs += s[i]; gq += q[i];
-    }
-    atomicAdd(&sh[gcur], gs); atomicAdd(&sh[groups + gcur], gq);
+    float* mine = sh + tid * 16;   // tid = r0 * C8 + c8
+    *reinterpret_cast<f32x4*>(mine) = (f32x4){s[0], s[1], s[2], s[3]};
+    *reinterpret_cast<f32x4*>(mine + 4) = (f32x4){s[4], s[5], s[6], s[7]};
+    *reinterpret_cast<f32x4*>(mine + 8) = (f32x4){q[0], q[1], q[2], q[3]};
+    *reinterpret_cast<f32x4*>(mine + 12) = (f32x4){q[4], q[5], q[6], q[7]};
   }
   __syncthreads();
-  for (int gi = tid; gi < groups; gi += nthr) {
-    atomicAdd(&stats[((long long)sample * groups + gi) * 2 + 0], (double)sh[gi]);
-    atomicAdd(&stats[((long long)sample * groups + gi) * 2 + 1], (double)sh[groups + gi]);
+  for (int c = tid; c < C; c += nthr) {               // rows of a channel, in order
+    const float* src = sh + (c >> 3) * 16 + (c & 7);
+    float cs = 0.f, cq = 0.f;
+    for (int r0 = 0; r0 < rpi; ++r0) { cs += src[r0 * C8 * 16]; cq += src[r0 * C8 * 16 + 8]; }
+    chan[c] = cs; chan[C + c] = cq;
+  }
+  __syncthreads();
+  for (int gi = tid; gi < groups; gi += nthr) {       // channels of a group, in order
+    float gs = 0.f, gq = 0.f;
+    for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) { gs += chan[c]; gq += chan[C + c]; }
+    if (part == nullptr) {
+      stats[((long long)sample * groups + gi) * 2 + 0] = (double)gs;
+      stats[((long long)sample * groups + gi) * 2 + 1] = (double)gq;
+    } else {
+      float* dst = part + ((long long)sample * gridDim.x + blockIdx.x) * 2 * groups;
+      dst[gi] = gs; dst[groups + gi] = gq;
+    }
+  }
+}
+
+// chunk partial sums of a sample -> stats, in chunk order (f64)
+__global__ void __launch_bounds__(64) gn_stats_finish_kernel(const float* __restrict__ part, double* __restrict__ stats, int groups, int chunks) {
+  const int sample = blockIdx.x;
+  for (int gi = threadIdx.x; gi < groups; gi += 64) {
+    double s = 0.0, q = 0.0;
+    const float* src = part + (long long)sample * chunks * 2 * groups;
+    for (int c = 0; c < chunks; ++c) { s += (double)src[c * 2 * groups + gi]; q += (double)src[c * 2 * groups + groups + gi]; }
+    stats[((long long)sample * groups + gi) * 2 + 0] = s;
+    stats[((long long)sample * groups + gi) * 2 + 1] = q;
   }
 }
 
@@ -316,6 +337,25 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(T* __restrict__ x, in
 
 }  // namespace
 
+namespace {
+// row chunks a sample is cut into (grid.x) and rows per chunk: ~1024 blocks in total (4 per CU), >= 128 rows per block so the
+// unrolled loop has work
+void gn_stats_geometry(const fyc_gn_stats_args* a, int& chunks, int& rpb) {
+  const int samples = a->rows / a->rows_per_sample;
+  chunks = (int)ceil_div64(1024, samples);
+  rpb = (int)ceil_div64(a->rows_per_sample, chunks);
+  if (rpb < 128) rpb = 128;
+  chunks = (int)ceil_div64(a->rows_per_sample, rpb);
+}
+}  // namespace
+
+extern "C" int64_t fyc_gn_stats_workspace(const fyc_gn_stats_args* a) {
+  if (a == nullptr || a->rows_per_sample <= 0 || a->rows <= 0 || a->groups <= 0) return 0;
+  int chunks = 1, rpb = 0;
+  gn_stats_geometry(a, chunks, rpb);
+  return chunks > 1 ? (int64_t)(a->rows / a->rows_per_sample) * chunks * 2 * a->groups * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int fyc_gn_stats(const fyc_gn_stats_args* a, void* stream) {
   FYC_REQUIRE(a && a->x && a->stats, "fyc_gn_stats: null pointer");
   FYC_REQUIRE(a->C % 8 == 0 && a->C <= 4096 && a->groups > 0 && a->C % a->groups == 0, "fyc_gn_stats: C=%d groups=%d", a->C, a->groups);
@@ -323,23 +363,26 @@ extern "C" int fyc_gn_stats(const fyc_gn_stats_args* a, void* stream) {
   FYC_REQUIRE(a->C / 8 <= 512, "fyc_gn_stats: C too large");
   hipStream_t st = (hipStream_t)stream;
   const int samples = a->rows / a->rows_per_sample;
-  hipError_t e = hipMemsetAsync(a->stats, 0, sizeof(double) * 2 * samples * a->groups, st);
-  if (e != hipSuccess) FYC_FAIL(-3, "fyc_gn_stats: memset failed: %s", hipGetErrorString(e));
-  // aim for ~1024 blocks in total (4 per CU), >= 128 rows per block so the unrolled loop has work
-  int chunks = (int)ceil_div64(1024, samples);
-  int rpb = (int)ceil_div64(a->rows_per_sample, chunks);
-  if (rpb < 128) rpb = 128;
-  chunks = (int)ceil_div64(a->rows_per_sample, rpb);
+  int chunks = 1, rpb = 0;
+  gn_stats_geometry(a, chunks, rpb);
+  const int64_t need = fyc_gn_stats_workspace(a);
+  FYC_REQUIRE(chunks == 1 || (a->workspace != nullptr && a->workspace_bytes >= need && ((uintptr_t)a->workspace % 4) == 0),
+              "fyc_gn_stats: %lld workspace bytes needed (fyc_gn_stats_workspace), got %lld", (long long)need, (long long)(a->workspace ? a->workspace_bytes : 0));
+  float* part = chunks > 1 ? a->workspace : nullptr;
   dim3 grid(chunks, samples);
-  const size_t sh = sizeof(float) * 2 * a->groups;
   const int c8 = a->C / 8;
   const int nthr = c8 >= 256 ? ((c8 + 63) / 64) * 64 : 256;  // thread t <-> fixed 8-channel chunk t % c8
+  const size_t sh = sizeof(float) * ((size_t)nthr * 16 + 2 * a->C);
   if (a->dtype == FYC_BF16)
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(nthr), sh, st, (const bf16_t*)a->x, a->stats, a->C, a->groups, a->rows_per_sample, rpb);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(nthr), sh, st, (const bf16_t*)a->x, a->stats, part, a->C, a->groups, a->rows_per_sample, rpb);
   else if (a->dtype == FYC_F32)
-    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(nthr), sh, st, (const float*)a->x, a->stats, a->C, a->groups, a->rows_per_sample, rpb);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(nthr), sh, st, (const float*)a->x, a->stats, part, a->C, a->groups, a->rows_per_sample, rpb);
   else FYC_FAIL(-2, "fyc_gn_stats: bad dtype");
   FYC_CHECK_LAUNCH("fyc_gn_stats");
+  if (chunks > 1) {
+    hipLaunchKernelGGL(gn_stats_finish_kernel, dim3(samples), dim3(64), 0, st, part, a->stats, a->groups, chunks);
+    FYC_CHECK_LAUNCH("fyc_gn_stats (finish)");
+  }
   return 0;
 }
 

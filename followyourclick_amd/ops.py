@@ -325,6 +325,14 @@ class HipOps:
         if stats.dtype != torch.float64:
             raise TypeError("gn stats buffer must be float64")
         a.x, a.stats, a.rows, a.C, a.groups, a.rows_per_sample, a.dtype = _p(x), _p(stats), rows, C_, groups, rows_per_sample, _dt(x)
+        key = ("gnws", rows, groups, rows_per_sample)
+        need = self._q_cache.get(key)
+        if need is None:
+            need = self._q_cache[key] = int(self.lib.fyc_gn_stats_workspace(C.byref(a)))
+        if need > 0:     # chunk partial sums of the ordered (atomic-free) reduction: the split-K scratch buffer, same stream
+            if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
         self._call("fyc_gn_stats", a)
 
     def gn_apply(self, x: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, y: Tensor, *, rows: int, C_: int,

@@ -174,14 +174,19 @@ int fyc_temporal_attention(const fyc_tattn_args* a, void* stream);
  *   cross-frame (ResnetBlock3D.norm1/norm2, conv_norm_out: nn.GroupNorm on the 5-D tensor,
  *   resnet.py:299,322; unet.py:665): rows_per_sample = F*H*W;
  *   per-frame (Transformer3DModel.norm, TemporalTransformer3DModel.norm, VAE): rows_per_sample = H*W.
- * stats: [samples][groups][2] doubles (sum, sum of squares), zeroed by the call.
+ * stats: [samples][groups][2] doubles (sum, sum of squares), written by the call.
+ * The sums are bitwise repeatable (fixed reduction order, no atomics).  Large samples are cut into row chunks whose partial
+ * sums pass through `workspace` (float, fyc_gn_stats_workspace() bytes; 0 = one block per sample, no workspace needed).
  */
 typedef struct {
   const void* x; double* stats;
   int32_t rows, C, groups, rows_per_sample;
   int32_t dtype;
+  int32_t pad_;
+  float* workspace; int64_t workspace_bytes;
 } fyc_gn_stats_args;
 int fyc_gn_stats(const fyc_gn_stats_args* a, void* stream);
+int64_t fyc_gn_stats_workspace(const fyc_gn_stats_args* a);   /* bytes of `workspace` this problem needs (x / stats may be NULL) */
 
 /* y = (x - mean) * rstd * gamma[c] + beta[c], optional SiLU */
 typedef struct {

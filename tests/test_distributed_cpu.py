@@ -139,13 +139,14 @@ def test_dropin_unet_receives_rank0_weights(tmp_path):
 def test_bench_entry_point_under_torch_distributed_run(tmp_path):
     """bench.py as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`):
     rendezvous on 127.0.0.1, weight broadcast, per-rank clips, barrier + max-over-ranks timing, ONE JSON line from rank 0 -
-    with gloo and the op emulator behind FYC_BENCH_EMULATE=1 (a test switch; the line says "data": "emulated").  No RCCL run of this
+    with gloo and the op emulator injected by the tests-side wrapper tests/bench_emulated.py (bench.main(emulation=...); the line
+    says "data": "emulated"; labels follow the arguments).  No RCCL run of this
     path exists yet (SCALE_rNN.json has been a skip record): this keeps the launch path from failing first on an 8-GPU node."""
     import json
     import subprocess
-    env = dict(os.environ, FYC_BENCH_EMULATE="1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29771",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "2", "--size", "64", "--ddim-steps", "2", "--dtype", "f32"]
+           os.path.join(ROOT, "tests", "bench_emulated.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "2", "--size", "64", "--ddim-steps", "2", "--dtype", "f32"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -154,3 +155,18 @@ def test_bench_entry_point_under_torch_distributed_run(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "emulated"
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 1 / (d["ms_per_step"] / 1000.0)) / d["value"] < 1e-2      # whole-job frames/s = n * frames * K / max time
     assert d["host_launch_ms_per_ddim_step"] > 0 and "parallelism" in d["config"] and d["config"]["parallelism"].startswith("dp2")
+    assert d["metric"] == "denoised frames/sec, 2f x 64^2 clip @ 2 DDIM steps" and d["config"]["workload"].startswith("custom")
+
+
+def test_bench_labels_follow_the_arguments():
+    """only the default arguments claim BASELINE.json's configs[1] (round 3 stamped every line with it)"""
+    import argparse
+    import bench
+    ns = lambda **kw: argparse.Namespace(**kw)   # noqa: E731
+    assert bench.workload_label(ns(frames=16, size=512, ddim_steps=25, ip_tokens=0)) == "configs[1]"
+    assert bench.workload_label(ns(frames=8, size=256, ddim_steps=5, ip_tokens=0)) == "configs[0]"
+    assert bench.workload_label(ns(frames=32, size=768, ddim_steps=50, ip_tokens=0)) == "configs[3]"
+    assert bench.workload_label(ns(frames=16, size=512, ddim_steps=25, ip_tokens=16)) == "configs[4]"
+    assert bench.workload_label(ns(frames=16, size=512, ddim_steps=2, ip_tokens=0)).startswith("custom")
+    cores, logical = bench.numa_node_cores(0)
+    assert 1 <= len(cores) <= logical

@@ -85,7 +85,7 @@ def test_unet_forward_with_panel_linears(golden_dir, dtype, tol, monkeypatch):
     calls = []
 
     class Spy(EmuOps):
-        def panel_linear_supported(self, dtype, *, rows, N, K, gn_rows_per_sample=0):   # the tiny widths are outside the kernel's shapes: force the path
+        def panel_linear_supported(self, dtype, *, rows, N, K, gn_rows_per_sample=0, gn_groups=32):   # the tiny widths are outside the kernel's shapes: force the path
             return N == K
 
         def panel_linear(self, x, out, **kw):

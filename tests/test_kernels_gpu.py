@@ -204,6 +204,23 @@ def test_gemm_batched(hip, emu, dt):
     close(o_h, o_e, f"bgemm {dt}", RTOL[dt])
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("Z,M,N,K", [(5, 128, 128, 64), (3, 256, 512, 256), (4, 64, 64, 64), (2, 1024, 512, 1024)])
+def test_gemm_batched_aligned(hip, emu, dt, Z, M, N, K):
+    """the VAE's materialised attention at aligned sizes (tokens and channels multiples of 8: the 16-byte bf16 epilogue; round 4
+    first shipped it without the batch offset on the output and every batch element landed on element 0 - only the N = 100 case
+    above, which takes the narrow epilogue, was tested)"""
+    T = DT[dt]
+    a, w = rnd((Z, M, K), T, 1), rnd((Z, N, K), T, 2)
+    kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, batch=Z, stride_a=M * K, stride_w=N * K, stride_o=M * N, out_scale=K ** -0.5)
+    o_h = torch.full((Z, M, N), float("nan"), dtype=T, device="cuda")
+    hip.gemm(a.cuda(), w.cuda(), o_h, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(Z, M, N, dtype=T)
+    emu.gemm(a, w, o_e, **kw)
+    close(o_h, o_e, f"bgemm aligned {dt} {Z}x{M}x{N}x{K}", RTOL[dt])
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,nq,nk,d,div", [(2, 8, 256, 256, 40, 1), (4, 8, 64, 77, 40, 2), (1, 8, 100, 300, 80, 1), (2, 8, 64, 64, 160, 1),
                                             (2, 8, 16, 16, 8, 1), (3, 2, 33, 93, 32, 3), (1, 8, 1024, 1024, 40, 1), (2, 8, 1, 1, 32, 1)])
@@ -580,7 +597,7 @@ def test_panel_linear_is_repeatable(hip, C, gn):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
-@pytest.mark.parametrize("samples,rps,C", [(2, 4 * 64, 320), (8, 64, 64), (2, 16 * 16, 2560), (6, 1, 128), (3, 1000, 960), (2, 37, 1920)])
+@pytest.mark.parametrize("samples,rps,C", [(2, 4 * 64, 320), (8, 64, 64), (2, 16 * 16, 2560), (6, 1, 128), (3, 1000, 960), (2, 37, 1920), (2, 16 * 1024, 320)])
 def test_groupnorm(hip, emu, dt, samples, rps, C):
     T = DT[dt]
     rows = samples * rps
@@ -592,6 +609,10 @@ def test_groupnorm(hip, emu, dt, samples, rps, C):
     emu.gn_stats(x, st_e, rows=rows, C_=C, groups=32, rows_per_sample=rps)
     torch.cuda.synchronize()
     close(st_h, st_e, f"gn_stats {dt} C{C}", 1e-5)
+    for _ in range(3):                                # ordered reduction (no atomics): the same bits every launch
+        st_2 = torch.full_like(st_h, float("nan"))
+        hip.gn_stats(x.cuda(), st_2, rows=rows, C_=C, groups=32, rows_per_sample=rps)
+        assert torch.equal(st_2, st_h)
     for silu in (False, True):
         y_h = torch.zeros(rows, C, dtype=T, device="cuda")
         hip.gn_apply(x.cuda(), st_h, gamma.cuda(), beta.cuda(), y_h, rows=rows, C_=C, groups=32, rows_per_sample=rps, eps=1e-5, silu=silu)
@@ -869,15 +890,17 @@ STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 21, 22, 23, 31]
 
 @pytest.mark.parametrize("dt,tile", [("bf16", t) for t in STAT_TILES] + [("f32", 0)])
 @pytest.mark.parametrize("M,N,K,cs_rows,res", [(512, 320, 320, 64, True), (768, 640, 128, 128, True), (1152, 128, 64, 192, False),
-                                               (4096, 320, 64, 4096, True), (1280, 328, 72, 640, False), (1040, 64, 64, 80, False)])
+                                               (4096, 320, 64, 4096, True), (1280, 328, 72, 640, False), (1040, 64, 64, 80, False),
+                                               (1152, 320, 64, 144, True), (2304, 640, 128, 576, True)])     # 12x12 / 24x24 frames (768^2): samples straddle wave rows
 def test_gemm_output_statistics(hip, emu, dt, tile, M, N, K, cs_rows, res):
     """per-(row tile, sample, channel) and per-row {sum, sum of squares} written by the LINEAR epilogue, folded by
     fyc_chan_stats_reduce == sums of the values it stored (partial row / column tiles, up to 4 samples per tile, samples
-    straddling tiles)"""
+    straddling tiles); the column sums are bitwise repeatable (ordered reduction, no atomics)"""
     T = DT[dt]
     a, w = rnd((M, K), T, 1), rnd((N, K), T, 2, 1 / math.sqrt(K))
     bias, r = rnd((N,), torch.float32, 3), (rnd((M, N), T, 4) if res else None)
     hip.set_tuning(1, tile)
+    again = []
     try:
         nparts = hip.gemm_row_parts(T, M=M, N=N, K=K)
         nt, tile_rows, slots = hip.gemm_stat_layout(T, M=M, N=N, K=K, cs_rows=cs_rows)
@@ -890,9 +913,16 @@ def test_gemm_output_statistics(hip, emu, dt, tile, M, N, K, cs_rows, res):
                  out_scale=1.25, chan_parts=parts, cs_rows=cs_rows, row_parts=rp, row_nparts=nparts)
         cs = torch.full((M // cs_rows, N, 2), float("nan"), dtype=torch.float64, device="cuda")
         hip.chan_stats_reduce(parts, cs, rows=M, N=N, cs_rows=cs_rows, tile_rows=tile_rows, slots=slots)
+        for _ in range(3):
+            p2 = torch.full_like(parts, float("nan"))
+            hip.gemm(a.cuda(), w.cuda(), torch.empty_like(o_h), M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, bias=bias.cuda(), residual=None if r is None else r.cuda(),
+                     out_scale=1.25, chan_parts=p2, cs_rows=cs_rows)
+            again.append(p2)
         torch.cuda.synchronize()
     finally:
         hip.set_tuning(1, 0)
+    for p2 in again:
+        assert torch.equal(torch.nan_to_num(p2, nan=-1.0), torch.nan_to_num(parts, nan=-1.0)), f"column sums differ between launches ({dt}, tile {tile})"
     o_e = torch.zeros(M, N, dtype=T)
     emu.gemm(a, w, o_e, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N, bias=bias, residual=r, out_scale=1.25)
     close(o_h, o_e, f"gemm+stats {dt} tile {tile}", RTOL[dt])

@@ -73,6 +73,14 @@ def sweep(h):
         ("conv up L1 st", 32768, 640, 11520, dict(rowbias=True, stats=True, conv=(32, 32, 1280))),
         ("conv up L2 st", 8192, 1280, 23040, dict(rowbias=True, stats=True, conv=(16, 16, 2560))),
     ]
+    if os.environ.get("PROBE_SMALL"):      # the 8x8 / 16x16 latent levels: latency-bound K chains, tile ids with the ring depth in bits 8+
+        cases = [
+            ("to_out L3 res", 2048, 1280, 1280, dict(res=True)), ("proj_in L3", 2048, 1280, 1280, dict()),
+            ("tQKV L3 ln rb", 2048, 3840, 1280, dict(ln=True, rowbias=True)), ("FF1 GEGLU L3 ln", 2048, 10240, 1280, dict(epi=1, ln=True)),
+            ("FF2|proj L3 res st", 2048, 1280, 6400, dict(res=True, stats=True, k2=1280)), ("shortcut L3", 2048, 1280, 2560, dict()),
+            ("to_out L2 res", 8192, 1280, 1280, dict(res=True)), ("proj_in L2", 8192, 1280, 1280, dict()),
+            ("tQKV L2 ln rb", 8192, 3840, 1280, dict(ln=True, rowbias=True)),
+        ]
     cfgs = [int(c) for c in os.environ.get("PROBE_CFGS", "0,1,3,5,6,7,8").split(",")]
     print("cold operands (8 rotating buffer sets), us per launch; tile 0 = the library's own choice")
     print("case".ljust(22), "shape".ljust(24), " ".join(f"c{c}".rjust(7) for c in cfgs))
