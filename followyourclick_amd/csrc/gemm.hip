@@ -61,7 +61,11 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
     const bool short_k = p.mode == FYC_GEMM_PLAIN && (p.N == 320 || p.N == 640) && p.K <= p.N;
     if (p.M >= 16384) cfg = short_k ? 6 : 5;
     else if (p.M >= 4096) cfg = (p.N >= 5120) ? 5 : 6;
-    else cfg = 2;
+    // M < 4096 (the 8x8 latent level): the widest tile that still gives the chip ~200+ work items.  Cold-operand probe at
+    // M = 2048 (profiles/r04_gemm_small_m_ring_depth.txt): N = 10240 GEGLU 256x320 59 us vs 95 us on 128x64 tiles, N = 3840
+    // 128x128 35 vs 47 us, N = 1280 stays on 128x64 (24 vs 27 / 34 us).  Deeper rings on the small tiles measured equal
+    // (3-deep) or 1.6x slower (4-deep: one workgroup per CU) - more workgroups in flight, not a deeper ring, hide the latency.
+    else cfg = (p.N >= 5120) ? 5 : (p.N >= 2560 ? 1 : 2);
   } else if (p.N % 256 == 0 && p.M >= 16384) {
     cfg = 7;
   } else if (p.N % 128 == 0 || p.N > 512) {
