@@ -386,11 +386,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
       const bool live = lact && row < 16 && m < p.M && n_lane < p.N;
       if (live) {
         const u32x4 v4 = *reinterpret_cast<const u32x4*>(stg + row * PITCH + lch * 16);
-#ifdef FYC_NT_STORE                      // experiment (tools/exp build): streaming stores / loads for the epilogue's HBM bursts
-        __builtin_nontemporal_store(v4, reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n_lane));
-#else
-        *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n_lane) = v4;
-#endif
+        *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n_lane) = v4;   // (nt stores: same GEMM time, consumers +10 %: profiles/r04_epilogue_nontemporal_ab.txt)
         if (do_cs || do_rp) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -436,11 +432,7 @@ __device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[B
     for (int j = 0; j < WTN; ++j) {
       const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
       const T* ptr = (m < p.M && n < p.N) ? R + ((long long)m * p.ldr + n) : zero;
-#ifdef FYC_NT_LOAD
-      raw[i][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(ptr));
-#else
       raw[i][j] = *reinterpret_cast<const u32x2*>(ptr);
-#endif
     }
   }
   __builtin_amdgcn_sched_barrier(0);

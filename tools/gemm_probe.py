@@ -28,6 +28,10 @@ def run(h, M, N, K, *, epi=0, res=False, ln=False, rowbias=False, stats=False, n
         kw.update(lda=Cin, mode=1, conv=dict(Hout=Hh, Wout=Ww, Hin=Hh, Win=Ww, Cin=Cin, stride=1))
     if k2:      # merged FF2 | proj_out: A = [hidden (K - k2) | tokens (k2)]
         kw.update(a2=torch.randn(M, k2, device=DEV).to(T), k_split=K - k2, lda2=k2)
+    if os.environ.get("PROBE_LDA0") and not conv:      # every A row aliases row 0: the A operand is cache-resident (what does the K loop cost without its HBM latency?)
+        kw["lda"] = 0
+        if k2:
+            kw["lda2"] = 0
     if ln:
         kw["ln_stats"] = torch.rand(M, 2, device=DEV) + 0.5
         kw["ln_colsum"] = torch.randn(N, device=DEV)
