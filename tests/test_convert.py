@@ -141,3 +141,51 @@ def test_save_videos_grid(dropin, tmp_path):
     save_videos_grid(vid, path, n_rows=6, fps=8)
     im = Image.open(path)
     assert im.n_frames == 4 and im.size == (2 * 10 + 2, 8 + 4)
+
+
+def test_load_weights(dropin, golden_dir, tmp_path):
+    """`animatediff.utils.util.load_weights` (reference animatediff/utils/util.py:91-154): only the `motion_modules.` tensors of the
+    motion-module checkpoint are taken (with or without the `state_dict` wrapper), unknown keys among them are an error, motion LoRAs are
+    merged one by one with their own alpha - the same merge `test_lora_merges_match_reference` pins against the reference's output."""
+    from animatediff.models.unet import UNet3DConditionModel
+    from animatediff.utils.util import load_weights
+    from test_dropin_api import TINY
+    g = np.load(os.path.join(golden_dir, "convert_lora.npz"))
+    unet = UNet3DConditionModel(**TINY)
+    sd0 = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), seed=0)
+    unet.load_state_dict(sd0)
+
+    class Pipe:
+        pass
+
+    pipe = Pipe()
+    pipe.unet, pipe.text_encoder, pipe.vae = unet, None, None
+    temporal = {k: v + 1.0 for k, v in sd0.items() if "motion_modules." in k and v.is_floating_point()}
+    spatial_key = next(k for k in sd0 if "motion_modules." not in k and k.endswith("weight"))
+    ckpt = str(tmp_path / "mm.ckpt")
+    torch.save({"state_dict": dict(temporal, **{spatial_key: sd0[spatial_key] + 5.0})}, ckpt)     # the spatial tensor must be ignored
+    motion = {k[len("motion/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("motion/")}
+    lora_path = str(tmp_path / "motion_lora.ckpt")
+    torch.save(motion, lora_path)
+    assert load_weights(pipe, motion_module_path=ckpt, motion_module_lora_configs=[dict(path=lora_path, alpha=0.5)]) is pipe
+    sd1 = unet.state_dict()
+    assert torch.equal(sd1[spatial_key], sd0[spatial_key])
+    merged = {k for k in g["changed"].tolist() if "motion_modules." in k}
+    assert merged
+    for k, v in temporal.items():
+        if k in merged:
+            delta = torch.from_numpy(g["after/" + k]) - _before_motion_merge(g, sd0, k)
+            assert torch.allclose(sd1[k], v + delta, atol=1e-5), k
+        else:
+            assert torch.equal(sd1[k], v), k
+    bad = str(tmp_path / "bad.ckpt")
+    torch.save({"down_blocks.0.motion_modules.0.no_such_tensor": torch.zeros(1)}, bad)
+    with pytest.raises(AssertionError):
+        load_weights(pipe, motion_module_path=bad)
+    with pytest.raises(ValueError):
+        load_weights(pipe, dreambooth_model_path=str(tmp_path / "model.bin"))
+
+
+def _before_motion_merge(g, sd0, k):
+    """the golden's `after/<k>` holds W0 + motion-LoRA delta for temporal keys (the kohya LoRA of that fixture touches spatial layers only)"""
+    return sd0[k]

@@ -141,9 +141,12 @@ def test_reference_inference_script_runs_unmodified_on_mi355x(tmp_path, monkeypa
 
 
 # ---- scripts/inference_org.py and scripts/inference_w_image_cond.py ----------------------------------------------------------------
-def _run_t2v_script(script, tmp_path, monkeypatch, device_is_gpu: bool, port: int, extra_args, first_image: bool):
-    """both scripts: text-to-video pipeline call without first-frame conditioning (a 4-channel UNet3D); `first_image`: the script
-    also builds a 2-D StableDiffusionPipeline and synthesises a first image with it (inference_w_image_cond.py)"""
+def _run_t2v_script(script, tmp_path, monkeypatch, device_is_gpu: bool, port: int, extra_args, first_image: bool, cfg_extra=None,
+                    own_argv=None):
+    """the text-to-video scripts: pipeline call without first-frame conditioning (a 4-channel UNet3D); `first_image`: the script
+    also builds a 2-D StableDiffusionPipeline and synthesises a first image with it (inference_w_image_cond.py); `cfg_extra(root, fab)`:
+    more keys for the model entry of the prompt config; `own_argv(cfg_path, icfg_path, root, frames, size)`: the whole command line
+    for scripts with a different argument set (animate.py)"""
     import followyourclick_amd
     import yaml
     from followyourclick_amd import ops as ops_mod
@@ -167,6 +170,8 @@ def _run_t2v_script(script, tmp_path, monkeypatch, device_is_gpu: bool, port: in
     steps, size, frames = 2, 64, 2
     cfg = {"TinyModel": dict(base="", path=fab["unet2d_ckpt"] if first_image else "", motion_module=[fab["motion_ckpt"]], seed=[1], steps=steps,
                              guidance_scale=8.0, lora_alpha=0.8)}
+    if cfg_extra is not None:
+        cfg["TinyModel"].update(cfg_extra(root, fab))
     cfg_path = os.path.join(root, "prompts.yaml")
     with open(cfg_path, "w") as f:
         yaml.safe_dump(cfg, f)
@@ -209,7 +214,9 @@ def _run_t2v_script(script, tmp_path, monkeypatch, device_is_gpu: bool, port: in
             monkeypatch.setattr(cls, "to", lambda self, device, _r=real_to: _r(self, "cpu"))
     out_dir = os.path.join(root, "out")
     argv = [script, "--config", cfg_path, "--prompt", prompt_file, "--pretrained_model_path", root, "--inference_config", icfg_path,
-            "--L", str(frames), "--W", str(size), "--H", str(size), "--seed", "1", "--ddp"] + extra_args(root, out_dir, fab)
+            "--L", str(frames), "--W", str(size), "--H", str(size), "--seed", "1", "--ddp"] + (extra_args(root, out_dir, fab) if extra_args is not None else [])
+    if own_argv is not None:
+        argv = [script] + own_argv(cfg_path, icfg_path, root, frames, size)
     monkeypatch.setattr(sys, "argv", argv)
     monkeypatch.chdir(root)
     try:
@@ -295,3 +302,129 @@ def test_reference_inference_w_image_cond_script_runs_unmodified_on_emulator(tmp
     script = os.path.join(E.REF_ROOT, "scripts", "inference_w_image_cond.py")
     seen, root, out_dir, run = _run_t2v_script(script, tmp_path, monkeypatch, False, 29765, _image_cond_args, True)
     _check_image_cond(seen, root, run, tol=6e-2)
+
+
+# ---- scripts/animate.py and scripts/inference_w_camera_lora.py -------------------------------------------------------------------
+ANIMATE = os.path.join(E.REF_ROOT, "scripts", "animate.py")
+CAMERA_LORA = os.path.join(E.REF_ROOT, "scripts", "inference_w_camera_lora.py")
+
+
+def _animate_cfg(root, fab):
+    # the upstream AnimateDiff prompt-config layout animate.py reads: prompts, negative prompts and seeds live in the YAML (:112-119)
+    return dict(prompt=[PROMPT], n_prompt=["blurry"], seed=[7])
+
+
+def _animate_argv(cfg_path, icfg_path, root, frames, size):
+    return ["--config", cfg_path, "--pretrained_model_path", root, "--inference_config", icfg_path, "--L", str(frames), "--W", str(size), "--H", str(size)]
+
+
+def _check_animate(seen, root, run, tol):
+    _check_t2v(seen, run, tol=tol)
+    assert seen["call"]["negative_prompt"] == "blurry" and float(seen["call"]["guidance_scale"]) == 8.0
+    runs = os.listdir(os.path.join(root, "samples"))
+    assert len(runs) == 1, runs
+    savedir = os.path.join(root, "samples", runs[0])
+    name = "0-" + "-".join(PROMPT.split(" ")[:10]) + ".gif"                                      # scripts/animate.py:144-145
+    assert os.listdir(os.path.join(savedir, "sample")) == [name]
+    assert os.path.getsize(os.path.join(savedir, "sample", name)) > 1000 and os.path.getsize(os.path.join(savedir, "sample.gif")) > 1000
+    import yaml
+    with open(os.path.join(savedir, "config.yaml")) as f:
+        assert yaml.safe_load(f)["TinyModel"]["random_seed"] == [7]                              # :125-128: manual_seed(7) -> initial_seed()
+
+
+@pytest.mark.skipif(not os.path.exists(ANIMATE), reason="scripts/animate.py is not on this box")
+def test_reference_animate_script_runs_unmodified_on_emulator(tmp_path, monkeypatch):
+    """scripts/animate.py (the upstream AnimateDiff driver the repository keeps): no DDP, prompts / negative prompts / seeds from the
+    YAML, bare motion-module checkpoint through strict=False (:66-76), per-prompt `torch.manual_seed`, pipeline call under
+    `torch.autocast("cuda")`, one GIF per prompt + the grid + config.yaml with the seeds - on the op emulator"""
+    seen, root, out_dir, run = _run_t2v_script(ANIMATE, tmp_path, monkeypatch, False, 29767, None, False, cfg_extra=_animate_cfg, own_argv=_animate_argv)
+    _check_animate(seen, root, run, tol=6e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(ANIMATE), reason="scripts/animate.py is not on this box")
+def test_reference_animate_script_runs_unmodified_on_mi355x(tmp_path, monkeypatch):
+    seen, root, out_dir, run = _run_t2v_script(ANIMATE, tmp_path, monkeypatch, True, 29768, None, False, cfg_extra=_animate_cfg, own_argv=_animate_argv)
+    _check_animate(seen, root, run, tol=6e-2)
+
+
+def _fabricate_motion_lora(root, fab, rank=4, seed=3):
+    """a motion-LoRA checkpoint in the layout `convert_motion_lora_ckpt_to_diffusers` consumes (reference
+    animatediff/utils/convert_lora_safetensor_to_diffusers.py:26-51): `<module path>.processor.<to_q|to_k|to_v|to_out>_lora.<down|up>.weight`
+    for the attention projections of every temporal transformer block, saved from a DDP run (`module.` prefix, `state_dict` wrapper)"""
+    sd = torch.load(fab["motion_ckpt"], map_location="cpu")
+    g = torch.Generator().manual_seed(seed)
+    lora = {}
+    for k, v in sd.items():
+        for proj in ("to_q", "to_k", "to_v", "to_out.0"):
+            if "motion_modules" in k and "attention_blocks" in k and k.endswith(proj + ".weight"):
+                stem = k[:-len(proj + ".weight")]
+                name = proj.split(".")[0]
+                lora[f"module.{stem}processor.{name}_lora.down.weight"] = torch.randn(rank, v.shape[1], generator=g) / v.shape[1] ** 0.5
+                lora[f"module.{stem}processor.{name}_lora.up.weight"] = torch.randn(v.shape[0], rank, generator=g) * 0.3 / rank ** 0.5
+    assert lora, "no temporal attention projections found in the fabricated motion module"
+    path = os.path.join(root, "motion_lora.ckpt")
+    torch.save({"state_dict": lora}, path)
+    return path, lora, sd
+
+
+def _camera_cfg(root, fab):
+    path, lora, base = _fabricate_motion_lora(root, fab)
+    fab["motion_lora"], fab["motion_base"] = lora, base
+    return dict(motion_module_lora_path=path)
+
+
+def _camera_args(root, out_dir, fab):
+    return ["--video_scale", "0.5"]
+
+
+def _check_camera_lora(seen, root, run, fab, tol):
+    # the merged temporal projections the pipeline ran with: W + 1.0 * up @ down (alpha is hard-coded, scripts/inference_w_camera_lora.py:216)
+    lora, base = fab["motion_lora"], fab["motion_base"]
+    n = 0
+    for k, down in lora.items():
+        if ".down." not in k:
+            continue
+        up = lora[k.replace(".down.", ".up.")]
+        key = k[len("module."):].replace("processor.", "").replace("_lora", "").replace("down.", "").replace("to_out.", "to_out.0.")
+        want = base[key].float() + up @ down
+        assert torch.allclose(seen["unet_sd"][key], want, atol=1e-5), key
+        assert (seen["unet_sd"][key] - base[key].float()).abs().max() > 1e-3, key
+        n += 1
+    assert n >= 8, n
+    # the negative prompt is the FIRST CHARACTER of NEG_PROMPT: `list(NEG_PROMPT) * len(...)` (:249), kept as the script has it
+    assert seen["call"]["negative_prompt"] == "l"
+    _check_t2v(seen, run, tol=tol, video_scale=0.5)
+    runs = os.listdir(os.path.join(root, "samples"))
+    assert len(runs) == 1 and "_vs_0.5_" in runs[0], runs
+    assert os.path.getsize(os.path.join(root, "samples", runs[0], "sample", f"0_{PROMPT}.gif")) > 1000
+    assert os.path.exists(os.path.join(root, "samples", runs[0], "config.yaml")) and os.path.exists(os.path.join(root, "samples", runs[0], "prompts.txt"))
+
+
+def _run_camera_lora(tmp_path, monkeypatch, device_is_gpu, port):
+    import pdb
+    monkeypatch.setattr(pdb, "set_trace", lambda *a, **k: None)     # the script stops in a debugger at :221; an unattended run continues
+    keep = {}
+
+    def cfg_extra(root, fab):
+        keep["fab"] = fab
+        return _camera_cfg(root, fab)
+    seen, root, out_dir, run = _run_t2v_script(CAMERA_LORA, tmp_path, monkeypatch, device_is_gpu, port, _camera_args, False, cfg_extra=cfg_extra)
+    return seen, root, run, keep["fab"]
+
+
+@pytest.mark.skipif(not os.path.exists(CAMERA_LORA), reason="scripts/inference_w_camera_lora.py is not on this box")
+def test_reference_inference_w_camera_lora_script_runs_unmodified_on_emulator(tmp_path, monkeypatch):
+    """scripts/inference_w_camera_lora.py: bare motion-module checkpoint (strict=False, :155-163), a motion LoRA merged into the temporal
+    attention projections by `convert_motion_lora_ckpt_to_diffusers` (:215-219, the engine repacks its weights afterwards),
+    `PromptDataset` tuples through DistributedSampler + DataLoader, pipeline call with `video_scale` - on the op emulator.  Imports
+    `load_weights` (:23), which therefore has to exist in the drop-in."""
+    seen, root, run, fab = _run_camera_lora(tmp_path, monkeypatch, False, 29769)
+    _check_camera_lora(seen, root, run, fab, tol=6e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(CAMERA_LORA), reason="scripts/inference_w_camera_lora.py is not on this box")
+def test_reference_inference_w_camera_lora_script_runs_unmodified_on_mi355x(tmp_path, monkeypatch):
+    seen, root, run, fab = _run_camera_lora(tmp_path, monkeypatch, True, 29770)
+    _check_camera_lora(seen, root, run, fab, tol=6e-2)
