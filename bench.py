@@ -129,7 +129,10 @@ def workload_label(args):
     """BASELINE.json's configs entry these arguments reproduce, or 'custom'"""
     key = (args.frames, args.size, args.ddim_steps, args.ip_tokens)
     names = {(8, 256, 5, 0): "configs[0]", (16, 512, 25, 0): "configs[1]", (32, 768, 50, 0): "configs[3]", (16, 512, 25, 16): "configs[4]"}
-    return names.get(key, "custom (no BASELINE.json config)")
+    label = names.get(key, "custom (no BASELINE.json config)")
+    if args.dtype != "bf16" and key in names:
+        label += f" at {args.dtype} instead of the config's bf16"
+    return label
 
 
 def main(argv=None, emulation=None):
@@ -143,7 +146,8 @@ def main(argv=None, emulation=None):
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=25)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="storage / MFMA operand type: bf16 (BASELINE configs[1], the default), f16 (the reference's deployed autocast precision), f32 (parity mode)")
     ap.add_argument("--ip-tokens", type=int, default=0, help="configs[4]: IP-Adapter decoupled cross-attention with this many image tokens")
     ap.add_argument("--vae", action="store_true", help="also time the VAE decode of the final latents (outside the metric)")
     ap.add_argument("--graph", action="store_true", help="replay DDIM steps 1..n-1 from one captured hipGraph (A/B vs eager launches)")
@@ -167,7 +171,8 @@ def main(argv=None, emulation=None):
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
         sync = torch.cuda.synchronize
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    is16 = args.dtype in ("bf16", "f16")                       # v_mfma_*_bf16 and v_mfma_*_f16 have the same dense peak on gfx950
 
     cfg = UNet3DConfig(use_ip_cross_attention=args.ip_tokens > 0, ip_num_tokens=max(args.ip_tokens, 4))
     if emulate:
@@ -293,8 +298,8 @@ def main(argv=None, emulation=None):
                     continue
         alg_bytes = sum(v["bytes"] for v in mm.values()) / launches
         result["roofline"] = {"kernel": "fyc_gemm_kernel (MFMA GEMM + implicit-GEMM conv3x3)", "bound": "mfma",
-                              "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                              "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": traffic,
+                              "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if is16 else 157.3, "unit": "TFLOP/s",
+                              "frac": round(ach / (PEAK_BF16_TFLOPS if is16 else 157.3), 4), "traffic": traffic,
                               "traffic_note": traffic_note,
                               "algorithmic_bytes_per_launch": round(alg_bytes),
                               "launches_per_ddim_step": launches // n_inst, "avg_launch_us": round(1e3 * ms / launches, 2),
@@ -318,7 +323,7 @@ def main(argv=None, emulation=None):
         # sub-block they replace ÷ summed launch time)
         for key, name in (("ff_block", "ff_block_kernel (fused GEGLU feed-forward block, C = 320)"),
                           ("temporal_block", "tblock_rr_kernel (fused temporal attention sub-block, C = 320)")):
-            if key in summ and summ[key]["flops"] > 0 and args.dtype == "bf16":
+            if key in summ and summ[key]["flops"] > 0 and is16:
                 a = summ[key]
                 at = a["flops"] / (a["ms"] * 1e-3) / 1e12
                 result["roofline_" + key] = {"kernel": name, "bound": "mfma", "achieved": round(at, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -349,7 +354,7 @@ def main(argv=None, emulation=None):
             vae.ops = tvae.inner
             vm = {k: v for k, v in vs.items() if k in ("gemm", "conv3x3")}
             vfl, vms, vl = sum(v["flops"] for v in vm.values()), sum(v["ms"] for v in vm.values()), sum(v["launches"] for v in vm.values())
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            peak = PEAK_BF16_TFLOPS if is16 else 157.3
             result["roofline_vae"] = {"kernel": "fyc_gemm_kernel inside VAEDecoderEngine.decode_video (implicit-GEMM conv3x3 + 1x1 / attention linears)",
                                       "bound": "mfma", "achieved": round(vfl / (vms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                                       "frac": round(vfl / (vms * 1e-3) / 1e12 / peak, 4), "traffic": None,

@@ -14,6 +14,19 @@ __version__ = "0.1.0"
 DROPIN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
 
 
+def default_compute_dtype():
+    """The element type the drop-in models compute in when their constructor is not given `compute_dtype` - which is always the case
+    when the reference's unmodified scripts build them.  FYC_COMPUTE_DTYPE = bf16 (default: BASELINE configs[1]) | f16 (IEEE half, the
+    precision class of the reference's own `torch.autocast("cuda")` deployment, scripts/inference.py:294) | f32 (parity mode)."""
+    import torch
+    name = os.environ.get("FYC_COMPUTE_DTYPE", "bf16").lower()
+    table = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16, "float16": torch.float16,
+             "half": torch.float16, "f32": torch.float32, "fp32": torch.float32, "float32": torch.float32}
+    if name not in table:
+        raise ValueError(f"FYC_COMPUTE_DTYPE={name!r}: expected one of bf16, f16, f32")
+    return table[name]
+
+
 def install_dropin(force: bool = False) -> str:
     """Put the drop-in `animatediff` / `diffusers` / `ip_adapter` packages first on sys.path so that the
     reference's scripts import this engine instead of the reference's torch modules."""

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 EXTRA = os.environ.get("FYC_BUILD_EXTRA", "").split()
 LIB = os.path.abspath(os.environ.get("FYC_BUILD_LIB") or os.path.join(HERE, "libfyc_hip.so"))
 OBJ = os.path.join(HERE, "_obj") if not (EXTRA or os.environ.get("FYC_BUILD_LIB")) else LIB + ".obj"
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f32.hip", "gemm_pp_plain.hip", "gemm_pp_conv.hip", "gemm_ov.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "temporal_attn.hip", "temporal_block.hip", "temporal_block_rr.hip", "ff_block.hip", "panel_linear.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f16_plain.hip", "gemm_f16_conv.hip", "gemm_f16_act.hip", "gemm_f32.hip", "gemm_pp_plain.hip", "gemm_pp_conv.hip", "gemm_ov.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "attention_small_f16.hip", "attention_medium_f16.hip", "attention_large_f16.hip", "temporal_attn.hip", "temporal_block.hip", "temporal_block_rr.hip", "ff_block.hip", "panel_linear.hip", "norm.hip", "elementwise.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file and every
 # kernel here fits in 256 registers), which removes the v_accvgpr_read/write traffic around the
 # softmax rescale and the epilogues (312 -> 0 such moves in the attention main loop).
@@ -48,7 +48,7 @@ def _hipcc() -> str:
 
 def _digest(path: str) -> str:
     h = hashlib.sha256()
-    for dep in [path, os.path.join(CSRC, "fyc_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "gemm_pp_kernel.h"), os.path.join(CSRC, "gemm_ov_kernel.h"), os.path.join(CSRC, "attention_kernel.h"), os.path.join(HERE, "..", "include", "fyc.h")]:
+    for dep in [path, os.path.join(CSRC, "fyc_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "gemm_pp_kernel.h"), os.path.join(CSRC, "gemm_ov_kernel.h"), os.path.join(CSRC, "attention_kernel.h"), os.path.join(CSRC, "attention_groups.h"), os.path.join(HERE, "..", "include", "fyc.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(_flags(os.path.basename(path))).encode())

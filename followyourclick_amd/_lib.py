@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FYC_LIB_PATH") or os.path.join(HERE, "libfyc_hip.so")   # FYC_LIB_PATH: A/B builds
 
-FYC_F32, FYC_BF16 = 0, 1
+FYC_F32, FYC_BF16, FYC_F16 = 0, 1, 2
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_CONV3X3_UP2 = 0, 1, 2
 EPI_LINEAR, EPI_GEGLU, EPI_HEADS = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
@@ -160,7 +160,7 @@ MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set
         "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
-FYC_VERSION = 200        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
+FYC_VERSION = 201        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
 
 
 class FycError(RuntimeError):

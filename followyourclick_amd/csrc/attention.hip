@@ -5,7 +5,7 @@
 extern "C" int fyc_attention(const fyc_attn_args* a, void* stream) {
   FYC_REQUIRE(a && a->q && a->k && a->vt && a->o, "fyc_attention: null pointer");
   FYC_REQUIRE(g_fyc_zero_page != nullptr, "fyc_attention: fyc_init() not called");
-  FYC_REQUIRE(a->dtype == FYC_BF16, "fyc_attention: bf16 only (f32 parity mode uses materialised attention)");
+  FYC_REQUIRE(a->dtype == FYC_BF16 || a->dtype == FYC_F16, "fyc_attention: bf16 / f16 only (f32 parity mode uses materialised attention)");
   FYC_REQUIRE(a->batch > 0 && a->heads > 0 && a->n_q > 0 && a->n_k > 0, "fyc_attention: bad sizes");
   FYC_REQUIRE(a->d % 8 == 0 && a->d >= 8 && a->d <= 160, "fyc_attention: head dim %d (multiple of 8, <= 160)", a->d);
   FYC_REQUIRE(a->ldvt % 8 == 0 && a->ldvt >= a->n_k, "fyc_attention: ldvt=%d must be a multiple of 8 and >= n_k", a->ldvt);
@@ -24,7 +24,12 @@ extern "C" int fyc_attention(const fyc_attn_args* a, void* stream) {
   const long long wg3 = (long long)a->batch * a->heads * ((a->n_q + 191) / 192);
   int qt = (a->n_q >= 1024 && wg3 >= 512 && a->d <= 48) ? 3 : 2;      // larger head dims: 3 tiles no longer fit 2 waves / SIMD
   if (g_fyc_tuning[3] >= 2 && g_fyc_tuning[3] <= 4 && (a->d <= 80 || g_fyc_tuning[3] == 2)) qt = g_fyc_tuning[3];
-  if (a->d <= 48) return fyca::run_small(p, qt, st);
-  if (a->d <= 96) return fyca::run_medium(p, qt, st);
-  return fyca::run_large(p, st);
+  if (a->dtype == FYC_F16) {
+    if (a->d <= 48) return fyca::run_small<f16_t>(p, qt, st);
+    if (a->d <= 96) return fyca::run_medium<f16_t>(p, qt, st);
+    return fyca::run_large<f16_t>(p, st);
+  }
+  if (a->d <= 48) return fyca::run_small<bf16_t>(p, qt, st);
+  if (a->d <= 96) return fyca::run_medium<bf16_t>(p, qt, st);
+  return fyca::run_large<bf16_t>(p, st);
 }

@@ -1,4 +1,4 @@
-// Flash-style attention for gfx950: bf16 MFMA QK^T / PV with wave-level online softmax (kernel template).
+// Flash-style attention for gfx950: bf16 (or f16: template parameter T) MFMA QK^T / PV with wave-level online softmax (kernel template).
 //
 // Layouts (written by the GEMM "HEADS" epilogue): q,k [B*H][N][d] ; vt [B*H][d][ldvt] (V transposed,
 // keys contiguous) ; o token-major [B*N][ldo] (channel = h*d + i) for the to_out GEMM.
@@ -30,7 +30,7 @@
 namespace fyca {
 
 struct AttnP {
-  const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
+  const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;   // 16-bit elements of the kernel's T (bf16 or f16: same pointer arithmetic)
   int batch, heads, n_q, n_k, d, ldo, ldvt, kv_batch_div, o_accumulate;
   float sl2e, o_scale;   // scale * log2(e)
   int nqb;               // query blocks per (b,h)
@@ -46,8 +46,32 @@ static __device__ __attribute__((aligned(16))) const unsigned short fyc_ones[72]
     FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
     FYC_1, 0, 0, 0, 0, 0, 0, 0};
 #undef FYC_1
+#define FYC_1 0x3C00
+static __device__ __attribute__((aligned(16))) const unsigned short fyc_ones_f16[72] = {
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1, FYC_1,
+    FYC_1, 0, 0, 0, 0, 0, 0, 0};
+#undef FYC_1
+template <typename T> __device__ __forceinline__ const unsigned short* ones_table();
+template <> __device__ __forceinline__ const unsigned short* ones_table<bf16_t>() { return fyc_ones; }
+template <> __device__ __forceinline__ const unsigned short* ones_table<f16_t>() { return fyc_ones_f16; }
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// the two MFMA shapes of the loop per element type: 16x16x32 on 8-element fragments, 16x16x16 on 4-element ones (raw 16-bit words)
+template <typename T> struct AttnMma;
+template <> struct AttnMma<bf16_t> {
+  __device__ static __forceinline__ f32x4 k32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ f32x4 k16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+};
+template <> struct AttnMma<f16_t> {
+  __device__ static __forceinline__ f32x4 k32(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ f32x4 k16(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  }
+};
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -68,8 +92,10 @@ __device__ __forceinline__ float quad_max(float mx) {
 
 // DP16: padded head dim / 16 (K-dim of QK^T).  DVT: 16-row blocks of O^T = d/16 + 1 (the extra row at index d is l).
 // DVT == DP16 <=> d % 16 == 8: index d is a free padding slot of the head dim, used for the in-MFMA max subtraction.
-template <int DP16, int DVT, int QT>
+template <typename T, int DP16, int DVT, int QT>
 __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
+  typedef typename Pair16<T>::Vec8 Frag;
+  const unsigned short* const fyc_ones = ones_table<T>();
   constexpr int KS = DP16 / 2;           // full 32-wide k-steps
   constexpr bool TAIL = (DP16 & 1) != 0; // plus one 16-wide k-step
   constexpr bool MSUB = (DVT == DP16);
@@ -100,9 +126,9 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
   }
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int kvb = (b / p.kv_batch_div) * p.heads + h;
-  const bf16_t* Q = p.q + (long long)bh * p.n_q * p.d;
-  const bf16_t* K = p.k + (long long)kvb * p.n_k * p.d;
-  const bf16_t* VT = p.vt + (long long)kvb * p.d * p.ldvt;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (long long)bh * p.n_q * p.d;
+  const T* K = reinterpret_cast<const T*>(p.k) + (long long)kvb * p.n_k * p.d;
+  const T* VT = reinterpret_cast<const T*>(p.vt) + (long long)kvb * p.d * p.ldvt;
   const char* zero = p.zero;
   const int ntiles = (p.n_k + KB - 1) / KB;
   const int dchunks = p.d >> 3;
@@ -230,7 +256,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
   // ---- Q fragments (B operand), pre-scaled by scale*log2(e): lane (query = r16, quad g) holds Q[query][32ks + 8g .. +8]
   //      and, for the 16-wide step, Q[query][32*KS + 4g .. +4]
   const int qbase = qb * (64 * QT) + wave * (16 * QT);
-  bf16x8 qf[QT][KS > 0 ? KS : 1];
+  Frag qf[QT][KS > 0 ? KS : 1];
   s16x4 qt4[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -240,17 +266,17 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
     for (int ks = 0; ks < KS; ++ks) {
       const int dd = 32 * ks + 8 * g;
       float v[8];
-      load8<bf16_t>((qok && dd < p.d) ? Q + (long long)query * p.d + dd : reinterpret_cast<const bf16_t*>(zero), v);
+      load8<T>((qok && dd < p.d) ? Q + (long long)query * p.d + dd : reinterpret_cast<const T*>(zero), v);
       u32x4 pk;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(v[2 * i] * p.sl2e, v[2 * i + 1] * p.sl2e);
-      qf[qt][ks] = __builtin_bit_cast(bf16x8, pk);
+      for (int i = 0; i < 4; ++i) pk[i] = Pair16<T>::pack(v[2 * i] * p.sl2e, v[2 * i + 1] * p.sl2e);
+      qf[qt][ks] = __builtin_bit_cast(Frag, pk);
     }
     if (TAIL) {
       const int dd = 32 * KS + 4 * g;
       float v[4];
-      ElemIO<bf16_t>::ld4((qok && dd < p.d) ? Q + (long long)query * p.d + dd : reinterpret_cast<const bf16_t*>(zero), v);
-      u32x2 pk = {pack_bf16x2(v[0] * p.sl2e, v[1] * p.sl2e), pack_bf16x2(v[2] * p.sl2e, v[3] * p.sl2e)};
+      ElemIO<T>::ld4((qok && dd < p.d) ? Q + (long long)query * p.d + dd : reinterpret_cast<const T*>(zero), v);
+      u32x2 pk = {Pair16<T>::pack(v[0] * p.sl2e, v[1] * p.sl2e), Pair16<T>::pack(v[2] * p.sl2e, v[3] * p.sl2e)};
       qt4[qt] = __builtin_bit_cast(s16x4, pk);
     }
   }
@@ -258,13 +284,13 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
   constexpr int MOFF = MSUB ? ((DP16 * 16 - 8) - (TAIL ? 32 * KS : 32 * (KS - 1))) : 0;   // d - first index of the last step
   constexpr int MG = TAIL ? MOFF / 4 : MOFF / 8;
   auto set_neg_max = [&](int qt, float m_bf16_exact) {       // writes -m into Q'[query][d]
-    const unsigned short bits = f32_to_bf16_bits(-m_bf16_exact);
+    const unsigned short bits = Pair16<T>::to_bits(-m_bf16_exact);
     if (g == MG) {
       if (TAIL) qt4[qt][0] = (short)bits;
       else {
         u32x4 t = __builtin_bit_cast(u32x4, qf[qt][KS > 0 ? KS - 1 : 0]);
         t[0] = (t[0] & 0xffff0000u) | bits;
-        qf[qt][KS > 0 ? KS - 1 : 0] = __builtin_bit_cast(bf16x8, t);
+        qf[qt][KS > 0 ? KS - 1 : 0] = __builtin_bit_cast(Frag, t);
       }
     }
   };
@@ -317,22 +343,22 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
           s[t][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (TAIL) s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt4[t], qt4[qt], s[t][qt], 0, 0, 0);
+          if (TAIL) s[t][qt] = AttnMma<T>::k16(kt4[t], qt4[qt], s[t][qt]);
         }
       if (TAIL && KS > 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int krow = kb * 32 + 8 * (r16 >> 2) + 4 * t + (r16 & 3);
-        bf16x8 kf[KS > 0 ? KS : 1];        // one key tile's fragments at a time: large head dims would not fit both
+        Frag kf[KS > 0 ? KS : 1];        // one key tile's fragments at a time: large head dims would not fit both
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int chunk = 4 * ks + g;
-          kf[ks] = *reinterpret_cast<const bf16x8*>(kr[t] + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16);
+          kf[ks] = *reinterpret_cast<const Frag*>(kr[t] + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16);
         }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[qt][ks], s[t][qt], 0, 0, 0);
+          for (int ks = 0; ks < KS; ++ks) s[t][qt] = AttnMma<T>::k32(kf[ks], qf[qt][ks], s[t][qt]);
       }
       __builtin_amdgcn_s_setprio(0);
     };
@@ -368,7 +394,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
           const bool mv = !started || (MSUB ? mx[qt] > RESCALE_THR : mx[qt] > m_run[qt] + RESCALE_THR);
           if (MSUB) {
             // new max = bf16(m_run + mx) so that it fits Q' exactly; this block's scores are still relative to the old one
-            const float m_new = mv ? bf16_bits_to_f32(f32_to_bf16_bits(m_run[qt] + mx[qt])) : m_run[qt];
+            const float m_new = mv ? round_through<T>(m_run[qt] + mx[qt]) : m_run[qt];
             const float delta = m_new - m_run[qt];
             const float alpha = started ? __builtin_amdgcn_exp2f(-delta) : 1.0f;    // first block: O^T is 0, and 2^-delta may overflow
             m_run[qt] = m_new;
@@ -406,16 +432,16 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[t][qt][r] -= shift[qt];
       }
-      bf16x8 pf[QT];
+      Frag pf[QT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         u32x4 pk;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          pk[2 * t] = pack_bf16x2(__builtin_amdgcn_exp2f(s[t][qt][0]), __builtin_amdgcn_exp2f(s[t][qt][1]));
-          pk[2 * t + 1] = pack_bf16x2(__builtin_amdgcn_exp2f(s[t][qt][2]), __builtin_amdgcn_exp2f(s[t][qt][3]));
+          pk[2 * t] = Pair16<T>::pack(__builtin_amdgcn_exp2f(s[t][qt][0]), __builtin_amdgcn_exp2f(s[t][qt][1]));
+          pk[2 * t + 1] = Pair16<T>::pack(__builtin_amdgcn_exp2f(s[t][qt][2]), __builtin_amdgcn_exp2f(s[t][qt][3]));
         }
-        pf[qt] = __builtin_bit_cast(bf16x8, pk);
+        pf[qt] = __builtin_bit_cast(Frag, pk);
       }
       // ---- O^T += V^T P^T  (row d of V^T is all ones: O^T[d] accumulates the row sums)
       __builtin_amdgcn_s_setprio(1);
@@ -423,9 +449,9 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
       for (int dv = 0; dv < DVT; ++dv) {
         const int vrow = dv * 16 + r16;
         const int chunk = kb * 4 + g;
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + vrow * 128 + ((chunk ^ (vrow & 7)) * 16));
+        const Frag vf = *reinterpret_cast<const Frag*>(sV + vrow * 128 + ((chunk ^ (vrow & 7)) * 16));
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) o[qt][dv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][dv], 0, 0, 0);
+        for (int qt = 0; qt < QT; ++qt) o[qt][dv] = AttnMma<T>::k32(vf, pf[qt], o[qt][dv]);
       }
       __builtin_amdgcn_s_setprio(0);
     };
@@ -451,7 +477,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
     const float inv = 1.0f / l;
     const int query = qbase + qt * 16 + r16;
     if (query >= p.n_q) continue;
-    bf16_t* orow = p.o + ((long long)b * p.n_q + query) * p.ldo + h * p.d;
+    T* orow = reinterpret_cast<T*>(p.o) + ((long long)b * p.n_q + query) * p.ldo + h * p.d;
 #pragma unroll
     for (int dv = 0; dv < DVT; ++dv) {
       const int dd = dv * 16 + 4 * g;
@@ -459,16 +485,16 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
       float v[4] = {o[qt][dv][0] * inv, o[qt][dv][1] * inv, o[qt][dv][2] * inv, o[qt][dv][3] * inv};
       if (p.o_accumulate) {
         float prev[4];
-        ElemIO<bf16_t>::ld4(orow + dd, prev);
+        ElemIO<T>::ld4(orow + dd, prev);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = prev[r] + p.o_scale * v[r];
       }
-      ElemIO<bf16_t>::st4(orow + dd, v);
+      ElemIO<T>::st4(orow + dd, v);
     }
   }
 }
 
-template <int DP16, int DVT, int QT>
+template <typename T, int DP16, int DVT, int QT>
 int launch_attn(const AttnP& p0, hipStream_t st) {
   constexpr int DC = DP16 * 2;
   constexpr int PC = (DC == 8) ? 8 : DC + 1;
@@ -476,7 +502,7 @@ int launch_attn(const AttnP& p0, hipStream_t st) {
   constexpr int V_BYTES = ((DVT * 16 * 8 + 255) / 256) * 256 * 16;
   constexpr int smem = 3 * (K_BYTES + V_BYTES) + 256 * 16;      // ring + per-thread loader offsets
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = fyc_attn_kernel<DP16, DVT, QT>;
+  auto kern = fyc_attn_kernel<T, DP16, DVT, QT>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);   // per call: cheap, and correct on every device
   AttnP p = p0;
   p.nqb = (p.n_q + 64 * QT - 1) / (64 * QT);
@@ -486,12 +512,13 @@ int launch_attn(const AttnP& p0, hipStream_t st) {
   return 0;
 }
 
-// one translation unit per group of head dims keeps the build parallel
-int run_small(const AttnP& p, int qt, hipStream_t st);     // d <= 48; qt = 16-query tiles per wave (2, 3, 4)
-int run_medium(const AttnP& p, int qt, hipStream_t st);    // 48 < d <= 96
-int run_large(const AttnP& p, hipStream_t st);              // 96 < d <= 160
+// one translation unit per (element type, group of head dims) keeps the build parallel: attention_{small,medium,large}[_f16].hip
+// instantiate the templates of attention_groups.h
+template <typename T> int run_small(const AttnP& p, int qt, hipStream_t st);     // d <= 48; qt = 16-query tiles per wave (2, 3, 4)
+template <typename T> int run_medium(const AttnP& p, int qt, hipStream_t st);    // 48 < d <= 96
+template <typename T> int run_large(const AttnP& p, hipStream_t st);              // 96 < d <= 160
 
 // d -> (DP16, DVT) = (ceil(d/16), d/16 + 1), d a multiple of 8
-#define FYC_ATTN_CASE(D, QT) case D: return launch_attn<(D + 15) / 16, D / 16 + 1, QT>(p, st)
+#define FYC_ATTN_CASE(D, QT) case D: return launch_attn<T, (D + 15) / 16, D / 16 + 1, QT>(p, st)
 
 }  // namespace fyca

@@ -1,0 +1,5 @@
+// fused attention instantiations, f16_t elements, the "small" head-dim group (attention_groups.h)
+#include "attention_groups.h"
+namespace fyca {
+template int run_small<f16_t>(const AttnP&, int, hipStream_t);
+}  // namespace fyca

@@ -203,9 +203,10 @@ __global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__
 
 }  // namespace
 
-#define FYC_DT(a, call_bf16, call_f32)                         \
+#define FYC_DT(a, call_bf16, call_f16, call_f32)               \
   do {                                                         \
     if ((a)->dtype == FYC_BF16) { call_bf16; }                 \
+    else if ((a)->dtype == FYC_F16) { call_f16; }              \
     else if ((a)->dtype == FYC_F32) { call_f32; }              \
     else FYC_FAIL(-2, "bad dtype %d", (a)->dtype);             \
   } while (0)
@@ -217,6 +218,7 @@ extern "C" int fyc_concat_channels(const fyc_concat_args* a, void* stream) {
   const long long chunks = a->rows * ((a->c1 + a->c2) / 8);
   FYC_DT(a,
          hipLaunchKernelGGL(concat_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, st, (const bf16_t*)a->a, (const bf16_t*)a->b, (bf16_t*)a->y, chunks, a->c1 / 8, a->c2 / 8),
+         hipLaunchKernelGGL(concat_kernel<f16_t>, dim3(grid_for(chunks)), dim3(256), 0, st, (const f16_t*)a->a, (const f16_t*)a->b, (f16_t*)a->y, chunks, a->c1 / 8, a->c2 / 8),
          hipLaunchKernelGGL(concat_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, st, (const float*)a->a, (const float*)a->b, (float*)a->y, chunks, a->c1 / 8, a->c2 / 8));
   FYC_CHECK_LAUNCH("fyc_concat_channels");
   return 0;
@@ -235,6 +237,7 @@ extern "C" int fyc_cast_from_f32(const fyc_cast_args* a, void* stream) {
   const long long n = a->rows * a->ld;
   FYC_DT(a,
          hipLaunchKernelGGL(cast_from_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->x, (bf16_t*)a->y, (long long)a->rows, a->cols, a->ld),
+         hipLaunchKernelGGL(cast_from_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->x, (f16_t*)a->y, (long long)a->rows, a->cols, a->ld),
          hipLaunchKernelGGL(cast_from_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->x, (float*)a->y, (long long)a->rows, a->cols, a->ld));
   FYC_CHECK_LAUNCH("fyc_cast_from_f32");
   return 0;
@@ -246,6 +249,7 @@ extern "C" int fyc_cast_to_f32(const fyc_cast_to_args* a, void* stream) {
   const long long n = a->rows * a->cols;
   FYC_DT(a,
          hipLaunchKernelGGL(cast_to_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->x, a->y, (long long)a->rows, a->cols, a->ld),
+         hipLaunchKernelGGL(cast_to_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const f16_t*)a->x, a->y, (long long)a->rows, a->cols, a->ld),
          hipLaunchKernelGGL(cast_to_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->x, a->y, (long long)a->rows, a->cols, a->ld));
   FYC_CHECK_LAUNCH("fyc_cast_to_f32");
   return 0;
@@ -261,6 +265,7 @@ extern "C" int fyc_unet_input(const fyc_unet_input_args* a, void* stream) {
   const int mf = a->mask ? a->mask_frames : 1;
   FYC_DT(a,
          hipLaunchKernelGGL(unet_input_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (bf16_t*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf),
+         hipLaunchKernelGGL(unet_input_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (f16_t*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf),
          hipLaunchKernelGGL(unet_input_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (float*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf));
   FYC_CHECK_LAUNCH("fyc_unet_input");
   return 0;
@@ -275,6 +280,7 @@ extern "C" int fyc_cfg_ddim_step(const fyc_cfg_ddim_args* a, void* stream) {
   const long long n = (long long)a->B * a->F * a->HW;
   FYC_DT(a,
          hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const bf16_t*)a->pred_single, a->video_scale),
+         hipLaunchKernelGGL(cfg_ddim_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const f16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const f16_t*)a->pred_single, a->video_scale),
          hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const float*)a->pred_single, a->video_scale));
   FYC_CHECK_LAUNCH("fyc_cfg_ddim_step");
   return 0;
@@ -286,6 +292,7 @@ extern "C" int fyc_nchw_to_nhwc(const fyc_nchw_in_args* a, void* stream) {
   const long long n = (long long)a->N * a->HW;
   FYC_DT(a,
          hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->z, (bf16_t*)a->x, a->N, a->C, a->HW, a->c_pad, a->scale),
+         hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->z, (f16_t*)a->x, a->N, a->C, a->HW, a->c_pad, a->scale),
          hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->z, (float*)a->x, a->N, a->C, a->HW, a->c_pad, a->scale));
   FYC_CHECK_LAUNCH("fyc_nchw_to_nhwc");
   return 0;
@@ -297,6 +304,7 @@ extern "C" int fyc_nhwc_to_nchw(const fyc_nhwc_out_args* a, void* stream) {
   const long long n = (long long)a->N * a->C * a->HW;
   FYC_DT(a,
          hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->x, a->y, a->N, a->C, a->HW, a->ld, a->mul, a->add, a->lo, a->hi),
+         hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const f16_t*)a->x, a->y, a->N, a->C, a->HW, a->ld, a->mul, a->add, a->lo, a->hi),
          hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->x, a->y, a->N, a->C, a->HW, a->ld, a->mul, a->add, a->lo, a->hi));
   FYC_CHECK_LAUNCH("fyc_nhwc_to_nchw");
   return 0;
@@ -309,6 +317,7 @@ extern "C" int fyc_embed_tokens(const fyc_embed_args* a, void* stream) {
   const long long n = a->rows * (a->C / 8);
   FYC_DT(a,
          hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const long long*)a->ids, a->table, a->pos, (bf16_t*)a->out, (long long)a->rows, a->seq, a->C, a->vocab),
+         hipLaunchKernelGGL(embed_tokens_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const long long*)a->ids, a->table, a->pos, (f16_t*)a->out, (long long)a->rows, a->seq, a->C, a->vocab),
          hipLaunchKernelGGL(embed_tokens_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const long long*)a->ids, a->table, a->pos, (float*)a->out, (long long)a->rows, a->seq, a->C, a->vocab));
   FYC_CHECK_LAUNCH("fyc_embed_tokens");
   return 0;
@@ -323,6 +332,7 @@ extern "C" int fyc_patchify(const fyc_patchify_args* a, void* stream) {
   const long long n = (long long)a->B * (a->H / a->P) * (a->W / a->P) * a->ld;
   FYC_DT(a,
          hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->image, (bf16_t*)a->out, a->B, a->Cin, a->H, a->W, a->P, a->ld),
+         hipLaunchKernelGGL(patchify_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->image, (f16_t*)a->out, a->B, a->Cin, a->H, a->W, a->P, a->ld),
          hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->image, (float*)a->out, a->B, a->Cin, a->H, a->W, a->P, a->ld));
   FYC_CHECK_LAUNCH("fyc_patchify");
   return 0;
@@ -335,6 +345,7 @@ extern "C" int fyc_pack_conv3x3(const fyc_pack_conv3x3_args* a, void* stream) {
   const long long n = (long long)a->O * 9 * Ip;
   FYC_DT(a,
          hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->w, (bf16_t*)a->out, a->O, a->I, Ip, 64),
+         hipLaunchKernelGGL(pack_conv3x3_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->w, (f16_t*)a->out, a->O, a->I, Ip, 64),
          hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->w, (float*)a->out, a->O, a->I, Ip, 32));
   FYC_CHECK_LAUNCH("fyc_pack_conv3x3");
   return 0;
@@ -348,6 +359,7 @@ extern "C" int fyc_pack_geglu(const fyc_pack_geglu_args* a, void* stream) {
   const long long n = (long long)a->O * a->I;
   FYC_DT(a,
          hipLaunchKernelGGL(pack_geglu_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->w, a->b, (bf16_t*)a->w_out, a->b_out, a->O, a->I),
+         hipLaunchKernelGGL(pack_geglu_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->w, a->b, (f16_t*)a->w_out, a->b_out, a->O, a->I),
          hipLaunchKernelGGL(pack_geglu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->w, a->b, (float*)a->w_out, a->b_out, a->O, a->I));
   FYC_CHECK_LAUNCH("fyc_pack_geglu");
   return 0;

@@ -125,7 +125,8 @@ __device__ __forceinline__ float halves_sum(float v) {
 }
 
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
+__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <typename Frag> __device__ __forceinline__ Frag frag(const char* sl, int piece) { return *reinterpret_cast<const Frag*>(sl + piece * PIECE); }
 
 #ifdef FF_TIMING                                                // phase timestamps of wave 0 of every workgroup (tools/ff_probe.py prints them)
 __device__ unsigned long long g_ff_time[1024 * 16];
@@ -134,7 +135,11 @@ __device__ unsigned long long g_ff_time[1024 * 16];
 #define FF_MARK(k) do {} while (0)
 #endif
 
+// T: the 16-bit element type of the tokens, the residual, the output and the weight stream (bf16_t or f16_t; FFP's pointers are
+// typed bf16_t for both: same arithmetic)
+template <typename T>
 __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
+  typedef typename Pair16<T>::Vec8 Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,11 +165,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
 
   // ---- the wave's 32 token rows as MFMA B operands: lane (token, k half) holds x[token][16 s + 8 kh .. +8] ----------------------
   FF_MARK(0);
-  bf16x8 xa[KS];
+  Frag xa[KS];
   {
     const bf16_t* xr = p.x + (row0 + wave * 32 + tok) * C_ + kh * 8;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xa[s] = *reinterpret_cast<const bf16x8*>(xr + s * 16);
+    for (int s = 0; s < KS; ++s) xa[s] = *reinterpret_cast<const Frag*>(xr + s * 16);
   }
 #pragma unroll
   for (int n = 0; n < GPW; ++n) dma_group(0, n);
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     for (int k = 0; k < KS; ++k) {
       const u32x4 t = __builtin_bit_cast(u32x4, xa[k]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s += __uint_as_float(t[e] << 16) + __uint_as_float(t[e] & 0xffff0000u);
+      for (int e = 0; e < 4; ++e) s += Pair16<T>::lo(t[e]) + Pair16<T>::hi(t[e]);
     }
     mu = halves_sum(s) * (1.0f / C_);
     float q = 0.f;
@@ -188,7 +193,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
       const u32x4 t = __builtin_bit_cast(u32x4, xa[k]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float a = __uint_as_float(t[e] << 16) - mu, b = __uint_as_float(t[e] & 0xffff0000u) - mu;
+        const float a = Pair16<T>::lo(t[e]) - mu, b = Pair16<T>::hi(t[e]) - mu;
         q = __builtin_fmaf(a, a, q);
         q = __builtin_fmaf(b, b, q);
       }
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     const char* sl = smem + (t & (NSLOT - 1)) * HALF_BYTES + lane16;
 #pragma unroll
     for (int u = 0; u < 2 * NB; ++u) {
-      oacc[u % NB] = mfma(frag(sl, u), xa[2 * t + u / NB], oacc[u % NB]);
+      oacc[u % NB] = mfma(frag<Frag>(sl, u), xa[2 * t + u / NB], oacc[u % NB]);
       if (u % 8 == 0 && u / 8 < GPW) dma_group(t + 2, u / 8);
     }
   }
@@ -224,8 +229,8 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     u32x4 t = __builtin_bit_cast(u32x4, xa[k]);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      t[e] = pack_bf16x2((__uint_as_float(t[e] << 16) - mu) * rs, (__uint_as_float(t[e] & 0xffff0000u) - mu) * rs);
-    xa[k] = __builtin_bit_cast(bf16x8, t);
+      t[e] = Pair16<T>::pack((Pair16<T>::lo(t[e]) - mu) * rs, (Pair16<T>::hi(t[e]) - mu) * rs);
+    xa[k] = __builtin_bit_cast(Frag, t);
   }
 
   // ---- hidden chunks -----------------------------------------------------------------------------------------------------------
@@ -243,7 +248,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     if (e % 4 == 0) { bv4 = *reinterpret_cast<const f32x4*>(bias + 2 * e); bg4 = *reinterpret_cast<const f32x4*>(bias + 32 + 2 * e); }
     const float o = geglu_one(hv[e] + bv4[e % 4], hg[e] + bg4[e % 4]);
     if (e & 1) {
-      unsigned pk = pack_bf16x2(glo, o);
+      unsigned pk = Pair16<T>::pack(glo, o);
       asm volatile("" : "+v"(pk));                              // "used" here: LLVM's sinking passes would otherwise move the gate down to FF2, its only consumer
       hbw[e >> 3][(e & 7) >> 1] = pk;
     } else {
@@ -254,11 +259,11 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
   // `after(s)` runs behind the MFMAs of k-step s (DMA groups, gate units)
   auto ff1_steps = [&](const char* sl, auto s0_, auto s1_, f32x16& hv, f32x16& hg, auto after) {
     constexpr int S0 = decltype(s0_)::value, S1 = decltype(s1_)::value;
-    bf16x8 wv = frag(sl, 0), wg = frag(sl, 1);
+    Frag wv = frag<Frag>(sl, 0), wg = frag<Frag>(sl, 1);
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
-      bf16x8 nv = wv, ng = wg;
-      if (s + 1 < S1) { nv = frag(sl, 2 * (s + 1 - S0)); ng = frag(sl, 2 * (s + 1 - S0) + 1); }
+      Frag nv = wv, ng = wg;
+      if (s + 1 < S1) { nv = frag<Frag>(sl, 2 * (s + 1 - S0)); ng = frag<Frag>(sl, 2 * (s + 1 - S0) + 1); }
       hv = mfma(wv, xa[s], hv);
       hg = mfma(wg, xa[s], hg);
       after(s);
@@ -272,12 +277,12 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     }
   };
   auto ff2 = [&](const char* sl, const u32x4 (&hbw)[2]) {
-    const bf16x8 hb[2] = {__builtin_bit_cast(bf16x8, hbw[0]), __builtin_bit_cast(bf16x8, hbw[1])};
-    bf16x8 w[2] = {frag(sl, P_W2), frag(sl, P_W2 + 1)};
+    const Frag hb[2] = {__builtin_bit_cast(Frag, hbw[0]), __builtin_bit_cast(Frag, hbw[1])};
+    Frag w[2] = {frag<Frag>(sl, P_W2), frag<Frag>(sl, P_W2 + 1)};
 #pragma unroll
     for (int u = 0; u < 2 * NB; u += 2) {                     // piece P_W2 + u: k-step u / NB, feature block u % NB; the next two in flight
-      bf16x8 n[2] = {w[0], w[1]};
-      if (u + 2 < 2 * NB) { n[0] = frag(sl, P_W2 + u + 2); n[1] = frag(sl, P_W2 + u + 3); }
+      Frag n[2] = {w[0], w[1]};
+      if (u + 2 < 2 * NB) { n[0] = frag<Frag>(sl, P_W2 + u + 2); n[1] = frag<Frag>(sl, P_W2 + u + 3); }
       oacc[u % NB] = mfma(w[0], hb[u / NB], oacc[u % NB]);
       oacc[(u + 1) % NB] = mfma(w[1], hb[(u + 1) / NB], oacc[(u + 1) % NB]);
       if ((u & 2) || u + 2 == 2 * NB) __builtin_amdgcn_sched_barrier(0);
@@ -363,13 +368,13 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
     for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        bf16_t* a = reinterpret_cast<bf16_t*>(rowp + (32 * j + 8 * b) * 2);
+        T* a = reinterpret_cast<T*>(rowp + (32 * j + 8 * b) * 2);
         const f32x4 bo = *reinterpret_cast<const f32x4*>(p.b_out + 32 * j + 8 * b + 4 * kh);
         float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
-        if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
+        if (p.res != nullptr) ElemIO<T>::ld4(a, rr);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = oacc[j][4 * b + r] + bo[r] + rr[r];
-        ElemIO<bf16_t>::st4(a, v);
+        ElemIO<T>::st4(a, v);
       }
   }
   dma_landed_barrier();
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(NT) ff_block_kernel(const FFP p) {
         if (p.parts != nullptr) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float x0 = __uint_as_float(v[e] << 16), x1 = __uint_as_float(v[e] & 0xffff0000u);
+            const float x0 = Pair16<T>::lo(v[e]), x1 = Pair16<T>::hi(v[e]);
             cs8[2 * e] += x0; cq8[2 * e] = __builtin_fmaf(x0, x0, cq8[2 * e]);
             cs8[2 * e + 1] += x1; cq8[2 * e + 1] = __builtin_fmaf(x1, x1, cq8[2 * e + 1]);
           }
@@ -447,7 +452,7 @@ extern "C" int fyc_ff_timing(unsigned long long* host_out, int n) {
 extern "C" int64_t fyc_ff_block_wstream_bytes(void) { return (int64_t)NHALF * HALF_BYTES; }
 
 extern "C" int fyc_ff_block_supported(const fyc_ff_block_args* a) {
-  if (a == nullptr || a->dtype != FYC_BF16 || a->C != C_ || a->hidden != HID || a->rows <= 0 || a->rows % ROWS != 0) return 0;
+  if (a == nullptr || (a->dtype != FYC_BF16 && a->dtype != FYC_F16) || a->C != C_ || a->hidden != HID || a->rows <= 0 || a->rows % ROWS != 0) return 0;
   if (a->chan_parts != nullptr && (a->cs_rows <= 0 || a->cs_rows % ROWS != 0 || a->rows % a->cs_rows != 0)) return 0;
   int64_t lds_cap = 0, n_cu = 0;
   device_limits(lds_cap, n_cu);
@@ -457,7 +462,7 @@ extern "C" int fyc_ff_block_supported(const fyc_ff_block_args* a) {
 
 extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
   FYC_REQUIRE(a && a->x && a->out && a->wstream && a->b_out, "fyc_ff_block: null pointer");
-  FYC_REQUIRE(fyc_ff_block_supported(a), "fyc_ff_block: built for bf16, C=320, hidden=1280, rows %% 128 == 0, cs_rows %% 128 == 0 and >= %d B of LDS (got C=%d hidden=%d rows=%d cs_rows=%d)",
+  FYC_REQUIRE(fyc_ff_block_supported(a), "fyc_ff_block: built for bf16 / f16, C=320, hidden=1280, rows %% 128 == 0, cs_rows %% 128 == 0 and >= %d B of LDS (got C=%d hidden=%d rows=%d cs_rows=%d)",
               LDS_BYTES, a->C, a->hidden, a->rows, a->cs_rows);
   FYC_REQUIRE(a->x != a->out, "fyc_ff_block: out must not alias x");
   FYC_REQUIRE(((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->out % 16) == 0 && ((uintptr_t)a->wstream % 16) == 0 && ((uintptr_t)a->b_out % 16) == 0 &&
@@ -473,12 +478,14 @@ extern "C" int fyc_ff_block(const fyc_ff_block_args* a, void* stream) {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ff_block_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) FYC_FAIL(-3, "fyc_ff_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
       if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
     }
   }
-  hipLaunchKernelGGL(ff_block_kernel, dim3((unsigned)p.ntiles), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  if (a->dtype == FYC_F16) hipLaunchKernelGGL(ff_block_kernel<f16_t>, dim3((unsigned)p.ntiles), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ff_block_kernel<bf16_t>, dim3((unsigned)p.ntiles), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_ff_block");
   return 0;
 }

@@ -10,6 +10,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -64,6 +67,39 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, h);
 }
 
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// The two 16-bit storage formats (FYC_BF16, FYC_F16) behind one interface: a pair of consecutive elements in a 32-bit word.
+// bf16 unpacks with a shift / mask and packs with v_cvt_pk_bf16_f32; f16 unpacks with v_cvt_f32_f16 (+ SDWA for the upper half) and
+// packs with v_cvt_pk_f16_f32 - one instruction per value or pair either way, round-to-nearest-even both.
+template <typename T> struct Pair16;
+template <> struct Pair16<bf16_t> {
+  typedef bf16x8 Vec8;
+  typedef bf16x4 Vec4;
+  static constexpr unsigned short ONE = 0x3F80;
+  __device__ static __forceinline__ float lo(unsigned u) { return __uint_as_float(u << 16); }
+  __device__ static __forceinline__ float hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+  __device__ static __forceinline__ unsigned pack(float a, float b) { return pack_bf16x2(a, b); }
+  __device__ static __forceinline__ float from_bits(unsigned short b) { return bf16_bits_to_f32(b); }
+  __device__ static __forceinline__ unsigned short to_bits(float f) { return f32_to_bf16_bits(f); }
+};
+template <> struct Pair16<f16_t> {
+  typedef f16x8 Vec8;
+  typedef f16x4 Vec4;
+  static constexpr unsigned short ONE = 0x3C00;
+  __device__ static __forceinline__ float lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+  __device__ static __forceinline__ float hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+  __device__ static __forceinline__ unsigned pack(float a, float b) {
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2));
+  }
+  __device__ static __forceinline__ float from_bits(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+  __device__ static __forceinline__ unsigned short to_bits(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+};
+// value of v after one rounding to T (identity for float)
+template <typename T> __device__ __forceinline__ float round_through(float v) { return Pair16<T>::from_bits(Pair16<T>::to_bits(v)); }
+template <> __device__ __forceinline__ float round_through<float>(float v) { return v; }
+
 template <typename T> struct ElemIO;
 template <> struct ElemIO<float> {
   static constexpr int VEC = 4;  // elements per 16-byte chunk
@@ -79,50 +115,52 @@ template <> struct ElemIO<float> {
     *reinterpret_cast<f32x4*>(p) = t;
   }
 };
-template <> struct ElemIO<bf16_t> {
+template <typename T> struct ElemIO16 {
   static constexpr int VEC = 8;
-  __device__ static __forceinline__ float ld(const bf16_t* p) {
-    return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p));
-  }
-  __device__ static __forceinline__ void st(bf16_t* p, float v) {
-    *reinterpret_cast<unsigned short*>(p) = f32_to_bf16_bits(v);
-  }
-  __device__ static __forceinline__ void ld4(const bf16_t* p, float v[4]) {
+  __device__ static __forceinline__ float ld(const T* p) { return Pair16<T>::from_bits(*reinterpret_cast<const unsigned short*>(p)); }
+  __device__ static __forceinline__ void st(T* p, float v) { *reinterpret_cast<unsigned short*>(p) = Pair16<T>::to_bits(v); }
+  __device__ static __forceinline__ void ld4(const T* p, float v[4]) {
     u32x2 t = *reinterpret_cast<const u32x2*>(p);
-    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
-    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+    v[0] = Pair16<T>::lo(t[0]); v[1] = Pair16<T>::hi(t[0]);
+    v[2] = Pair16<T>::lo(t[1]); v[3] = Pair16<T>::hi(t[1]);
   }
-  __device__ static __forceinline__ void st4(bf16_t* p, const float v[4]) {
+  __device__ static __forceinline__ void st4(T* p, const float v[4]) {
     u32x2 t;
-    t[0] = pack_bf16x2(v[0], v[1]);
-    t[1] = pack_bf16x2(v[2], v[3]);
+    t[0] = Pair16<T>::pack(v[0], v[1]);
+    t[1] = Pair16<T>::pack(v[2], v[3]);
     *reinterpret_cast<u32x2*>(p) = t;
   }
 };
+template <> struct ElemIO<bf16_t> : ElemIO16<bf16_t> {};
+template <> struct ElemIO<f16_t> : ElemIO16<f16_t> {};
 
 // 8 consecutive elements as floats (two 16-B loads for f32, one for bf16)
 template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
   ElemIO<float>::ld4(p, v); ElemIO<float>::ld4(p + 4, v + 4);
 }
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
+template <typename T> __device__ __forceinline__ void load8_16(const T* p, float v[8]) {
   u32x4 t = *reinterpret_cast<const u32x4*>(p);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    v[2 * i] = __uint_as_float(t[i] << 16);
-    v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    v[2 * i] = Pair16<T>::lo(t[i]);
+    v[2 * i + 1] = Pair16<T>::hi(t[i]);
   }
 }
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) { load8_16<bf16_t>(p, v); }
+template <> __device__ __forceinline__ void load8<f16_t>(const f16_t* p, float v[8]) { load8_16<f16_t>(p, v); }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
   ElemIO<float>::st4(p, v); ElemIO<float>::st4(p + 4, v + 4);
 }
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
+template <typename T> __device__ __forceinline__ void store8_16(T* p, const float v[8]) {
   u32x4 t;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+  for (int i = 0; i < 4; ++i) t[i] = Pair16<T>::pack(v[2 * i], v[2 * i + 1]);
   *reinterpret_cast<u32x4*>(p) = t;
 }
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) { store8_16<bf16_t>(p, v); }
+template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float v[8]) { store8_16<f16_t>(p, v); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

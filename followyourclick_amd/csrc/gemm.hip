@@ -10,9 +10,10 @@ namespace {
 // A 128x64 tile grid (320 tiles) re-fetches 3.4x the operand bytes per FLOP of the 320-wide tiles, and 128x320 tiles alone
 // leave 3/4 of the CUs idle (64 tiles).  Each output tile is therefore cut into `splitk` K slices (one work item each, raw f32
 // partials to the caller's workspace) and this kernel adds the slices and applies the LINEAR epilogue.
+template <typename T>
 __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
                                                             const float* __restrict__ rowbias, int rows_per_batch, int ldrb,
-                                                            const bf16_t* __restrict__ residual, int ldr, bf16_t* __restrict__ out, int ldo,
+                                                            const T* __restrict__ residual, int ldr, T* __restrict__ out, int ldo,
                                                             int M, int N, float out_scale) {
   const int n8 = N >> 3;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < (long long)M * n8; idx += gridDim.x * 256ll) {
@@ -37,13 +38,13 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* __restr
     }
     if (residual) {
       float r[8];
-      load8<bf16_t>(residual + (long long)m * ldr + n, r);
+      load8<T>(residual + (long long)m * ldr + n, r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += r[e];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= out_scale;
-    store8<bf16_t>(out + (long long)m * ldo + n, v);
+    store8<T>(out + (long long)m * ldo + n, v);
   }
 }
 
@@ -109,6 +110,7 @@ int stat_slots(int bm, int cs_rows) {
 }
 // `stats`: the epilogue also writes output statistics - not built for the 64-byte K-tile configs (their ring stage is too small
 // for the accumulators), which fall back to the 128-byte ones
+inline bool is16(int dtype) { return dtype == FYC_BF16 || dtype == FYC_F16; }   // the 16-bit storage formats share every tile / epilogue decision
 void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
   if (a->dtype == FYC_F32) { cfg = (a->N % 128 == 0) ? 1 : 2; ns = 2; return; }
   GemmP q;
@@ -120,7 +122,7 @@ void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
 }
 // K slices per output tile (1 = no split) and the tile config a split problem uses
 int split_of(const fyc_gemm_args* a, int& cfg) {
-  if (a->dtype != FYC_BF16 || a->epilogue != FYC_EPI_LINEAR || a->act != FYC_ACT_NONE || a->batch > 1 || a->tile != 0 || g_fyc_tuning[1] > 0 || g_fyc_tuning[0] == 1) return 1;
+  if (!is16(a->dtype) || a->epilogue != FYC_EPI_LINEAR || a->act != FYC_ACT_NONE || a->batch > 1 || a->tile != 0 || g_fyc_tuning[1] > 0 || g_fyc_tuning[0] == 1) return 1;
   if (a->ln_stats != nullptr || a->chan_parts != nullptr || a->row_parts != nullptr) return 1;
   if (a->M > 4096 || a->K < 2048 || a->N % 8 != 0 || a->N < 256) return 1;
   const int c = (a->N % 320 == 0) ? 6 : 1;                     // 128x320 or 128x128 tiles
@@ -164,8 +166,8 @@ extern "C" int fyc_gemm_stat_layout(const fyc_gemm_args* a, int32_t* tile_rows, 
 extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   FYC_REQUIRE(a != nullptr, "fyc_gemm: null args");
   FYC_REQUIRE(g_fyc_zero_page != nullptr, "fyc_gemm: fyc_init() not called");
-  FYC_REQUIRE(a->dtype == FYC_F32 || a->dtype == FYC_BF16, "fyc_gemm: bad dtype %d", a->dtype);
-  const int es = a->dtype == FYC_BF16 ? 2 : 4, ch = 16 / es;
+  FYC_REQUIRE(a->dtype == FYC_F32 || is16(a->dtype), "fyc_gemm: bad dtype %d", a->dtype);
+  const int es = is16(a->dtype) ? 2 : 4, ch = 16 / es;
   FYC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "fyc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
   FYC_REQUIRE((a->ln_stats == nullptr) == (a->ln_colsum == nullptr) && (a->ln_stats == nullptr || (a->mode == FYC_GEMM_PLAIN && a->batch <= 1 && ((uintptr_t)a->ln_stats % 8) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0)),
               "fyc_gemm: ln_stats / ln_colsum must come together (PLAIN mode, no batch, 8-/16-byte aligned)");
@@ -260,15 +262,15 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(a->epilogue == FYC_EPI_LINEAR, "fyc_gemm: bad epilogue %d", a->epilogue);
     FYC_REQUIRE(a->out != nullptr, "fyc_gemm: out is null");
   }
-  p.wide = (a->dtype == FYC_BF16 && a->epilogue != FYC_EPI_HEADS && a->N % (a->epilogue == FYC_EPI_GEGLU ? 32 : 8) == 0 && a->ldo % 8 == 0 && a->stride_o % 8 == 0 &&
+  p.wide = (is16(a->dtype) && a->epilogue != FYC_EPI_HEADS && a->N % (a->epilogue == FYC_EPI_GEGLU ? 32 : 8) == 0 && a->ldo % 8 == 0 && a->stride_o % 8 == 0 &&
             ((uintptr_t)a->out % 16) == 0 && (a->residual == nullptr || (a->ldr % 8 == 0 && ((uintptr_t)a->residual % 16) == 0)) &&
             (a->bias == nullptr || ((uintptr_t)a->bias % 16) == 0) &&
             (a->rowbias == nullptr || (p.ldrb % 4 == 0 && ((uintptr_t)a->rowbias % 16) == 0)) && g_fyc_tuning[6] == 0) ? 1 : 0;
   // bias / colsum / rowbias rows may be fetched as 16-byte vectors and staged through LDS (always true for the engine's buffers)
-  p.colc = (a->dtype == FYC_BF16 && a->epilogue != FYC_EPI_GEGLU && a->N % 4 == 0 && ((uintptr_t)a->bias % 16) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0 &&
+  p.colc = (is16(a->dtype) && a->epilogue != FYC_EPI_GEGLU && a->N % 4 == 0 && ((uintptr_t)a->bias % 16) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0 &&
             (a->rowbias == nullptr || (p.ldrb % 4 == 0 && ((uintptr_t)a->rowbias % 16) == 0))) ? 1 : 0;
   if (p.wide) p.colc = 1;
-  if (a->dtype == FYC_BF16 && a->epilogue == FYC_EPI_HEADS && p.colc && g_fyc_tuning[6] == 0 && g_fyc_tuning[7] == 0 && p.head_dim % 8 == 0 && a->tokens % 16 == 0 && a->N % 8 == 0) {
+  if (is16(a->dtype) && a->epilogue == FYC_EPI_HEADS && p.colc && g_fyc_tuning[6] == 0 && g_fyc_tuning[7] == 0 && p.head_dim % 8 == 0 && a->tokens % 16 == 0 && a->N % 8 == 0) {
     bool ok = true;                                   // wide head-split epilogue: 16-byte runs into every segment
     for (int s = 0; s < a->N / a->seg_cols; ++s)
       ok = ok && ((uintptr_t)a->seg_out[s] % 16) == 0 && (!a->seg_transposed[s] || p.seg_ld[s] % 8 == 0);
@@ -290,6 +292,7 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
       p.wide = 0;
     }
   }
+  const bool f16 = a->dtype == FYC_F16;
   // the ping-pong main loop is built for bf16 problems with the 16-byte epilogues, whole 64-element K tiles (at least two) and no batch
   const bool pp_ok = a->dtype == FYC_BF16 && p.wide && batch == 1 && a->act == FYC_ACT_NONE && a->K % 64 == 0 && a->K >= 128;
   if (fycg::pp_cfg(cfg) && !pp_ok) cfg = pp_twin(cfg);
@@ -310,12 +313,17 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
       q.splitk = sk; q.ws = (float*)a->workspace;
       if (scfg == 6 && g_fyc_tuning[9] == 2 && pp_ok) scfg = 22;
       const int rc = fycg::pp_cfg(scfg) ? (a->mode == FYC_GEMM_PLAIN ? fycg::run_pp_plain(q, scfg, st) : fycg::run_pp_conv(q, scfg, st))
+                     : f16 ? ((a->mode == FYC_GEMM_PLAIN) ? fycg::run_f16_plain(q, batch, scfg, 2, st) : fycg::run_f16_conv(q, batch, scfg, 2, st))
                      : (a->mode == FYC_GEMM_PLAIN) ? fycg::run_bf16_plain(q, batch, scfg, 2, st) : fycg::run_bf16_conv(q, batch, scfg, 2, st);
       if (rc != 0) return rc;
       const long long items = (long long)a->M * (a->N / 8);
       const int blocks = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-      hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->workspace, sk, a->bias, a->rowbias, p.rows_per_batch, p.ldrb,
-                         (const bf16_t*)a->residual, a->ldr, (bf16_t*)a->out, a->ldo, a->M, a->N, a->out_scale);
+      if (f16)
+        hipLaunchKernelGGL(splitk_finish_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const float*)a->workspace, sk, a->bias, a->rowbias, p.rows_per_batch, p.ldrb,
+                           (const f16_t*)a->residual, a->ldr, (f16_t*)a->out, a->ldo, a->M, a->N, a->out_scale);
+      else
+        hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const float*)a->workspace, sk, a->bias, a->rowbias, p.rows_per_batch, p.ldrb,
+                           (const bf16_t*)a->residual, a->ldr, (bf16_t*)a->out, a->ldo, a->M, a->N, a->out_scale);
       FYC_CHECK_LAUNCH("fyc_gemm split-K finish");
       return 0;
     }
@@ -325,10 +333,11 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   if (a->dtype == FYC_F32) return fycg::run_f32(p, batch, cfg, st);
   if (p.act != FYC_ACT_NONE) {
     FYC_REQUIRE(a->mode == FYC_GEMM_PLAIN, "fyc_gemm: act needs the PLAIN mode");
-    return fycg::run_bf16_act(p, batch, cfg, st);
+    return f16 ? fycg::run_f16_act(p, batch, cfg, st) : fycg::run_bf16_act(p, batch, cfg, st);
   }
   if (fycg::ov_cfg(cfg)) return fycg::run_ov(p, cfg, st);
   if (fycg::pp_cfg(cfg)) return a->mode == FYC_GEMM_PLAIN ? fycg::run_pp_plain(p, cfg, st) : fycg::run_pp_conv(p, cfg, st);
+  if (f16) return a->mode == FYC_GEMM_PLAIN ? fycg::run_f16_plain(p, batch, cfg, ns, st) : fycg::run_f16_conv(p, batch, cfg, ns, st);
   if (a->mode == FYC_GEMM_PLAIN) return fycg::run_bf16_plain(p, batch, cfg, ns, st);
   return fycg::run_bf16_conv(p, batch, cfg, ns, st);
 }

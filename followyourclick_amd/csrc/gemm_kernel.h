@@ -98,6 +98,12 @@ template <> struct Mma<bf16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
+template <> struct Mma<f16_t> {
+  typedef f16x8 Frag;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   typedef f32x4 Frag;
   // lane quad g holds k = 4*chunk + {0..3}; MFMA #j contracts element j of all four quads.
@@ -210,7 +216,8 @@ __device__ __forceinline__ void ln_row(const GemmP& p, int m, float& mu, float& 
 
 template <typename T> __device__ __forceinline__ float round_to(float v);
 template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
-template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return round_through<bf16_t>(v); }
+template <> __device__ __forceinline__ float round_to<f16_t>(float v) { return round_through<f16_t>(v); }
 
 // Column constants of one output tile, staged through LDS once per tile: colc[0..BN) = bias (+ the rowbias row when it is the
 // same for the whole tile), colc[BN..2BN) = LayerNorm column sums.  Every global load in the epilogue is followed by an
@@ -257,7 +264,7 @@ __device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc,
 template <typename T, int BM, int BN, int WGM, int WGN, int STG_BYTES, int MODE>
 __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
                                                        long long bz, char* stg_stage, int wave, int lane) {
-  static_assert(sizeof(T) == 2, "bf16 only");
+  static_assert(sizeof(T) == 2, "16-bit outputs only (bf16 / f16)");
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
   constexpr bool LN = (MODE == FYC_GEMM_PLAIN);
   constexpr int PITCH = WTN * 32 + 16;               // bytes per staged row: the wave's WTN * 16 bf16 columns + 16 (keeps the 16-byte reads aligned)
@@ -325,7 +332,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += r4[r];
       }
-      unsigned lo = pack_bf16x2(v[0] * p.out_scale, v[1] * p.out_scale), hi = pack_bf16x2(v[2] * p.out_scale, v[3] * p.out_scale);
+      unsigned lo = Pair16<T>::pack(v[0] * p.out_scale, v[1] * p.out_scale), hi = Pair16<T>::pack(v[2] * p.out_scale, v[3] * p.out_scale);
       asm volatile("" : "+v"(lo), "+v"(hi));       // pin the conversion HERE (LLVM otherwise sinks it to the staging write of pass 2 and carries 4 floats instead of 2 words)
       pk[i][j] = (u32x2){lo, hi};
     }
@@ -390,7 +397,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
         if (do_cs || do_rp) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float x0 = __uint_as_float(v4[e] << 16), x1 = __uint_as_float(v4[e] & 0xffff0000u);
+            const float x0 = Pair16<T>::lo(v4[e]), x1 = Pair16<T>::hi(v4[e]);
             if (do_cs) {
               cs8[2 * e] += x0; cq8[2 * e] = __builtin_fmaf(x0, x0, cq8[2 * e]);
               cs8[2 * e + 1] += x1; cq8[2 * e + 1] = __builtin_fmaf(x1, x1, cq8[2 * e + 1]);
@@ -440,7 +447,7 @@ __device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[B
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int j = 0; j < WTN; ++j)
-      acc[i][j] = (f32x4){__uint_as_float(raw[i][j][0] << 16), __uint_as_float(raw[i][j][0] & 0xffff0000u), __uint_as_float(raw[i][j][1] << 16), __uint_as_float(raw[i][j][1] & 0xffff0000u)};
+      acc[i][j] = (f32x4){Pair16<T>::lo(raw[i][j][0]), Pair16<T>::hi(raw[i][j][0]), Pair16<T>::lo(raw[i][j][1]), Pair16<T>::hi(raw[i][j][1])};
 }
 
 // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j).
@@ -653,7 +660,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
               if (R) {
                 const u32x4 t = rres[i & 1][q];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) { v[2 * e] += Pair16<T>::lo(t[e]); v[2 * e + 1] += Pair16<T>::hi(t[e]); }
               }
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
@@ -661,7 +668,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
             // statistics of the values AS STORED: pack once (v_cvt_pk_bf16_f32), store, unpack with a shift / mask
             u32x4 pk;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            for (int e = 0; e < 4; ++e) pk[e] = Pair16<T>::pack(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n) = pk;
           }
         }
@@ -1177,5 +1184,9 @@ int run_bf16_plain(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
 int run_bf16_conv(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
 int run_bf16_act(const GemmP& p, int batch, int cfg, hipStream_t st);   // LINEAR + activation: tile configs 1, 2, 6
 int run_f32(const GemmP& p, int batch, int cfg, hipStream_t st);
+// f16 storage (FYC_F16): the same kernels on v_mfma_f32_16x16x32_f16
+int run_f16_plain(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
+int run_f16_conv(const GemmP& p, int batch, int cfg, int ns, hipStream_t st);
+int run_f16_act(const GemmP& p, int batch, int cfg, hipStream_t st);
 
 }  // namespace fycg

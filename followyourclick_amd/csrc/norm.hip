@@ -375,6 +375,8 @@ extern "C" int fyc_gn_stats(const fyc_gn_stats_args* a, void* stream) {
   const size_t sh = sizeof(float) * ((size_t)nthr * 16 + 2 * a->C);
   if (a->dtype == FYC_BF16)
     hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(nthr), sh, st, (const bf16_t*)a->x, a->stats, part, a->C, a->groups, a->rows_per_sample, rpb);
+  else if (a->dtype == FYC_F16)
+    hipLaunchKernelGGL(gn_stats_kernel<f16_t>, grid, dim3(nthr), sh, st, (const f16_t*)a->x, a->stats, part, a->C, a->groups, a->rows_per_sample, rpb);
   else if (a->dtype == FYC_F32)
     hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(nthr), sh, st, (const float*)a->x, a->stats, part, a->C, a->groups, a->rows_per_sample, rpb);
   else FYC_FAIL(-2, "fyc_gn_stats: bad dtype");
@@ -397,6 +399,9 @@ extern "C" int fyc_gn_apply(const fyc_gn_apply_args* a, void* stream) {
   if (a->dtype == FYC_BF16)
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a->x, a->stats, a->gamma, a->beta,
                        (bf16_t*)a->y, chunks, a->C, a->groups, a->rows_per_sample, a->eps, a->silu);
+  else if (a->dtype == FYC_F16)
+    hipLaunchKernelGGL(gn_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)a->x, a->stats, a->gamma, a->beta,
+                       (f16_t*)a->y, chunks, a->C, a->groups, a->rows_per_sample, a->eps, a->silu);
   else if (a->dtype == FYC_F32)
     hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a->x, a->stats, a->gamma, a->beta,
                        (float*)a->y, chunks, a->C, a->groups, a->rows_per_sample, a->eps, a->silu);
@@ -443,6 +448,9 @@ extern "C" int fyc_gn_apply_cs(const fyc_gn_apply_cs_args* a, void* stream) {
   if (a->dtype == FYC_BF16)
     hipLaunchKernelGGL(gn_apply_cs_kernel<bf16_t>, grid, dim3(nthr), sh, st, (const bf16_t*)a->x1, a->cs1, a->C1, (const bf16_t*)a->x2, a->cs2, a->C2,
                        a->gamma, a->beta, (bf16_t*)a->y, a->groups, a->rows_per_sample, rpb, a->eps, a->silu, stat_samples);
+  else if (a->dtype == FYC_F16)
+    hipLaunchKernelGGL(gn_apply_cs_kernel<f16_t>, grid, dim3(nthr), sh, st, (const f16_t*)a->x1, a->cs1, a->C1, (const f16_t*)a->x2, a->cs2, a->C2,
+                       a->gamma, a->beta, (f16_t*)a->y, a->groups, a->rows_per_sample, rpb, a->eps, a->silu, stat_samples);
   else if (a->dtype == FYC_F32)
     hipLaunchKernelGGL(gn_apply_cs_kernel<float>, grid, dim3(nthr), sh, st, (const float*)a->x1, a->cs1, a->C1, (const float*)a->x2, a->cs2, a->C2,
                        a->gamma, a->beta, (float*)a->y, a->groups, a->rows_per_sample, rpb, a->eps, a->silu, stat_samples);
@@ -462,6 +470,8 @@ extern "C" int fyc_layernorm(const fyc_layernorm_args* a, void* stream) {
   const int need = (a->C / 8 + 15) / 16;  // 16-B chunks per lane
   if (a->dtype == FYC_BF16) {
     if (need <= 3) FYC_LN(bf16_t, 3); else if (need <= 5) FYC_LN(bf16_t, 5); else if (need <= 10) FYC_LN(bf16_t, 10); else FYC_LN(bf16_t, 16);
+  } else if (a->dtype == FYC_F16) {
+    if (need <= 3) FYC_LN(f16_t, 3); else if (need <= 5) FYC_LN(f16_t, 5); else if (need <= 10) FYC_LN(f16_t, 10); else FYC_LN(f16_t, 16);
   } else if (a->dtype == FYC_F32) {
     if (need <= 3) FYC_LN(float, 3); else if (need <= 5) FYC_LN(float, 5); else if (need <= 10) FYC_LN(float, 10); else FYC_LN(float, 16);
   } else FYC_FAIL(-2, "fyc_layernorm: bad dtype");
@@ -479,6 +489,8 @@ extern "C" int fyc_row_stats(const fyc_row_stats_args* a, void* stream) {
   const int need = (a->C / 8 + 15) / 16;
   if (a->dtype == FYC_BF16) {
     if (need <= 3) FYC_RS(bf16_t, 3); else if (need <= 5) FYC_RS(bf16_t, 5); else if (need <= 10) FYC_RS(bf16_t, 10); else FYC_RS(bf16_t, 16);
+  } else if (a->dtype == FYC_F16) {
+    if (need <= 3) FYC_RS(f16_t, 3); else if (need <= 5) FYC_RS(f16_t, 5); else if (need <= 10) FYC_RS(f16_t, 10); else FYC_RS(f16_t, 16);
   } else if (a->dtype == FYC_F32) {
     if (need <= 3) FYC_RS(float, 3); else if (need <= 5) FYC_RS(float, 5); else if (need <= 10) FYC_RS(float, 10); else FYC_RS(float, 16);
   } else FYC_FAIL(-2, "fyc_row_stats: bad dtype");
@@ -493,6 +505,8 @@ extern "C" int fyc_softmax_rows(const fyc_softmax_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == FYC_BF16)
     hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)a->rows), dim3(256), 0, st, (bf16_t*)a->x, a->cols, a->ld, a->causal_rows);
+  else if (a->dtype == FYC_F16)
+    hipLaunchKernelGGL(softmax_rows_kernel<f16_t>, dim3((unsigned)a->rows), dim3(256), 0, st, (f16_t*)a->x, a->cols, a->ld, a->causal_rows);
   else if (a->dtype == FYC_F32)
     hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)a->rows), dim3(256), 0, st, (float*)a->x, a->cols, a->ld, a->causal_rows);
   else FYC_FAIL(-2, "fyc_softmax_rows: bad dtype");

@@ -60,12 +60,15 @@ __device__ __forceinline__ void dma_landed_barrier() {
   __syncthreads();
 }
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
+__device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <typename Frag> __device__ __forceinline__ Frag frag(const char* sl, int piece) { return *reinterpret_cast<const Frag*>(sl + piece * PIECE); }
 
 // KS = K / 32 MFMA k-steps (10 or 20); NPASS = N / 320 column passes (1 or 2), unrolled: the accumulators of a pass are dead
 // before the next one starts, and a runtime loop around this much unrolled code made the register allocator spill (ff_block.hip)
-template <int KS, int NPASS>
+// E16: the 16-bit element type of x / residual / out / the weight stream (bf16_t or f16_t; PLP's pointers are typed bf16_t for both)
+template <typename E16, int KS, int NPASS>
 __global__ void __launch_bounds__(NT) panel_linear_kernel(const PLP p) {
+  typedef typename Pair16<E16>::Vec8 Frag;
   constexpr int K = KS * 32, SPP = KS / 2;          // stages per pass
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const tile = smem + RING_BYTES;
@@ -82,13 +85,13 @@ __global__ void __launch_bounds__(NT) panel_linear_kernel(const PLP p) {
     dma16(p.ws + (long long)T * STAGE_BYTES + q * PIECE, lane16, lds0 + (T & 1) * STAGE_BYTES + q * PIECE);
   };
 
-  bf16x8 xa[2][KS];
+  Frag xa[2][KS];
   {
     const bf16_t* xr = p.x + (row0 + wave * 32 + r16) * K + g * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const bf16x8*>(xr + (long long)i * 16 * K + s * 32);
+      for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const Frag*>(xr + (long long)i * 16 * K + s * 32);
   }
 #pragma unroll
   for (int n = 0; n < 10; ++n) dma_piece(0, n);
@@ -135,9 +138,9 @@ __global__ void __launch_bounds__(NT) panel_linear_kernel(const PLP p) {
         u32x4 t = __builtin_bit_cast(u32x4, xa[i][s]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          t[e] = pack_bf16x2(__builtin_fmaf(__uint_as_float(t[e] << 16), sc[2 * e], sh[2 * e]),
-                             __builtin_fmaf(__uint_as_float(t[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]));
-        xa[i][s] = __builtin_bit_cast(bf16x8, t);
+          t[e] = Pair16<E16>::pack(__builtin_fmaf(Pair16<E16>::lo(t[e]), sc[2 * e], sh[2 * e]),
+                                 __builtin_fmaf(Pair16<E16>::hi(t[e]), sc[2 * e + 1], sh[2 * e + 1]));
+        xa[i][s] = __builtin_bit_cast(Frag, t);
       }
     }
     __syncthreads();                                                   // the table is dead: the tile region may take the residual DMA
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(NT) panel_linear_kernel(const PLP p) {
 #pragma unroll
       for (int u = 0; u < 2 * NB; ++u) {
         const int sk = u / NB, j = u % NB;
-        const bf16x8 wf = frag(sl, u);
+        const Frag wf = frag<Frag>(sl, u);
 #pragma unroll
         for (int i = 0; i < 2; ++i) oacc[i][j] = mfma(wf, xa[i][2 * st + sk], oacc[i][j]);
         if (u < 10 && T + 1 < NPASS * SPP) dma_piece(T + 1, u);
@@ -177,14 +180,14 @@ __global__ void __launch_bounds__(NT) panel_linear_kernel(const PLP p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        bf16_t* a = reinterpret_cast<bf16_t*>(tile + (wave * 32 + i * 16 + r16) * (PN * 2)) + j * 16 + g * 4;
+        E16* a = reinterpret_cast<E16*>(tile + (wave * 32 + i * 16 + r16) * (PN * 2)) + j * 16 + g * 4;
         f32x4 bo = {0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr) bo = *reinterpret_cast<const f32x4*>(p.bias + pass * PN + j * 16 + g * 4);
         float rr[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
-        if (p.res != nullptr) ElemIO<bf16_t>::ld4(a, rr);
+        if (p.res != nullptr) ElemIO<E16>::ld4(a, rr);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = oacc[i][j][r] + bo[r] + rr[r];
-        ElemIO<bf16_t>::st4(a, v);
+        ElemIO<E16>::st4(a, v);
       }
     __syncthreads();
     {
@@ -201,9 +204,9 @@ __global__ void __launch_bounds__(NT) panel_linear_kernel(const PLP p) {
   }
 }
 
-template <int KS, int NPASS>
+template <typename T, int KS, int NPASS>
 int launch(const PLP& p, int rows, hipStream_t st) {
-  auto kern = panel_linear_kernel<KS, NPASS>;
+  auto kern = panel_linear_kernel<T, KS, NPASS>;
   {
     constexpr int kMaxDev = 64;
     static std::mutex mu;
@@ -230,7 +233,7 @@ extern "C" int64_t fyc_panel_linear_wstream_bytes(int32_t N, int32_t K) {
 }
 
 extern "C" int fyc_panel_linear_supported(const fyc_panel_linear_args* a) {
-  if (a == nullptr || a->dtype != FYC_BF16 || a->rows <= 0 || a->rows % ROWS != 0) return 0;
+  if (a == nullptr || (a->dtype != FYC_BF16 && a->dtype != FYC_F16) || a->rows <= 0 || a->rows % ROWS != 0) return 0;
   if (!((a->K == 320 || a->K == 640) && (a->N == 320 || a->N == 640))) return 0;
   if (a->gn_cs != nullptr && (a->gn_rows_per_sample <= 0 || a->gn_rows_per_sample % ROWS != 0 || a->rows % a->gn_rows_per_sample != 0 ||
                               a->gn_groups <= 0 || a->K % a->gn_groups != 0 || a->gn_stat_samples <= 0)) return 0;
@@ -248,7 +251,7 @@ extern "C" int fyc_panel_linear_supported(const fyc_panel_linear_args* a) {
 
 extern "C" int fyc_panel_linear(const fyc_panel_linear_args* a, void* stream) {
   FYC_REQUIRE(a && a->x && a->out && a->wstream, "fyc_panel_linear: null pointer");
-  FYC_REQUIRE(fyc_panel_linear_supported(a), "fyc_panel_linear: built for bf16, rows %% 128 == 0, K and N in {320, 640}, GroupNorm samples of whole 128-row tiles (got rows=%d K=%d N=%d gn_rows_per_sample=%d)",
+  FYC_REQUIRE(fyc_panel_linear_supported(a), "fyc_panel_linear: built for bf16 / f16, rows %% 128 == 0, K and N in {320, 640}, GroupNorm samples of whole 128-row tiles (got rows=%d K=%d N=%d gn_rows_per_sample=%d)",
               a->rows, a->K, a->N, a->gn_rows_per_sample);
   FYC_REQUIRE(a->gn_cs == nullptr || (a->gn_gamma != nullptr && a->gn_beta != nullptr), "fyc_panel_linear: gn_cs needs gn_gamma / gn_beta");
   FYC_REQUIRE(a->x != a->out && a->residual != a->x, "fyc_panel_linear: out must not alias x (residual may alias out)");
@@ -259,6 +262,10 @@ extern "C" int fyc_panel_linear(const fyc_panel_linear_args* a, void* stream) {
   p.gn_cs = a->gn_cs; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta; p.gn_rows_per_sample = a->gn_rows_per_sample;
   p.gn_stat_samples = a->gn_stat_samples; p.gn_groups = a->gn_groups; p.gn_eps = a->gn_eps; p.N = a->N;
   hipStream_t st = (hipStream_t)stream;
-  if (a->K == 320) return a->N == 320 ? launch<10, 1>(p, a->rows, st) : launch<10, 2>(p, a->rows, st);
-  return a->N == 320 ? launch<20, 1>(p, a->rows, st) : launch<20, 2>(p, a->rows, st);
+  if (a->dtype == FYC_F16) {
+    if (a->K == 320) return a->N == 320 ? launch<f16_t, 10, 1>(p, a->rows, st) : launch<f16_t, 10, 2>(p, a->rows, st);
+    return a->N == 320 ? launch<f16_t, 20, 1>(p, a->rows, st) : launch<f16_t, 20, 2>(p, a->rows, st);
+  }
+  if (a->K == 320) return a->N == 320 ? launch<bf16_t, 10, 1>(p, a->rows, st) : launch<bf16_t, 10, 2>(p, a->rows, st);
+  return a->N == 320 ? launch<bf16_t, 20, 1>(p, a->rows, st) : launch<bf16_t, 20, 2>(p, a->rows, st);
 }

@@ -6,7 +6,7 @@
 // pure index arithmetic here: one wave64 owns one (clip b, pixel p, head h) task and gathers the
 // F rows of that pixel (row stride P*3C) straight into MFMA operand registers.
 //
-// bf16 path (v_mfma_f32_16x16x32_bf16), F <= 32:
+// 16-bit path (v_mfma_f32_16x16x32_bf16 / _f16: template parameter T), F <= 32:
 //   S^T = K Q^T (rows = key frames, cols = query frames), full softmax in registers (all keys of a
 //   query are in 4 lanes x 4..8 regs), O^T = V^T P^T with the keys as the 32 MFMA k-slots.
 // f32 path: scalar reference-precision kernel (parity mode only).
@@ -21,8 +21,13 @@ struct TAttnP {
   const char* zero;
 };
 
-template <int DP, int DVT, int NFT>
+template <typename T> struct TMma;
+template <> struct TMma<bf16_t> { __device__ static __forceinline__ f32x4 k32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); } };
+template <> struct TMma<f16_t> { __device__ static __forceinline__ f32x4 k32(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
+
+template <typename T, int DP, int DVT, int NFT>
 __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
+  typedef typename Pair16<T>::Vec8 Frag;
   constexpr int KS = DP / 32;
   const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
   const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -32,12 +37,12 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
   const long long bp = task / p.heads;
   const int pix = (int)(bp % p.pixels), b = (int)(bp / p.pixels);
   const int F = p.frames, C = p.heads * p.d, ld = 3 * C;
-  const bf16_t* base = reinterpret_cast<const bf16_t*>(p.qkv) + ((long long)b * F * p.pixels + pix) * ld + h * p.d;
+  const T* base = reinterpret_cast<const T*>(p.qkv) + ((long long)b * F * p.pixels + pix) * ld + h * p.d;
   const long long fstride = (long long)p.pixels * ld;  // elements between consecutive frames of a pixel
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(p.zero);
+  const T* zero = reinterpret_cast<const T*>(p.zero);
 
   // Q / K fragments: lane (frame = 16*tile + r16, quad g) holds 8 consecutive head channels
-  bf16x8 qf[NFT][KS], kf[NFT][KS];
+  Frag qf[NFT][KS], kf[NFT][KS];
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft) {
     const int fr = ft * 16 + r16;
@@ -45,8 +50,8 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
     for (int ks = 0; ks < KS; ++ks) {
       const int dd = 32 * ks + 8 * g;
       const bool ok = fr < F && dd < p.d;
-      qf[ft][ks] = *reinterpret_cast<const bf16x8*>(ok ? base + fr * fstride + dd : zero);
-      kf[ft][ks] = *reinterpret_cast<const bf16x8*>(ok ? base + fr * fstride + C + dd : zero);
+      qf[ft][ks] = *reinterpret_cast<const Frag*>(ok ? base + fr * fstride + dd : zero);
+      kf[ft][ks] = *reinterpret_cast<const Frag*>(ok ? base + fr * fstride + C + dd : zero);
     }
   }
   // V^T fragments: lane (dv = 16*t + r16, quad g): k-slot j<4 <-> frame 4g+j, j>=4 <-> frame 16+4g+(j-4).  The operand wants
@@ -63,11 +68,11 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
     for (int ks = 0; ks < KS; ++ks) {
       const int dd = 32 * ks + 8 * g;
       const bool ok = fr < F && dd < p.d;
-      *reinterpret_cast<bf16x8*>(&vt[fr][dd]) = *reinterpret_cast<const bf16x8*>(ok ? base + fr * fstride + 2 * C + dd : zero);
+      *reinterpret_cast<Frag*>(&vt[fr][dd]) = *reinterpret_cast<const Frag*>(ok ? base + fr * fstride + 2 * C + dd : zero);
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // same wave wrote and reads: LDS ops of a wave complete in order
-  bf16x8 vf[DVT];
+  Frag vf[DVT];
 #pragma unroll
   for (int t = 0; t < DVT; ++t) {
     const int dv = t * 16 + r16;
@@ -81,11 +86,11 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
     u32x4 pk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) pk[i] = (unsigned)e[2 * i] | ((unsigned)e[2 * i + 1] << 16);
-    vf[t] = __builtin_bit_cast(bf16x8, pk);
+    vf[t] = __builtin_bit_cast(Frag, pk);
   }
 
   const float sl2e = p.scale * 1.44269504088896340736f;
-  bf16_t* obase = reinterpret_cast<bf16_t*>(p.o) + ((long long)b * F * p.pixels + pix) * C + h * p.d;
+  T* obase = reinterpret_cast<T*>(p.o) + ((long long)b * F * p.pixels + pix) * C + h * p.d;
   const long long ofstride = (long long)p.pixels * C;
 
 #pragma unroll
@@ -96,7 +101,7 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
     for (int kt = 0; kt < NFT; ++kt) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][ks], qf[qt][ks], a, 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) a = TMma<T>::k32(kf[kt][ks], qf[qt][ks], a);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (kt * 16 + 4 * g + r >= F) a[r] = -INFINITY;
@@ -124,17 +129,17 @@ __global__ void __launch_bounds__(256) tattn_bf16_kernel(const TAttnP p) {
     u32x4 pk;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      pk[i] = (unsigned)f32_to_bf16_bits(pv[2 * i] * inv) | ((unsigned)f32_to_bf16_bits(pv[2 * i + 1] * inv) << 16);
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+      pk[i] = (unsigned)Pair16<T>::to_bits(pv[2 * i] * inv) | ((unsigned)Pair16<T>::to_bits(pv[2 * i + 1] * inv) << 16);
+    const Frag pf = __builtin_bit_cast(Frag, pk);
     const int fq = qt * 16 + r16;
 #pragma unroll
     for (int t = 0; t < DVT; ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t], pf, acc, 0, 0, 0);
+      acc = TMma<T>::k32(vf[t], pf, acc);
       const int dd = t * 16 + 4 * g;
       if (fq < F && dd < p.d) {
         float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-        ElemIO<bf16_t>::st4(obase + fq * ofstride + dd, v);
+        ElemIO<T>::st4(obase + fq * ofstride + dd, v);
       }
     }
   }
@@ -174,14 +179,25 @@ __global__ void __launch_bounds__(256) tattn_f32_kernel(const TAttnP p) {
   }
 }
 
-template <int DP, int DVT>
+template <typename T, int DP, int DVT>
 int launch_t(const TAttnP& p, hipStream_t st) {
   const long long ntask = (long long)p.clips * p.pixels * p.heads;
   dim3 grid((unsigned)((ntask + 3) / 4));
-  if (p.frames <= 16) hipLaunchKernelGGL((tattn_bf16_kernel<DP, DVT, 1>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((tattn_bf16_kernel<DP, DVT, 2>), grid, dim3(256), 0, st, p);
+  if (p.frames <= 16) hipLaunchKernelGGL((tattn_bf16_kernel<T, DP, DVT, 1>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((tattn_bf16_kernel<T, DP, DVT, 2>), grid, dim3(256), 0, st, p);
   FYC_CHECK_LAUNCH("fyc_temporal_attention");
   return 0;
+}
+
+template <typename T>
+int launch_d(const TAttnP& p, hipStream_t st) {
+  if (p.d <= 32) return launch_t<T, 32, 2>(p, st);
+  if (p.d <= 48) return launch_t<T, 64, 3>(p, st);
+  if (p.d <= 64) return launch_t<T, 64, 4>(p, st);
+  if (p.d <= 80) return launch_t<T, 96, 5>(p, st);
+  if (p.d <= 96) return launch_t<T, 96, 6>(p, st);
+  if (p.d <= 128) return launch_t<T, 128, 8>(p, st);
+  return launch_t<T, 160, 10>(p, st);
 }
 
 }  // namespace
@@ -202,12 +218,6 @@ extern "C" int fyc_temporal_attention(const fyc_tattn_args* a, void* stream) {
     FYC_CHECK_LAUNCH("fyc_temporal_attention(f32)");
     return 0;
   }
-  FYC_REQUIRE(a->dtype == FYC_BF16, "fyc_temporal_attention: bad dtype");
-  if (a->d <= 32) return launch_t<32, 2>(p, st);
-  if (a->d <= 48) return launch_t<64, 3>(p, st);
-  if (a->d <= 64) return launch_t<64, 4>(p, st);
-  if (a->d <= 80) return launch_t<96, 5>(p, st);
-  if (a->d <= 96) return launch_t<96, 6>(p, st);
-  if (a->d <= 128) return launch_t<128, 8>(p, st);
-  return launch_t<160, 10>(p, st);
+  FYC_REQUIRE(a->dtype == FYC_BF16 || a->dtype == FYC_F16, "fyc_temporal_attention: bad dtype");
+  return a->dtype == FYC_F16 ? launch_d<f16_t>(p, st) : launch_d<bf16_t>(p, st);
 }

@@ -41,7 +41,14 @@ constexpr int LDS_BYTES = X_BYTES + W_BYTES + Q_BYTES + S_BYTES;
 static_assert(C_ * OP <= W_BYTES, "the w_out slice of a head reuses the w_qkv K-tile buffers");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
+template <typename T> struct BMma;
+template <> struct BMma<bf16_t> { __device__ static __forceinline__ f32x4 k32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); } };
+template <> struct BMma<f16_t> { __device__ static __forceinline__ f32x4 k32(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
+
+// T: the 16-bit element type of x / out / the weights (bf16_t or f16_t; TBlockP's pointers are typed bf16_t for both: same arithmetic)
+template <typename T>
 __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
+  typedef typename Pair16<T>::Vec8 Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
   char* sW = sX + X_BYTES;
@@ -70,7 +77,7 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
     float s = 0.f, q = 0.f;
     for (int ch = part * 10; ch < part * 10 + 10; ++ch) {
       float v[8];
-      load8<bf16_t>(reinterpret_cast<const bf16_t*>(sX + row * XP + ch * 16), v);
+      load8<T>(reinterpret_cast<const T*>(sX + row * XP + ch * 16), v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s += v[e]; q = __builtin_fmaf(v[e], v[e], q); }
     }
@@ -90,7 +97,7 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) oacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+  const Frag zero8 = __builtin_bit_cast(Frag, (u32x4){0u, 0u, 0u, 0u});
 
   // The 8 x 5 K tiles of w_qkv are one stream: a thread keeps the five tiles of the NEXT head in registers (slot = K tile), loaded
   // while the current head computes - one head of work (several us) covers the L2 latency that a one-tile-ahead prefetch left
@@ -130,15 +137,15 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
       const char* wb = sW + (kt & 1) * (128 * WP);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[4], bf[2];
+        Frag af[4], bf[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sX + (wm * 64 + i * 16 + r16) * XP + (kt * 64 + ks * 32 + g * 8) * 2);
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const Frag*>(sX + (wm * 64 + i * 16 + r16) * XP + (kt * 64 + ks * 32 + g * 8) * 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(wb + (wn * 32 + j * 16 + r16) * WP + (ks * 32 + g * 8) * 2);
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const Frag*>(wb + (wn * 32 + j * 16 + r16) * WP + (ks * 32 + g * 8) * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) qacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], qacc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) qacc[i][j] = BMma<T>::k32(bf[j], af[i], qacc[i][j]);
       }
       if (kt + 1 < KT) {
         wstore((kt + 1) & 1, wreg[kt + 1]);
@@ -163,7 +170,7 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = rs * (qacc[i][j][r] - mu * c4[r]) + b4[r] + pe4[r];
-          ElemIO<bf16_t>::st4(reinterpret_cast<bf16_t*>(sQ + row * QP) + col, v);
+          ElemIO<T>::st4(reinterpret_cast<T*>(sQ + row * QP) + col, v);
         }
       }
     }
@@ -184,15 +191,15 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
     // ---- phase B: attention over the 16 frames of pixel `wave` (rows wave*16 .. +15), as fyc_temporal_attention ------------
     {
       const char* qrow = sQ + (wave * 16 + r16) * QP;        // this lane's frame row
-      bf16x8 qf[2], kf[2];
+      Frag qf[2], kf[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int dd = 32 * ks + 8 * g;
-        qf[ks] = dd < D_ ? *reinterpret_cast<const bf16x8*>(qrow + dd * 2) : zero8;
-        kf[ks] = dd < D_ ? *reinterpret_cast<const bf16x8*>(qrow + (D_ + dd) * 2) : zero8;
+        qf[ks] = dd < D_ ? *reinterpret_cast<const Frag*>(qrow + dd * 2) : zero8;
+        kf[ks] = dd < D_ ? *reinterpret_cast<const Frag*>(qrow + (D_ + dd) * 2) : zero8;
       }
       // V^T fragments: lane (dv = 16 t + r16, quad g) holds frames 4g .. 4g+3 in k-slots 0..3 (k-slots 4..7: frames 16+, none)
-      bf16x8 vf[3];
+      Frag vf[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int dv = t * 16 + r16;
@@ -201,11 +208,11 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
         for (int j = 0; j < 4; ++j)
           e[j] = dv < D_ ? *reinterpret_cast<const unsigned short*>(sQ + (wave * 16 + 4 * g + j) * QP + (2 * D_ + dv) * 2) : (unsigned short)0;
         const u32x4 pk = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), 0u, 0u};
-        vf[t] = __builtin_bit_cast(bf16x8, pk);
+        vf[t] = __builtin_bit_cast(Frag, pk);
       }
       f32x4 s = {0.f, 0.f, 0.f, 0.f};                        // S^T: key frame 4g + r, query frame r16
-      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[1], s, 0, 0, 0);
+      s = BMma<T>::k32(kf[0], qf[0], s);
+      s = BMma<T>::k32(kf[1], qf[1], s);
       float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -215,19 +222,19 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
       const float inv = 1.0f / sum;
-      const u32x4 ppk = {(unsigned)f32_to_bf16_bits(e4[0] * inv) | ((unsigned)f32_to_bf16_bits(e4[1] * inv) << 16),
-                         (unsigned)f32_to_bf16_bits(e4[2] * inv) | ((unsigned)f32_to_bf16_bits(e4[3] * inv) << 16), 0u, 0u};
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, ppk);
+      const u32x4 ppk = {(unsigned)Pair16<T>::to_bits(e4[0] * inv) | ((unsigned)Pair16<T>::to_bits(e4[1] * inv) << 16),
+                         (unsigned)Pair16<T>::to_bits(e4[2] * inv) | ((unsigned)Pair16<T>::to_bits(e4[3] * inv) << 16), 0u, 0u};
+      const Frag pf = __builtin_bit_cast(Frag, ppk);
       // O^T = V^T P^T: channel 16 t + 4g + r of query frame r16 -> in place over the q columns of the lane's own row.  All of
       // this wave's reads of its 16 rows (q, k, v above) are complete: the MFMAs that consumed them have been issued in order.
       f32x4 o[3];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t], pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int t = 0; t < 3; ++t) o[t] = BMma<T>::k32(vf[t], pf, (f32x4){0.f, 0.f, 0.f, 0.f});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         float v[4] = {o[t][0], o[t][1], o[t][2], o[t][3]};   // channels >= 40 are exact zeros (vf rows of zeros): the K padding
-        ElemIO<bf16_t>::st4(reinterpret_cast<bf16_t*>(sQ + (wave * 16 + r16) * QP) + t * 16 + 4 * g, v);
+        ElemIO<T>::st4(reinterpret_cast<T*>(sQ + (wave * 16 + r16) * QP) + t * 16 + 4 * g, v);
       }
     }
 #pragma unroll
@@ -241,15 +248,15 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kk = ks * 32 + g * 8;
-      bf16x8 af[4], bf[5];
+      Frag af[4], bf[5];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = kk < 48 ? *reinterpret_cast<const bf16x8*>(sQ + (wm * 64 + i * 16 + r16) * QP + kk * 2) : zero8;
+      for (int i = 0; i < 4; ++i) af[i] = kk < 48 ? *reinterpret_cast<const Frag*>(sQ + (wm * 64 + i * 16 + r16) * QP + kk * 2) : zero8;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) bf[j] = kk < 48 ? *reinterpret_cast<const bf16x8*>(sW + (wn * 80 + j * 16 + r16) * OP + kk * 2) : zero8;
+      for (int j = 0; j < 5; ++j) bf[j] = kk < 48 ? *reinterpret_cast<const Frag*>(sW + (wn * 80 + j * 16 + r16) * OP + kk * 2) : zero8;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], oacc[i][j], 0, 0, 0);
+        for (int j = 0; j < 5; ++j) oacc[i][j] = BMma<T>::k32(bf[j], af[i], oacc[i][j]);
     }
     // (the barrier at the top of the next head orders these reads before sW / sQ are overwritten)
   }
@@ -262,13 +269,13 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int col = wn * 80 + j * 16 + g * 4;
-      bf16_t* xr = reinterpret_cast<bf16_t*>(sX + row * XP) + col;
+      T* xr = reinterpret_cast<T*>(sX + row * XP) + col;
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b_out + col);
       float res[4], v[4];
-      ElemIO<bf16_t>::ld4(xr, res);
+      ElemIO<T>::ld4(xr, res);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = oacc[i][j][r] + b4[r] + res[r];
-      ElemIO<bf16_t>::st4(xr, v);
+      ElemIO<T>::st4(xr, v);
     }
   }
   __syncthreads();
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(512) temporal_block_kernel(const TBlockP p) {
 }  // namespace
 
 extern "C" int fyc_temporal_block_supported(const fyc_temporal_block_args* a) {
-  if (!(a != nullptr && a->dtype == FYC_BF16 && a->C == C_ && a->heads == H_ && a->d == D_ && a->frames == F_ && a->pixels > 0 &&
+  if (!(a != nullptr && (a->dtype == FYC_BF16 || a->dtype == FYC_F16) && a->C == C_ && a->heads == H_ && a->d == D_ && a->frames == F_ && a->pixels > 0 &&
         a->pixels % PIX == 0 && a->clips > 0)) return 0;
   static std::mutex mu;                            // LDS per CU of this process's device, queried once (0: no device answered)
   static int64_t lds_cap = -1;
@@ -300,7 +307,7 @@ extern "C" int64_t fyc_temporal_block_wstream_bytes(void) { return fyc_temporal_
 
 extern "C" int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream) {
   FYC_REQUIRE(a && a->x && a->out && a->b_out && (a->wstream || (a->w_qkv && a->colsum && a->bias && a->w_out)), "fyc_temporal_block: null pointer");
-  FYC_REQUIRE(fyc_temporal_block_supported(a), "fyc_temporal_block: built for bf16, C=320, 8 heads of 40, 16 frames, pixels %% 8 == 0 (got C=%d heads=%d d=%d frames=%d pixels=%d)",
+  FYC_REQUIRE(fyc_temporal_block_supported(a), "fyc_temporal_block: built for bf16 / f16, C=320, 8 heads of 40, 16 frames, pixels %% 8 == 0 (got C=%d heads=%d d=%d frames=%d pixels=%d)",
               a->C, a->heads, a->d, a->frames, a->pixels);
   FYC_REQUIRE(a->x != a->out, "fyc_temporal_block: in-place operation is not supported (tiles read rows of every frame)");
   if (a->wstream != nullptr) return fyc_temporal_block_rr_launch(a, stream);      // pre-packed stream: the register-resident kernel
@@ -316,12 +323,14 @@ extern "C" int fyc_temporal_block(const fyc_temporal_block_args* a, void* stream
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_block_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_block_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) FYC_FAIL(-3, "fyc_temporal_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
       if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;      // only after success: a failed call is retried
     }
   }
-  hipLaunchKernelGGL(temporal_block_kernel, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+  if (a->dtype == FYC_F16) hipLaunchKernelGGL(temporal_block_kernel<f16_t>, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(temporal_block_kernel<bf16_t>, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_temporal_block");
   return 0;
 }

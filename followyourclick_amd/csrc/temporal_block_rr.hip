@@ -72,11 +72,12 @@ __device__ __forceinline__ void dma_landed_barrier() {
   __syncthreads();
 }
 #ifdef TB_NO_MFMA                                              // ablation build: DMA + LDS reads + barriers only, wrong results
-__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { c[0] += __builtin_bit_cast(f32x4, a)[0] + __builtin_bit_cast(f32x4, b)[0]; return c; }
+template <typename Frag> __device__ __forceinline__ f32x4 mfma(Frag a, Frag b, f32x4 c) { c[0] += __builtin_bit_cast(f32x4, a)[0] + __builtin_bit_cast(f32x4, b)[0]; return c; }
 #else
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 #endif
-__device__ __forceinline__ bf16x8 frag(const char* sl, int piece) { return *reinterpret_cast<const bf16x8*>(sl + piece * PIECE); }
+template <typename Frag> __device__ __forceinline__ Frag frag(const char* sl, int piece) { return *reinterpret_cast<const Frag*>(sl + piece * PIECE); }
 
 // reductions over the four 16-lane rows of a wave by v_permlane16_swap / v_permlane32_swap: plain VALU.  No LDS-queue instruction
 // (ds_bpermute = __shfl_xor) may sit between asm-issued DMAs: profiles/r03_ff_block_race.txt
@@ -92,11 +93,11 @@ __device__ __forceinline__ float rows_max(float v) {
   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
-__device__ __forceinline__ bf16x8 op8(const f32x4& a, const f32x4& b) {          // two 4-row results -> one 8-slot operand
-  return __builtin_bit_cast(bf16x8, (u32x4){pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])});
+template <typename T> __device__ __forceinline__ typename Pair16<T>::Vec8 op8(const f32x4& a, const f32x4& b) {          // two 4-row results -> one 8-slot operand
+  return __builtin_bit_cast(typename Pair16<T>::Vec8, (u32x4){Pair16<T>::pack(a[0], a[1]), Pair16<T>::pack(a[2], a[3]), Pair16<T>::pack(b[0], b[1]), Pair16<T>::pack(b[2], b[3])});
 }
-__device__ __forceinline__ bf16x8 op4(const f32x4& a) {                          // one 4-row result, upper slots zero
-  return __builtin_bit_cast(bf16x8, (u32x4){pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), 0u, 0u});
+template <typename T> __device__ __forceinline__ typename Pair16<T>::Vec8 op4(const f32x4& a) {                          // one 4-row result, upper slots zero
+  return __builtin_bit_cast(typename Pair16<T>::Vec8, (u32x4){Pair16<T>::pack(a[0], a[1]), Pair16<T>::pack(a[2], a[3]), 0u, 0u});
 }
 
 #ifdef TB_TIMING                                                // phase timestamps of wave 0 of every workgroup (tools/tblock_probe.py --timing)
@@ -106,7 +107,10 @@ __device__ unsigned long long g_tb_time[1024 * 24];
 #define TB_MARK(k) do {} while (0)
 #endif
 
+// T: the 16-bit element type of x / out / the weight stream (bf16_t or f16_t; TRP's pointers are typed bf16_t for both)
+template <typename T>
 __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
+  typedef typename Pair16<T>::Vec8 Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,13 +125,13 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
   bf16_t* ob = p.out + ((long long)clip * F_ * p.pixels + p0) * C_;
 
   // ---- the wave's 2 pixels x 16 frames as MFMA operands: lane (frame r16, quad g) holds x[pixel 2 wave + i][frame][32 s + 8 g .. +8]
-  bf16x8 xa[2][KS];
+  Frag xa[2][KS];
   {
     const bf16_t* xr = xb + r16 * fstride + (2 * wave) * C_ + g * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const bf16x8*>(xr + i * C_ + s * 32);
+      for (int s = 0; s < KS; ++s) xa[i][s] = *reinterpret_cast<const Frag*>(xr + i * C_ + s * 32);
   }
   TB_MARK(0);
   {                                                           // stage 0 (head 0, A) into slot 0
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
     for (int k = 0; k < KS; ++k) {
       const u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s += __uint_as_float(t[e] << 16) + __uint_as_float(t[e] & 0xffff0000u);
+      for (int e = 0; e < 4; ++e) s += Pair16<T>::lo(t[e]) + Pair16<T>::hi(t[e]);
     }
     const float m = rows_sum(s) * (1.0f / C_);
     float q = 0.f;
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
       const u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float a = __uint_as_float(t[e] << 16) - m, b = __uint_as_float(t[e] & 0xffff0000u) - m;
+        const float a = Pair16<T>::lo(t[e]) - m, b = Pair16<T>::hi(t[e]) - m;
         q = __builtin_fmaf(a, a, q);
         q = __builtin_fmaf(b, b, q);
       }
@@ -164,8 +168,8 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
       u32x4 t = __builtin_bit_cast(u32x4, xa[i][k]);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        t[e] = pack_bf16x2((__uint_as_float(t[e] << 16) - m) * rs, (__uint_as_float(t[e] & 0xffff0000u) - m) * rs);
-      xa[i][k] = __builtin_bit_cast(bf16x8, t);
+        t[e] = Pair16<T>::pack((Pair16<T>::lo(t[e]) - m) * rs, (Pair16<T>::hi(t[e]) - m) * rs);
+      xa[i][k] = __builtin_bit_cast(Frag, t);
     }
   }
 
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
     dma16(p.ws + (long long)tnext * STAGE_BYTES + q * PIECE, lane16, lds0 + (tnext & 1) * STAGE_BYTES + q * PIECE);
   };
 
-  bf16x8 q_op[2][2], k_op[2][2];
+  Frag q_op[2][2], k_op[2][2];
 
   // ---- stage A of a head (slot 0): q^T, k^T = W' xn^T (+ bias + positional encoding), packed as operands of S^T ------------
   auto stage_a = [&](int t) {
@@ -196,14 +200,14 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int b = 0; b < 6; ++b) qk[i][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 w[6], w1[6];                                       // fragments two k-steps ahead of their MFMAs: one k-step (192 cycles of
+    Frag w[6], w1[6];                                       // fragments two k-steps ahead of their MFMAs: one k-step (192 cycles of
 #pragma unroll                                                 // MFMA) does not cover an LDS round trip while DMA pieces are landing
-    for (int b = 0; b < 6; ++b) { w[b] = frag(sl, b); w1[b] = frag(sl, 6 + b); }
+    for (int b = 0; b < 6; ++b) { w[b] = frag<Frag>(sl, b); w1[b] = frag<Frag>(sl, 6 + b); }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      bf16x8 n[6];
+      Frag n[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) n[b] = (s + 2 < KS) ? frag(sl, (s + 2) * 6 + b) : w1[b];
+      for (int b = 0; b < 6; ++b) n[b] = (s + 2 < KS) ? frag<Frag>(sl, (s + 2) * 6 + b) : w1[b];
 #pragma unroll
       for (int b = 0; b < 6; ++b)
 #pragma unroll
@@ -219,10 +223,10 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int b = 0; b < 6; ++b) qk[i][b] += *reinterpret_cast<const f32x4*>(tab + b * 16);
-      q_op[i][0] = op8(qk[i][0], qk[i][1]);
-      q_op[i][1] = op4(qk[i][2]);
-      k_op[i][0] = op8(qk[i][3], qk[i][4]);
-      k_op[i][1] = op4(qk[i][5]);
+      q_op[i][0] = op8<T>(qk[i][0], qk[i][1]);
+      q_op[i][1] = op4<T>(qk[i][2]);
+      k_op[i][0] = op8<T>(qk[i][3], qk[i][4]);
+      k_op[i][1] = op4<T>(qk[i][5]);
     }
   };
 
@@ -242,14 +246,14 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int b = 0; b < 3; ++b) v[i][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 w[3], w1[3], w2[3];                                // three k-steps ahead: a k-step is only 6 MFMAs here
+    Frag w[3], w1[3], w2[3];                                // three k-steps ahead: a k-step is only 6 MFMAs here
 #pragma unroll
-    for (int b = 0; b < 3; ++b) { w[b] = frag(sl, b); w1[b] = frag(sl, 3 + b); w2[b] = frag(sl, 6 + b); }
+    for (int b = 0; b < 3; ++b) { w[b] = frag<Frag>(sl, b); w1[b] = frag<Frag>(sl, 3 + b); w2[b] = frag<Frag>(sl, 6 + b); }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      bf16x8 n[3];
+      Frag n[3];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) n[b] = (s + 3 < KS) ? frag(sl, (s + 3) * 3 + b) : w2[b];
+      for (int b = 0; b < 3; ++b) n[b] = (s + 3 < KS) ? frag<Frag>(sl, (s + 3) * 3 + b) : w2[b];
 #pragma unroll
       for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
       }
     }
     // softmax over the 16 keys of a query: a lane holds keys 4 g .. 4 g + 3 of query r16
-    bf16x8 p_op[2];
+    Frag p_op[2];
     float inv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -281,33 +285,33 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) sv[e] = __builtin_amdgcn_exp2f(sv[e] - m);
       inv[i] = __builtin_amdgcn_rcpf(rows_sum((sv[0] + sv[1]) + (sv[2] + sv[3])));
-      p_op[i] = op4(sv);
+      p_op[i] = op4<T>(sv);
     }
-    bf16x8 wo[4], wo1[4];                                     // the first Wo' fragments are requested before the attention chain
+    Frag wo[4], wo1[4];                                     // the first Wo' fragments are requested before the attention chain
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { wo[q] = frag(sl, B_WO + q); wo1[q] = frag(sl, B_WO + 4 + q); }
+    for (int q = 0; q < 4; ++q) { wo[q] = frag<Frag>(sl, B_WO + q); wo1[q] = frag<Frag>(sl, B_WO + 4 + q); }
     const float* tab = reinterpret_cast<const float*>(base + B_TAB * PIECE) + r16 * 16 + g * 4;      // [feature 48][frame]
-    bf16x8 o_op[2][2];
+    Frag o_op[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       f32x4 ot[3];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         v[i][b] += *reinterpret_cast<const f32x4*>(tab + b * 256);
-        ot[b] = mfma(op4(v[i][b]), p_op[i], (f32x4){0.f, 0.f, 0.f, 0.f});
+        ot[b] = mfma(op4<T>(v[i][b]), p_op[i], (f32x4){0.f, 0.f, 0.f, 0.f});
       }
 #pragma unroll
       for (int b = 0; b < 3; ++b) ot[b] *= inv[i];
-      o_op[i][0] = op8(ot[0], ot[1]);
-      o_op[i][1] = op4(ot[2]);
+      o_op[i][0] = op8<T>(ot[0], ot[1]);
+      o_op[i][1] = op4<T>(ot[2]);
     }
     // output projection of the head: 20 column blocks x 2 k-steps, four fragments in flight
 #pragma unroll
     for (int u = 0; u < 2 * NB / 4; ++u) {                     // u = t2 * 5 + jb: pieces B_WO + 4 u .. + 4, two groups in flight
       const int t2 = u / (NB / 4), jb = u - t2 * (NB / 4);
-      bf16x8 n[4];
+      Frag n[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) n[q] = (u + 2 < 2 * NB / 4) ? frag(sl, B_WO + (u + 2) * 4 + q) : wo1[q];
+      for (int q = 0; q < 4; ++q) n[q] = (u + 2 < 2 * NB / 4) ? frag<Frag>(sl, B_WO + (u + 2) * 4 + q) : wo1[q];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -344,13 +348,13 @@ __global__ void __launch_bounds__(NT) tblock_rr_kernel(const TRP p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      bf16_t* a = reinterpret_cast<bf16_t*>(smem + ((2 * wave + i) * 16 + r16) * TP) + j * 16 + g * 4;
+      T* a = reinterpret_cast<T*>(smem + ((2 * wave + i) * 16 + r16) * TP) + j * 16 + g * 4;
       const f32x4 bo = *reinterpret_cast<const f32x4*>(p.b_out + j * 16 + g * 4);
       float rr[4], vv[4];
-      ElemIO<bf16_t>::ld4(a, rr);
+      ElemIO<T>::ld4(a, rr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) vv[r] = oacc[i][j][r] + bo[r] + rr[r];
-      ElemIO<bf16_t>::st4(a, vv);
+      ElemIO<T>::st4(a, vv);
     }
   __syncthreads();
   {
@@ -392,12 +396,14 @@ int fyc_temporal_block_rr_launch(const fyc_temporal_block_args* a, void* stream)
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= kMaxDev || !attr_done[dev]) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tblock_rr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tblock_rr_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(tblock_rr_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) FYC_FAIL(-3, "fyc_temporal_block: %d bytes of dynamic LDS refused: %s", LDS_BYTES, hipGetErrorString(e));
       if (dev >= 0 && dev < kMaxDev) attr_done[dev] = true;
     }
   }
-  hipLaunchKernelGGL(tblock_rr_kernel, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  if (a->dtype == FYC_F16) hipLaunchKernelGGL(tblock_rr_kernel<f16_t>, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(tblock_rr_kernel<bf16_t>, dim3((unsigned)(a->clips * (a->pixels / PIX))), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
   FYC_CHECK_LAUNCH("fyc_temporal_block (register-resident)");
   return 0;
 }

@@ -20,7 +20,7 @@ from typing import Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from followyourclick_amd import ops as ops_mod
+from followyourclick_amd import default_compute_dtype, ops as ops_mod
 from followyourclick_amd.engine import UNet3DConfig
 from followyourclick_amd.engine.schema import unet_schema
 from followyourclick_amd.engine.unet3d import UNet3DEngine
@@ -71,7 +71,7 @@ class UNet3DConditionModel(nn.Module):
                  use_first_frame_condition_concat=False, image_condition_dim=1024, use_ip_cross_attention=False, scale=1.0,
                  num_tokens=4, use_camera_motion_condition=False, use_text_encoder_2=False, text_encoder_2_dim=4096,
                  use_inflated_groupnorm=False, use_fps_condition=False, use_temporal_conv=False,
-                 use_first_frame_mask_condition_concat=False, compute_dtype: torch.dtype = torch.bfloat16, **unused):
+                 use_first_frame_mask_condition_concat=False, compute_dtype: torch.dtype = None, **unused):
         super().__init__()
         kwargs = {k: v for k, v in locals().items() if k not in ("self", "unused", "__class__", "compute_dtype")}
         mm = dict(motion_module_kwargs or {})
@@ -115,7 +115,7 @@ class UNet3DConditionModel(nn.Module):
                 setattr(self, k, v)
         self.ip_scale = scale
         self.config = SimpleNamespace(**kwargs)
-        self.compute_dtype = compute_dtype
+        self.compute_dtype = compute_dtype if compute_dtype is not None else default_compute_dtype()
         for name, shape in unet_schema(self.engine_config).items():
             _attach(self, name, shape, buffer=name.endswith("pos_encoder.pe"))
         self.image_proj_model = None   # set by scripts/inference.py:167 (`unet.image_proj_model = ip_adapter.init_proj()`)

@@ -38,7 +38,7 @@ class UNet2DConditionModel(UNet3DConditionModel):
                  downsample_padding: int = 1, mid_block_scale_factor: float = 1, act_fn: str = "silu", norm_num_groups: int = 32,
                  norm_eps: float = 1e-5, cross_attention_dim: int = 1280, attention_head_dim=8, dual_cross_attention: bool = False,
                  use_linear_projection: bool = False, class_embed_type=None, num_class_embeds=None, upcast_attention: bool = False,
-                 resnet_time_scale_shift: str = "default", compute_dtype: torch.dtype = torch.bfloat16, **unused):
+                 resnet_time_scale_shift: str = "default", compute_dtype: torch.dtype = None, **unused):
         cfg2d = {k: v for k, v in locals().items() if k not in ("self", "unused", "__class__", "compute_dtype")}
         try:
             down3, up3, mid3 = [_TO_3D[b] for b in down_block_types], [_TO_3D[b] for b in up_block_types], _TO_3D[mid_block_type]

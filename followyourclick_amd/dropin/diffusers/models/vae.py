@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
-from followyourclick_amd import ops as ops_mod
+from followyourclick_amd import default_compute_dtype, ops as ops_mod
 from followyourclick_amd.engine import VAEDecoderConfig
 from followyourclick_amd.engine.schema import vae_decoder_schema, vae_encoder_schema
 from followyourclick_amd.engine.vae import VAEDecoderEngine, VAEEncoderEngine
@@ -59,7 +59,7 @@ class AutoencoderKL(nn.Module):
     def __init__(self, in_channels: int = 3, out_channels: int = 3, down_block_types: Tuple[str, ...] = ("DownEncoderBlock2D",),
                  up_block_types: Tuple[str, ...] = ("UpDecoderBlock2D",), block_out_channels: Tuple[int, ...] = (64,),
                  layers_per_block: int = 1, act_fn: str = "silu", latent_channels: int = 4, norm_num_groups: int = 32,
-                 sample_size: int = 32, compute_dtype: torch.dtype = torch.bfloat16, **unused):
+                 sample_size: int = 32, compute_dtype: torch.dtype = None, **unused):
         super().__init__()
         self.engine_config = VAEDecoderConfig(latent_channels=latent_channels, out_channels=out_channels,
                                               block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
@@ -68,7 +68,7 @@ class AutoencoderKL(nn.Module):
                                       up_block_types=up_block_types, block_out_channels=tuple(block_out_channels),
                                       layers_per_block=layers_per_block, act_fn=act_fn, latent_channels=latent_channels,
                                       norm_num_groups=norm_num_groups, sample_size=sample_size)
-        self.compute_dtype = compute_dtype
+        self.compute_dtype = compute_dtype if compute_dtype is not None else default_compute_dtype()
         g = torch.Generator().manual_seed(0)
         schema = dict(vae_encoder_schema(self.engine_config, in_channels))
         schema.update(vae_decoder_schema(self.engine_config))

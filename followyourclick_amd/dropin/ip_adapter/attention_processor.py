@@ -33,14 +33,14 @@ def fused_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
     o = _ops.get()
     o.ensure_init(q.device)
     dt_in = q.dtype
-    dt = torch.float32 if dt_in == torch.float32 else torch.bfloat16
+    dt = dt_in if dt_in in (torch.float32, torch.float16) else torch.bfloat16      # fp16 modules (the reference's deployment) stay fp16
     ld = ((Nk + 7) // 8) * 8
     qh = q.to(dt).reshape(B, N, heads, d).permute(0, 2, 1, 3).contiguous()
     kh = k.to(dt).reshape(B, Nk, heads, d).permute(0, 2, 1, 3).contiguous()
     vt = torch.zeros(B, heads, d, ld, dtype=dt, device=q.device)
     vt[..., :Nk] = v.to(dt).reshape(B, Nk, heads, d).permute(0, 2, 3, 1)
     out = torch.empty(B * N, C, dtype=dt, device=q.device)
-    if dt == torch.bfloat16:
+    if dt != torch.float32:
         o.attention(qh, kh, vt, out, batch=B, heads=heads, n_q=N, n_k=Nk, d=d, ldo=C, ldvt=ld, scale=scale)
     else:
         for b in range(B):

@@ -21,7 +21,7 @@ class ImageProjModel(EngineBacked):
     """Projection Model: Linear(clip_dim -> tokens*D) -> (B, tokens, D) -> LayerNorm(D)"""
 
     def __init__(self, cross_attention_dim=1024, clip_embeddings_dim=1024, clip_extra_context_tokens=4,
-                 compute_dtype: torch.dtype = torch.bfloat16):
+                 compute_dtype: torch.dtype = None):
         super().__init__()
         self.cross_attention_dim = cross_attention_dim
         self.clip_extra_context_tokens = clip_extra_context_tokens

@@ -19,7 +19,7 @@ def _node(parent: nn.Module, name: str) -> nn.Module:
 class Resampler(EngineBacked):
     def __init__(self, dim=1024, depth=8, dim_head=64, heads=16, num_queries=8, embedding_dim=768, output_dim=1024, ff_mult=4,
                  max_seq_len: int = 257, apply_pos_emb: bool = False, num_latents_mean_pooled: int = 0,
-                 compute_dtype: torch.dtype = torch.bfloat16):
+                 compute_dtype: torch.dtype = None):
         super().__init__()
         if apply_pos_emb or num_latents_mean_pooled:
             raise NotImplementedError("Resampler on the MI355X engine: apply_pos_emb / num_latents_mean_pooled are not used by "

@@ -21,10 +21,11 @@ from .engine import encoders as EN
 
 class EngineBacked(nn.Module):
     """parameters live on the module under their checkpoint names; the packed device copy is rebuilt when they change"""
-    compute_dtype: torch.dtype = torch.bfloat16
+    compute_dtype: torch.dtype = None
 
-    def _init_engine_state(self, compute_dtype: torch.dtype) -> None:
-        self.compute_dtype = compute_dtype
+    def _init_engine_state(self, compute_dtype: torch.dtype = None) -> None:
+        from . import default_compute_dtype
+        self.compute_dtype = compute_dtype if compute_dtype is not None else default_compute_dtype()
         self._engine = None
         self._engine_key = None
 
@@ -81,7 +82,7 @@ class TextEncoderOutput:
 
 
 class ClipTextHip(EngineBacked):
-    def __init__(self, state_dict, config, compute_dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, state_dict, config, compute_dtype: torch.dtype = None):
         super().__init__()
         get = (lambda k, d=None: getattr(config, k, d)) if not isinstance(config, dict) else (lambda k, d=None: config.get(k, d))
         self.engine_config = EN.ClipTextConfig(
@@ -97,7 +98,7 @@ class ClipTextHip(EngineBacked):
         self._init_engine_state(compute_dtype)
 
     @classmethod
-    def from_transformers(cls, model, compute_dtype: torch.dtype = torch.bfloat16) -> "ClipTextHip":
+    def from_transformers(cls, model, compute_dtype: torch.dtype = None) -> "ClipTextHip":
         m = cls(model.state_dict(), model.config, compute_dtype)
         return m.to(next(model.parameters()).device)
 
@@ -124,7 +125,7 @@ class VisionEncoderOutput:
 
 
 class ClipVisionHip(EngineBacked):
-    def __init__(self, state_dict, config, compute_dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, state_dict, config, compute_dtype: torch.dtype = None):
         super().__init__()
         get = (lambda k, d=None: getattr(config, k, d)) if not isinstance(config, dict) else (lambda k, d=None: config.get(k, d))
         self.engine_config = EN.ClipVisionConfig(
@@ -138,7 +139,7 @@ class ClipVisionHip(EngineBacked):
         self._init_engine_state(compute_dtype)
 
     @classmethod
-    def from_transformers(cls, model, compute_dtype: torch.dtype = torch.bfloat16) -> "ClipVisionHip":
+    def from_transformers(cls, model, compute_dtype: torch.dtype = None) -> "ClipVisionHip":
         m = cls(model.state_dict(), model.config, compute_dtype)
         return m.to(next(model.parameters()).device)
 

@@ -71,7 +71,7 @@ class UNet3DEngine(EngineBase):
         self.device = packed.conv_in_w.device
         self.heads = self.cfg.attention_head_dim
         self.groups = self.cfg.norm_num_groups
-        self.mat_attn = self.dtype != torch.bfloat16  # f32 parity mode: materialised attention through the GEMM
+        self.mat_attn = self.dtype == torch.float32  # f32 parity mode: materialised attention through the GEMM (bf16 / f16: fyc_attention)
         self.transformers: List[Packed] = []
         for blk in self.P.down:
             self.transformers += [l.attn for l in blk.layers if l.attn is not None]

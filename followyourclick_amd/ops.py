@@ -20,12 +20,20 @@ from . import _lib as L
 Tensor = torch.Tensor
 
 
+_DTYPE_CODES = {torch.bfloat16: L.FYC_BF16, torch.float16: L.FYC_F16, torch.float32: L.FYC_F32}
+
+
+def _dtc(dtype: torch.dtype) -> int:
+    """torch dtype of the activations / weights -> fyc_dtype (include/fyc.h): bf16 production, f16 (the reference's deployed
+    fp16-autocast precision class), f32 parity mode"""
+    try:
+        return _DTYPE_CODES[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {dtype}") from None
+
+
 def _dt(t: Tensor) -> int:
-    if t.dtype == torch.bfloat16:
-        return L.FYC_BF16
-    if t.dtype == torch.float32:
-        return L.FYC_F32
-    raise TypeError(f"unsupported activation dtype {t.dtype}")
+    return _dtc(t.dtype)
 
 
 def _p(t: Optional[Tensor]) -> Optional[int]:
@@ -132,7 +140,7 @@ class HipOps:
         if key not in self._q_cache:
             g = L.GemmArgs()
             g.M, g.N, g.K, g.mode, g.batch, g.tile = M, N, K, mode, batch, tile
-            g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+            g.dtype = _dtc(dtype)
             self._q_cache[key] = int(self.lib.fyc_gemm_row_parts(C.byref(g))) if hasattr(self.lib, "fyc_gemm_row_parts") else 0
         return self._q_cache[key]
 
@@ -142,7 +150,7 @@ class HipOps:
         if key not in self._q_cache:
             g = L.GemmArgs()
             g.M, g.N, g.K, g.mode, g.batch, g.epilogue = M, N, K, mode, 1, L.EPI_LINEAR
-            g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+            g.dtype = _dtc(dtype)
             self._q_cache[key] = int(self.lib.fyc_gemm_workspace_bytes(C.byref(g))) if hasattr(self.lib, "fyc_gemm_workspace_bytes") else 0
         return self._q_cache[key]
 
@@ -156,7 +164,7 @@ class HipOps:
             else:
                 g = L.GemmArgs()
                 g.M, g.N, g.K, g.mode, g.batch, g.tile, g.cs_rows = M, N, K, mode, batch, tile, cs_rows
-                g.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+                g.dtype = _dtc(dtype)
                 tr, sl = L.i32(0), L.i32(0)
                 n = int(self.lib.fyc_gemm_stat_layout(C.byref(g), C.byref(tr), C.byref(sl)))
                 self._q_cache[key] = (n, int(tr.value), int(sl.value))
@@ -232,7 +240,7 @@ class HipOps:
             return False
         a = L.TemporalBlockArgs()
         a.clips, a.frames, a.pixels, a.heads, a.d, a.C = clips, frames, pixels, heads, d, heads * d
-        a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+        a.dtype = _dtc(dtype)
         return bool(self.lib.fyc_temporal_block_supported(C.byref(a)))
 
     def temporal_block(self, x: Tensor, out: Tensor, *, w_qkv: Tensor, colsum: Tensor, bias: Tensor, pe_bias: Optional[Tensor],
@@ -261,7 +269,7 @@ class HipOps:
         a = L.FFBlockArgs()
         a.rows, a.C, a.hidden, a.cs_rows = rows, C_, hidden, cs_rows
         a.chan_parts = 16 if cs_rows > 0 else None         # only tested for null / alignment by the query
-        a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+        a.dtype = _dtc(dtype)
         self._q_cache[key] = bool(self.lib.fyc_ff_block_supported(C.byref(a)))
         return self._q_cache[key]
 
@@ -291,7 +299,7 @@ class HipOps:
         if key not in self._q_cache:
             a = L.PanelLinearArgs()
             a.rows, a.N, a.K = rows, N, K
-            a.dtype = L.FYC_BF16 if dtype == torch.bfloat16 else L.FYC_F32
+            a.dtype = _dtc(dtype)
             if gn_rows_per_sample > 0:
                 a.gn_cs, a.gn_rows_per_sample, a.gn_stat_samples, a.gn_groups = 16, gn_rows_per_sample, 1, gn_groups     # pointer only tested for null
             self._q_cache[key] = bool(self.lib.fyc_panel_linear_supported(C.byref(a)))

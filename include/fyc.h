@@ -14,7 +14,7 @@
  *  - the callee never allocates, frees or synchronises: all tensors/workspaces are raw device
  *    pointers owned by the caller; work is enqueued on `hip_stream` (hipGraph-capturable).
  *  - activations are channels-last: [frames = B*F][H][W][C] (== token-major [rows][C]), element type
- *    `dtype` (FYC_BF16 production, FYC_F32 parity mode); statistics, biases, norm affine
+ *    `dtype` (FYC_BF16 production, FYC_F16 = the reference's deployed fp16-autocast precision class, FYC_F32 parity mode); statistics, biases, norm affine
  *    parameters, time-embedding rows and latents are always f32.
  */
 #ifndef FYC_H
@@ -30,9 +30,11 @@ extern "C" {
  * call and refuse a library whose MAJOR differs: argument structs grow at the end between majors (round 3 appended `wstream` to
  * fyc_temporal_block_args and widened the tuning table to 16 keys without bumping the number: a round-2 host would have passed a short
  * struct whose missing tail the library reads as a pointer).  History: 100 = rounds 1-3 (see above), 200 = round 4 (structs as of this file). */
-#define FYC_VERSION 200
+#define FYC_VERSION 201
 
-typedef enum { FYC_F32 = 0, FYC_BF16 = 1 } fyc_dtype;
+/* FYC_F16 (minor version 1): IEEE half storage with f32 accumulation - every op that takes FYC_BF16 takes it, same layouts, same
+ * packed weight streams (16-bit elements), v_mfma_*_f16 instead of v_mfma_*_bf16; the packers cast to the `dtype` they are given */
+typedef enum { FYC_F32 = 0, FYC_BF16 = 1, FYC_F16 = 2 } fyc_dtype;
 
 /* ---- library ------------------------------------------------------------------------- */
 int fyc_version(void);

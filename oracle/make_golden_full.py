@@ -12,6 +12,8 @@ production precision, by executing the REAL reference (container only; TEST INFR
     python -m oracle.make_golden_full cfg4full   # BASELINE configs[3] at its REAL shape: one forward, F=32, 96x96 latent, max_len 32 (~25 min on 8 cores)
     python -m oracle.make_golden_full cfg5full   # BASELINE configs[4] at its REAL shape: one CFG-pair forward, 16f@512^2, 16 IP tokens + rectangle mask (~10 min)
     python -m oracle.make_golden_full cfg5yard   # bf16-autocast drift of the NO-quirk oracle along the cfg5 trajectory (the engine's yardstick)
+    python -m oracle.make_golden_full f16yard    # fp16-autocast drift of the REAL reference along the cfg1 and cfg2 trajectories and of the small
+                                                 # full-width forward: the yardstick of the engine's FYC_F16 mode (the precision the reference deploys)
 
 Every UNet golden exists twice: `*_f32` = the reference as the CPU runs it (fp32), `*_bf16` = the same
 reference code under the CUDA-autocast cast policy with bfloat16 (oracle/autocast_emul.py), i.e. the
@@ -408,6 +410,47 @@ def cfg5yard():
     np.savez_compressed(os.path.join(OUT, "cfg5_yardstick.npz"), **d)
 
 
+def f16yard():
+    """What the reference itself loses when it runs as deployed - `torch.autocast("cuda")` = float16 (scripts/inference.py:294) -
+    measured against its own f32 run: the yardstick for the engine's FYC_F16 mode, next to the bf16 `drift` values the trajectory
+    goldens already hold.  The f32 runs are NOT repeated: the stored `step{i}_f32` tensors of cfg1 / cfg2_trajectory.npz and the stored
+    f32 output of unet_full_small_fwd.npz are the reference side (the fp16 run starts from the same seeded weights and inputs).
+    Only scalars are stored (tests/golden/f16_yardstick.npz); partial results are saved after every part."""
+    d = {}
+    path = os.path.join(OUT, "f16_yardstick.npz")
+    # (1) the small full-width forward (F = 4, 16 x 16 latent)
+    g = np.load(os.path.join(OUT, "unet_full_small_fwd.npz"))
+    cfg, unet = full_unet()
+    inp = W.seeded_inputs(cfg, 1, int(g["frames"]), int(g["h"]), int(g["w"]), seed=int(g["input_seed"]))
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    kw = dict(use_fps_condition=True, fps_tensor=torch.from_numpy(g["fps"]), flow_control=torch.from_numpy(g["flow"]))
+    with torch.no_grad():
+        with CudaAutocastOnCpu(torch.float16):
+            y16 = unet(x9, torch.tensor(int(g["timestep"])), inp["text"], **kw).sample.float()
+    d["small_fwd_drift_f16"] = np.float64(rel(y16, torch.from_numpy(g["out_f32"])))
+    d["small_fwd_drift_bf16"] = np.float64(g["drift"])
+    log(f"f16yard small forward: fp16-autocast vs f32 {d['small_fwd_drift_f16']:.3e} (bf16-autocast: {float(g['drift']):.3e})")
+    np.savez_compressed(path, **d)
+    pipe = _pipeline(unet, cfg)
+    for tag in ("cfg1", "cfg2"):
+        t = np.load(os.path.join(OUT, f"{tag}_trajectory.npz"))
+        frames, lat, steps, seed = int(t["frames"]), int(t["lat"]), int(t["steps"]), int(t["input_seed"])
+        keep = set(int(i) for i in t["keep"])
+        pipe.decode_latents = lambda latents, _f=frames: np.zeros((1, 3, _f, 8, 8), dtype=np.float32)
+        inp = W.seeded_inputs(cfg, 1, frames, lat, lat, seed=seed)
+        t0 = time.time()
+        log(f"f16yard {tag}: {steps} steps under fp16 autocast")
+        with CudaAutocastOnCpu(torch.float16):
+            traj, _ = _run_pipeline(pipe, inp, frames, lat * 8, steps, keep)
+        for i in sorted(keep):
+            d[f"{tag}_drift_f16_{i}"] = np.float64(rel(traj[i], torch.from_numpy(t[f"step{i}_f32"])))
+            d[f"{tag}_drift_bf16_{i}"] = np.float64(t[f"drift{i}"])
+            log(f"f16yard {tag} step {i}: fp16-autocast vs f32 {d[f'{tag}_drift_f16_{i}']:.3e} (bf16-autocast: {float(t[f'drift{i}']):.3e})")
+        log(f"f16yard {tag}: {time.time() - t0:.0f}s")
+        np.savez_compressed(path, **d)
+    np.savez_compressed(path, **d)
+
+
 def cfg1():
     _trajectory("cfg1", 8, 32, 5, {0, 1, 2, 3, 4}, seed=51)
 
@@ -421,6 +464,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     for part in sys.argv[1:]:
         log("==", part)
-        dict(small=small, ip=ip, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2, cfg4=cfg4, cfg5=cfg5, cfg4full=cfg4full, cfg5full=cfg5full, cfg5yard=cfg5yard)[part]()
+        dict(small=small, ip=ip, vae=vae, p2=p2, cfg1=cfg1, cfg2=cfg2, cfg4=cfg4, cfg5=cfg5, cfg4full=cfg4full, cfg5full=cfg5full, cfg5yard=cfg5yard, f16yard=f16yard)[part]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -174,8 +174,8 @@ class EmuOps:
         idx = torch.arange(batch) // kv_batch_div
         S = torch.matmul(Q, Kt[idx].transpose(-1, -2)) * scale
         P = S.softmax(dim=-1)
-        if q.dtype == torch.bfloat16:
-            P = P.to(torch.bfloat16).to(acc_t)  # the kernel feeds bf16 probabilities to the MFMA
+        if q.dtype != torch.float32:
+            P = P.to(q.dtype).to(acc_t)  # the kernel feeds bf16 / f16 probabilities to the MFMA
         O = torch.matmul(P, Vt[idx].transpose(-1, -2))           # b h n d
         O = O.permute(0, 2, 1, 3).reshape(batch * n_q, heads * d)
         dst = _strided(_flat(o), (batch * n_q, heads * d), (ldo, 1), 0)
@@ -190,15 +190,15 @@ class EmuOps:
         q, k, v = x[:, :, :, 0], x[:, :, :, 1], x[:, :, :, 2]          # b f p h d
         q, k, v = (t.permute(0, 2, 3, 1, 4) for t in (q, k, v))          # b p h f d
         P = (torch.matmul(q, k.transpose(-1, -2)) * scale).softmax(dim=-1)
-        if qkv.dtype == torch.bfloat16:
-            P = P.to(torch.bfloat16).to(acc_t)
+        if qkv.dtype != torch.float32:
+            P = P.to(qkv.dtype).to(acc_t)
         O = torch.matmul(P, v).permute(0, 3, 1, 2, 4).reshape(clips * frames * pixels, Cc)
         _flat(o)[: O.numel()].reshape(O.shape).copy_(O.to(o.dtype))
 
     def temporal_block_supported(self, dtype, *, clips, frames, pixels, heads, d):
         """the shapes libfyc_hip.so's kernel is built for (csrc/temporal_block.hip); `temporal_block` itself is a
         specification for any head layout that fits the operand packing (3 d <= 128, d <= 48)"""
-        return dtype == torch.bfloat16 and heads == 8 and d == 40 and frames == 16 and pixels % 8 == 0
+        return dtype in (torch.bfloat16, torch.float16) and heads == 8 and d == 40 and frames == 16 and pixels % 8 == 0
 
     @staticmethod
     def _tblock_unpack(wstream, C_, heads, d):
@@ -288,7 +288,7 @@ class EmuOps:
     def ff_block_supported(self, dtype, *, rows, C_, hidden, cs_rows=0):
         """the shape libfyc_hip.so's kernel is built for (csrc/ff_block.hip); `ff_block` itself is a specification for any
         C, hidden that are multiples of 32"""
-        return dtype == torch.bfloat16 and C_ == 320 and hidden == 1280 and rows % 128 == 0 and (cs_rows == 0 or (cs_rows % 128 == 0 and rows % cs_rows == 0))
+        return dtype in (torch.bfloat16, torch.float16) and C_ == 320 and hidden == 1280 and rows % 128 == 0 and (cs_rows == 0 or (cs_rows % 128 == 0 and rows % cs_rows == 0))
 
     @staticmethod
     def _ff_unpack(wstream, C_, hidden):
@@ -369,7 +369,7 @@ class EmuOps:
 
     def panel_linear_supported(self, dtype, *, rows, N, K, gn_rows_per_sample=0, gn_groups=32):
         """the shapes libfyc_hip.so's kernel is built for (csrc/panel_linear.hip)"""
-        return (dtype == torch.bfloat16 and rows % 128 == 0 and K in (320, 640) and N in (320, 640)
+        return (dtype in (torch.bfloat16, torch.float16) and rows % 128 == 0 and K in (320, 640) and N in (320, 640)
                 and (gn_rows_per_sample == 0 or (gn_rows_per_sample % 128 == 0 and rows % gn_rows_per_sample == 0)))
 
     @staticmethod

@@ -322,7 +322,7 @@ def test_cfg5_ip_mask_trajectory_vs_oracle(golden_dir, dtype):
         assert r < (1e-3 if dtype == torch.float32 else BF16_FACTOR * drift), (i, r, drift)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_vae_decode_full_width_vs_reference(golden_dir, dtype):
     g = _load(golden_dir, "vae_full.npz")
     vcfg = VAEDecoderConfig()
@@ -333,4 +333,68 @@ def test_vae_decode_full_width_vs_reference(golden_dir, dtype):
     ref16 = (g["out_bf16"] / 2 + 0.5).clamp(0, 1)
     e, drift = (out - ref).abs().max().item(), (ref16 - ref).abs().max().item()
     report(f"vae full width {dtype}: max abs err {e:.3e} (ref-bf16 vs ref-f32 {drift:.3e})")
-    assert e < (1e-4 if dtype == torch.float32 else 1.5 * drift), e      # bf16 measured 1.29 x the reference's own bf16 error
+    # bf16 measured 1.29 x the reference's own bf16 error; f16 (three more mantissa bits) must be well inside it
+    assert e < (1e-4 if dtype == torch.float32 else 1.5 * drift if dtype == torch.bfloat16 else 0.4 * drift), e
+
+
+# ---- FYC_F16: the precision class the reference deploys (torch.autocast("cuda") = float16, scripts/inference.py:294) ----------------------
+# engine-f16 vs reference-f32 may be at most F16_FACTOR x the reference's OWN fp16-autocast drift (tests/golden/f16_yardstick.npz,
+# oracle/make_golden_full.py f16yard), and must in any case be well inside the bf16 drift of the same checkpoint (F16_VS_BF16_DRIFT):
+# an f16 mode that lost its three extra mantissa bits somewhere (a bf16 rounding left in a kernel) fails the second bound even where
+# the yardstick file is missing a checkpoint.
+F16_FACTOR = 1.5
+F16_VS_BF16_DRIFT = 0.5
+
+
+def _f16_bounds(yard, key, bf16_drift):
+    bound = F16_VS_BF16_DRIFT * bf16_drift
+    d16 = float(yard[key]) if yard is not None and key in yard else None
+    if d16 is not None:
+        bound = min(bound, F16_FACTOR * d16)
+    return bound, d16
+
+
+def test_f16_mode_vs_reference(golden_dir, engines):
+    """the engine's float16 mode (every kernel on v_mfma_*_f16, 16-bit storage in IEEE half) against the REAL reference's f32 outputs: the
+    small full-width forward, the whole cfg1 trajectory and the benchmarked cfg2 trajectory (steps 0 / 4 / 24)"""
+    path = os.path.join(golden_dir, "f16_yardstick.npz")
+    yard = _load(golden_dir, "f16_yardstick.npz") if os.path.exists(path) else None
+    dtype = torch.float16
+    g = _load(golden_dir, "unet_full_small_fwd.npz")
+    cfg = Fn.UNetConfig()
+    F, H, Wd = int(g["frames"]), int(g["h"]), int(g["w"])
+    inp = W.seeded_inputs(cfg, 1, F, H, Wd, seed=int(g["input_seed"]))
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    eng = engines(dtype)
+    eng.prepare_context(inp["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), 2)
+    out = eng.forward(_nhwc(x9, dtype), temb, 2, F, H, Wd).float().cpu().reshape(2, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    assert torch.isfinite(out).all()
+    r32 = rel(out, g["out_f32"])
+    bound, d16 = _f16_bounds(yard, "small_fwd_drift_f16", float(g["drift"]))
+    report(f"full-width fwd (F=4, 16x16) {dtype}: vs ref-f32 {r32:.3e} (ref-fp16-autocast vs ref-f32 {d16}, ref-bf16-autocast {float(g['drift']):.3e})")
+    assert r32 < bound, (r32, bound)
+    for name, tag, keep, run in (("cfg1_trajectory.npz", "cfg1", (0, 1, 2, 3, 4), 5), ("cfg2_trajectory.npz", "cfg2", (0, 4, 24), 25)):
+        if not os.path.exists(os.path.join(golden_dir, name)):
+            continue
+        g, got = _trajectory(golden_dir, engines, name, dtype, run)
+        for i in keep:
+            r32 = rel(got[i], g[f"step{i}_f32"])
+            bound, d16 = _f16_bounds(yard, f"{tag}_drift_f16_{i}", float(g[f"drift{i}"]))
+            report(f"{tag} step {i} {dtype}: vs ref-f32 {r32:.3e} (ref-fp16-autocast vs ref-f32 {d16}, ref-bf16-autocast {float(g[f'drift{i}']):.3e})")
+            assert torch.isfinite(got[i]).all()
+            assert r32 < bound, (tag, i, r32, bound)
+
+
+def test_f16_sampling_is_bitwise_repeatable(golden_dir, engines):
+    """same property as the bf16 / f32 modes: two eager runs of the sampling loop at the benchmarked shape give the same bits"""
+    g = _load(golden_dir, "cfg1_trajectory.npz")
+    inp = W.seeded_inputs(Fn.UNetConfig(), 1, 16, 64, 64, seed=int(g["input_seed"]))
+    smp = DDIMSampler(engines(torch.float16), DDIMConfig())
+
+    def run():
+        out = smp.sample(inp["latents"], g["text_embeddings"], 2, 8.0, inp["first_image_latents"], inp["first_images_mask"], fps=[2], flow=[4])
+        torch.cuda.synchronize()
+        return out.cpu()
+    a, b = run(), run()
+    assert torch.isfinite(a).all() and torch.equal(a, b), rel(a, b)

@@ -11,8 +11,9 @@ from emu_ops import EmuOps
 
 pytestmark = pytest.mark.gpu
 
-DT = {"bf16": torch.bfloat16, "f32": torch.float32}
-RTOL = {"bf16": 4e-3, "f32": 2e-5}
+DT = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
+RTOL = {"bf16": 4e-3, "f32": 2e-5, "f16": 5e-4}      # f16 (FYC_F16): same operand values on both sides, one rounding to 11 bits at the end
+F16_TILES = [(0, 0), (1, 2), (2, 2), (3, 2), (5, 2), (6, 2)]      # the f16 instantiations share the tile templates: a subset keeps the suite short
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +52,7 @@ CONV_TILES = [(0, 0), (1, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (1
 
 def _dt_tiles(tiles):
     """f32 parity mode has a fixed tile choice: only the automatic one is parametrised for it"""
-    return [("bf16", t) for t in tiles] + [("f32", (0, 0))]
+    return [("bf16", t) for t in tiles] + [("f32", (0, 0))] + [("f16", t) for t in F16_TILES]
 
 
 @pytest.mark.parametrize("dt,tile_ring", _dt_tiles(PLAIN_TILES))
@@ -108,7 +109,7 @@ def test_gemm_conv(hip, emu, dt, tile_ring, mode, stride, frames, H, W, Cin, Cou
     close(o_h, o_e, f"conv {dt} mode={mode} s={stride} {frames}x{H}x{W} {Cin}->{Cout}", RTOL[dt])
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_gemm_geglu(hip, emu, dt):
     T = DT[dt]
     M, C = 200, 64
@@ -152,7 +153,7 @@ def test_gemm_geglu_rejects_odd_wave_tiles(hip):
     assert torch.isfinite(o.float()).all()
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("tokens,heads,d", [(64, 8, 8), (77, 8, 40), (20, 2, 160)])
 def test_gemm_heads(hip, emu, dt, tokens, heads, d):
     T = DT[dt]
@@ -172,7 +173,7 @@ def test_gemm_heads(hip, emu, dt, tokens, heads, d):
         close(oh[i], oe[i], f"heads {dt} seg {n}", RTOL[dt])
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("M,C", [(300, 64), (1000, 320)])
 def test_gemm_dual_source_k(hip, emu, dt, M, C):
     """A = [tok | hidden]: the merged FF2 + output projection GEMM (K = C + 4C)"""
@@ -188,7 +189,7 @@ def test_gemm_dual_source_k(hip, emu, dt, M, C):
     close(o_h, o_e, f"dual-source gemm {dt} M={M} C={C}", RTOL[dt])
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_gemm_batched(hip, emu, dt):
     """the materialised-attention shape: S[z] = q[z] k[z]^T * scale, d = 40"""
     T = DT[dt]
@@ -204,7 +205,7 @@ def test_gemm_batched(hip, emu, dt):
     close(o_h, o_e, f"bgemm {dt}", RTOL[dt])
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("Z,M,N,K", [(5, 128, 128, 64), (3, 256, 512, 256), (4, 64, 64, 64), (2, 1024, 512, 1024)])
 def test_gemm_batched_aligned(hip, emu, dt, Z, M, N, K):
     """the VAE's materialised attention at aligned sizes (tokens and channels multiples of 8: the 16-byte bf16 epilogue; round 4
@@ -333,9 +334,9 @@ def test_temporal_attention(hip, emu, dt, clips, F, P, H, d):
     close(o_h, o_e, f"tattn {dt} F{F} P{P} d{d}", 6e-3 if dt == "bf16" else 2e-5)
 
 
-def _temporal_operands(with_pe, seed=0):
+def _temporal_operands(with_pe, seed=0, T=torch.bfloat16):
     from followyourclick_amd.engine.weights import Packed, pack_temporal_block
-    T, H, d, F = torch.bfloat16, 8, 40, 16
+    H, d, F = 8, 40, 16
     C = H * d
     att = Packed(qkv_f=((rnd((3 * C, C), torch.float32, seed + 1) * C ** -0.5).to(T), rnd((3 * C,), torch.float32, seed + 2) * 0.1, None),
                  pe_w=rnd((24, 3 * C), torch.float32, seed + 3) * 0.5 if with_pe else None,
@@ -428,10 +429,10 @@ def test_panel_linear(hip, emu, rows, N, K, with_gn, with_res):
         hip.panel_linear(xc, xc, wstream=ws.cuda(), rows=rows, N=N, K=K) if N == K else (_ for _ in ()).throw(RuntimeError("alias"))
 
 
-def _ff_operands(seed=0):
+def _ff_operands(seed=0, T=torch.bfloat16):
     """a packed feed-forward (engine/weights.py::_ff layout) with the LayerNorm folded in, at the kernel's widths"""
     from followyourclick_amd.engine.weights import Packed
-    T, C, hid = torch.bfloat16, 320, 1280
+    C, hid = 320, 1280
     w1 = (rnd((2 * hid, C), torch.float32, seed + 1) * C ** -0.5).to(T)
     return Packed(w1=w1, b1=rnd((2 * hid,), torch.float32, seed + 2) * 0.2, cs1=w1.float().sum(dim=1).contiguous(),
                   po_w=(rnd((C, C + hid), torch.float32, seed + 3) * (C + hid) ** -0.5).to(T), po_b=rnd((C,), torch.float32, seed + 4) * 0.1)
@@ -596,7 +597,7 @@ def test_panel_linear_is_repeatable(hip, C, gn):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("samples,rps,C", [(2, 4 * 64, 320), (8, 64, 64), (2, 16 * 16, 2560), (6, 1, 128), (3, 1000, 960), (2, 37, 1920), (2, 16 * 1024, 320)])
 def test_groupnorm(hip, emu, dt, samples, rps, C):
     T = DT[dt]
@@ -622,7 +623,7 @@ def test_groupnorm(hip, emu, dt, samples, rps, C):
         close(y_h, y_e, f"gn_apply {dt} C{C} silu={silu}", RTOL[dt])
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("rows,C,pe", [(100, 320, False), (64, 64, True), (33, 1280, True), (7, 640, False)])
 def test_layernorm(hip, emu, dt, rows, C, pe):
     T = DT[dt]
@@ -638,7 +639,7 @@ def test_layernorm(hip, emu, dt, rows, C, pe):
     close(y_h, y_e, f"layernorm {dt} C{C}", RTOL[dt])
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_softmax_rows(hip, emu, dt):
     T = DT[dt]
     x = (rnd((50, 104), torch.float32, 1) * 4).to(T)
@@ -651,7 +652,7 @@ def test_softmax_rows(hip, emu, dt):
     assert torch.equal(x_h[:, 100:].cpu(), x[:, 100:])
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_elementwise(hip, emu, dt):
     T = DT[dt]
     a, b = rnd((77, 64), T, 1), rnd((77, 128), T, 2)
@@ -675,7 +676,7 @@ def test_elementwise(hip, emu, dt):
     assert torch.equal(z_h.cpu(), y_e[:, :9].float())
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("use_mask,cfg", [(True, 2), (False, 1)])
 def test_unet_input_and_ddim(hip, emu, dt, use_mask, cfg):
     T = DT[dt]
@@ -698,7 +699,7 @@ def test_unet_input_and_ddim(hip, emu, dt, use_mask, cfg):
         close(l_h, l_e, f"cfg_ddim {dt} type{ptype}", 1e-6)
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_vae_layout_kernels(hip, emu, dt):
     T = DT[dt]
     z = rnd((3, 4, 30), torch.float32, 1)
@@ -722,7 +723,7 @@ def test_missing_device_tensor_raises(hip):
 
 
 # ---- conditioning-encoder ops ---------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("act", [1, 2])
 @pytest.mark.parametrize("M,N,K", [(154, 3072, 768), (514, 320, 1280), (32, 64, 64), (77, 264, 72)])
 def test_gemm_activation(hip, emu, dt, act, M, N, K):
@@ -740,7 +741,7 @@ def test_gemm_activation(hip, emu, dt, act, M, N, K):
         hip.gemm(a.cuda(), w.cuda(), o_h, M=M, N=N - N % 32, K=K, lda=K, ldw=K, ldo=N, epilogue=1, act=act)
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_softmax_rows_causal(hip, emu, dt):
     T = DT[dt]
     heads, n, ld = 3, 77, 80
@@ -781,7 +782,7 @@ def test_embed_tokens_and_patchify(hip, emu, dt):
         hip.patchify(img.cuda(), p_h, B=B, Cin=3, H=28, W=42, P=16, ld=1024)
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_weight_packers_match_the_host_packers(hip, dt):
     """fyc_pack_conv3x3 / fyc_pack_geglu (the layouts fyc_gemm expects, for hosts without torch) == engine/weights.py, bit for bit"""
     from followyourclick_amd.engine import weights as Wt
@@ -803,7 +804,7 @@ def test_weight_packers_match_the_host_packers(hip, dt):
 
 
 # ---- LayerNorm folded into the consuming GEMM ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("rows,C", [(300, 320), (64, 64), (1000, 1280), (33, 640)])
 def test_row_stats(hip, emu, dt, rows, C):
     T = DT[dt]
@@ -866,7 +867,7 @@ def test_gemm_layernorm_fold(hip, emu, dt, epi, M, C):
         hip.gemm(cu(x), cu(wf), o_h, **dict(kw, bias=cu(bias)), ln_stats=cu(st))
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_ddim_three_way_guidance(hip, emu, dt):
     """single + video_scale*(uncond - single) + guidance*(cond - uncond) (reference pipeline_animation.py:754-760)"""
     T = DT[dt]
@@ -888,7 +889,7 @@ def test_ddim_three_way_guidance(hip, emu, dt):
 STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 21, 22, 23, 31]
 
 
-@pytest.mark.parametrize("dt,tile", [("bf16", t) for t in STAT_TILES] + [("f32", 0)])
+@pytest.mark.parametrize("dt,tile", [("bf16", t) for t in STAT_TILES] + [("f32", 0)] + [("f16", t) for t in (0, 5, 6)])
 @pytest.mark.parametrize("M,N,K,cs_rows,res", [(512, 320, 320, 64, True), (768, 640, 128, 128, True), (1152, 128, 64, 192, False),
                                                (4096, 320, 64, 4096, True), (1280, 328, 72, 640, False), (1040, 64, 64, 80, False),
                                                (1152, 320, 64, 144, True), (2304, 640, 128, 576, True)])     # 12x12 / 24x24 frames (768^2): samples straddle wave rows
@@ -933,7 +934,7 @@ def test_gemm_output_statistics(hip, emu, dt, tile, M, N, K, cs_rows, res):
     close(rows, torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], dim=-1), f"row_parts {dt} tile {tile} ({nparts} parts)", 2e-6)
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 def test_conv_output_statistics(hip, emu, dt):
     T = DT[dt]
     frames, H, W, Cin, Cout = 4, 16, 16, 64, 320

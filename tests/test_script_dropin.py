@@ -140,6 +140,21 @@ def test_reference_inference_script_runs_unmodified_on_mi355x(tmp_path, monkeypa
     _check(seen, out_dir, run, tol=6e-2)
 
 
+def test_reference_inference_script_in_f16_mode_on_emulator(tmp_path, monkeypatch):
+    """FYC_COMPUTE_DTYPE=f16: the unmodified script (which cannot pass constructor arguments) runs every drop-in model in IEEE half - the
+    precision class of its own `torch.autocast("cuda")` - and lands ~8x closer to the f32 oracle than the bf16 default's 6e-2 bound"""
+    monkeypatch.setenv("FYC_COMPUTE_DTYPE", "f16")
+    seen, out_dir, run = _run_script(tmp_path, monkeypatch, device_is_gpu=False, port=29771)
+    _check(seen, out_dir, run, tol=1e-2)
+
+
+@pytest.mark.gpu
+def test_reference_inference_script_in_f16_mode_on_mi355x(tmp_path, monkeypatch):
+    monkeypatch.setenv("FYC_COMPUTE_DTYPE", "f16")
+    seen, out_dir, run = _run_script(tmp_path, monkeypatch, device_is_gpu=True, port=29772)
+    _check(seen, out_dir, run, tol=1e-2)
+
+
 # ---- scripts/inference_org.py and scripts/inference_w_image_cond.py ----------------------------------------------------------------
 def _run_t2v_script(script, tmp_path, monkeypatch, device_is_gpu: bool, port: int, extra_args, first_image: bool, cfg_extra=None,
                     own_argv=None):
