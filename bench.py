@@ -130,8 +130,9 @@ def workload_label(args):
     key = (args.frames, args.size, args.ddim_steps, args.ip_tokens)
     names = {(8, 256, 5, 0): "configs[0]", (16, 512, 25, 0): "configs[1]", (32, 768, 50, 0): "configs[3]", (16, 512, 25, 16): "configs[4]"}
     label = names.get(key, "custom (no BASELINE.json config)")
-    if args.dtype != "bf16" and key in names:
-        label += f" at {args.dtype} instead of the config's bf16"
+    dt = getattr(args, "dtype", "bf16")
+    if dt != "bf16" and key in names:
+        label += f" at {dt} instead of the config's bf16"
     return label
 
 

@@ -164,6 +164,7 @@ def test_bench_labels_follow_the_arguments():
     import bench
     ns = lambda **kw: argparse.Namespace(**kw)   # noqa: E731
     assert bench.workload_label(ns(frames=16, size=512, ddim_steps=25, ip_tokens=0)) == "configs[1]"
+    assert bench.workload_label(ns(frames=16, size=512, ddim_steps=25, ip_tokens=0, dtype="f16")) == "configs[1] at f16 instead of the config's bf16"
     assert bench.workload_label(ns(frames=8, size=256, ddim_steps=5, ip_tokens=0)) == "configs[0]"
     assert bench.workload_label(ns(frames=32, size=768, ddim_steps=50, ip_tokens=0)) == "configs[3]"
     assert bench.workload_label(ns(frames=16, size=512, ddim_steps=25, ip_tokens=16)) == "configs[4]"
