@@ -85,9 +85,7 @@ constexpr float RESCALE_THR = 6.0f;   // log2 units: probabilities stay <= 64 be
 // traffic), then across the halves (v_permlane32_swap)
 __device__ __forceinline__ float quad_max(float mx) {
   mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x401F)));
-  const unsigned u = __builtin_bit_cast(unsigned, mx);
-  auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+  return swap32_max(mx);      // (fyc_common.h: NOT fmaxf over the builtin's two results - hipcc folds that to the first one)
 }
 
 // DP16: padded head dim / 16 (K-dim of QK^T).  DVT: 16-row blocks of O^T = d/16 + 1 (the extra row at index d is l).

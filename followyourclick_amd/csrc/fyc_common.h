@@ -214,6 +214,25 @@ __device__ __forceinline__ f32x2 geglu_pair(f32x2 h, f32x2 g) {
   return h * (g * phi);
 }
 
+// Maximum over the two lane halves (swap32) / over lane rows 16 apart (swap16) of a wave by gfx950's v_permlane*_swap: plain VALU, no
+// LDS queue.  The empty asm is REQUIRED: hipcc 7.2 simplifies fmaxf(r[0], r[1]) of __builtin_amdgcn_permlane*_swap(x, x, ...) to r[0]
+// (the optimised IR keeps extractvalue 0 only - it takes the two results of a swap of equal operands for equal values), so the
+// "maximum" silently covered half of the lanes.  Found in round 4 when the f16 attention overflowed: its running max ignored the keys
+// of lanes 32..63, the lazy rescale never fired for them and a late score 2^16 above the max became an infinite probability (bf16's
+// exponent range had hidden the same defect since round 1).  Sums through the same builtins are not affected (x + x is not x).
+__device__ __forceinline__ float swap32_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  unsigned a = r[0], b = r[1];
+  asm volatile("" : "+v"(a), "+v"(b));
+  return fmaxf(__uint_as_float(a), __uint_as_float(b));
+}
+__device__ __forceinline__ float swap16_max(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  unsigned a = r[0], b = r[1];
+  asm volatile("" : "+v"(a), "+v"(b));
+  return fmaxf(__uint_as_float(a), __uint_as_float(b));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

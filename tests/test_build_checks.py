@@ -61,3 +61,42 @@ def test_no_compiler_lds_queue_traffic_between_asm_dmas(src, tmp_path):
         for stmt in re.findall(r";;#ASMSTART(.*?);;#ASMEND", body, flags=re.S):
             if "global_load_lds" in stmt and re.search(r"s_mov_b32 m0,", stmt):
                 assert re.search(r"s_mov_b32 (s\d+|vcc_lo|vcc_hi|ttmp\d+), m0", stmt) and len(re.findall(r"s_mov_b32 m0,", stmt)) >= 2, f"{src}::{name}: a DMA statement leaves M0 modified:\n{stmt}"
+
+
+def test_lane_swap_maximum_keeps_both_halves(tmp_path):
+    """hipcc 7.2 simplifies `fmaxf(r[0], r[1])` of `__builtin_amdgcn_permlane32_swap(x, x, ...)` to `r[0]`: the attention kernel's running
+    maximum then ignored the keys held by lanes 32..63 (round 4: infinite probabilities in the f16 form, hidden by bf16's exponent range
+    before that).  fyc_common.h::swap32_max / swap16_max make the two results opaque; this checks the generated code: every
+    v_permlane*_swap of the helper is followed by a v_max that reads BOTH of its registers - and documents the miscompiled plain form,
+    so that a compiler which no longer needs the workaround shows up here as well."""
+    src = tmp_path / "swapmax.hip"
+    src.write_text('#include "%s"\n' % os.path.join(CSRC, "fyc_common.h") + '''
+__global__ void fixed(const float* in, float* out) { out[threadIdx.x] = swap32_max(swap16_max(in[threadIdx.x])); }
+__global__ void plain(const float* in, float* out) {          // the attention kernel's quad_max as it was written in rounds 1-4
+  float mx = in[threadIdx.x];
+  mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x401F)));
+  const unsigned u = __builtin_bit_cast(unsigned, mx);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  out[threadIdx.x] = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+''')
+    out = tmp_path / "swapmax.s"
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", str(src), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bodies = _kernel_bodies(out.read_text())
+    fixed = next(v for k, v in bodies.items() if "fixed" in k)
+    swaps = list(re.finditer(r"v_permlane(16|32)_swap_b32\w*\s+(v\d+),\s*(v\d+)", fixed))
+    assert len(swaps) == 2, fixed
+    for m in swaps:
+        tail = fixed[m.end():]
+        nxt = re.search(r"v_permlane(16|32)_swap", tail)
+        tail = tail[:nxt.start()] if nxt else tail
+        a, b = m.group(2), m.group(3)
+        # (canonicalising v_max x, x, x first, then the max of the two)
+        assert re.search(rf"v_max_f32\w*\s+v\d+,\s*({a},\s*{b}|{b},\s*{a})\b", tail), f"the maximum after {m.group(0)} does not combine both results:\n{fixed}"
+    plain = next(v for k, v in bodies.items() if "plain" in k)
+    m = re.search(r"v_permlane32_swap_b32\w*\s+(v\d+),\s*(v\d+)", plain)
+    combined = m and re.search(rf"v_max_f32\w*\s+v\d+,\s*({m.group(1)},\s*{m.group(2)}|{m.group(2)},\s*{m.group(1)})\b", plain[m.end():])
+    if combined:
+        pytest.skip("this hipcc compiles the plain fmaxf form correctly: the asm barrier in swap32_max / swap16_max is no longer needed")
+    # (hipcc 7.2.0: the plain form stores the swap's first result unreduced - the defect the helpers exist for)

@@ -319,6 +319,34 @@ def test_attention_score_offsets_and_late_spikes(hip, emu, d, offset):
     close(o_h, o_e, f"attn offsets d{d} off{offset}", 8e-3)
 
 
+@pytest.mark.parametrize("dt,height", [("bf16", 150.0), ("bf16", 40.0), ("f16", 40.0), ("f16", 18.0)])
+@pytest.mark.parametrize("key", [416 + 3, 416 + 12, 416 + 20, 416 + 29, 200, 31, 63 - 8])
+@pytest.mark.parametrize("d", [40, 160])
+def test_attention_late_spike_in_every_lane_quad(hip, emu, dt, height, key, d):
+    """One key beats a query's running maximum by `height` (log2 units) late in the sequence, for keys held by each of the four lane
+    quads of a query column (key % 32 // 8).  Rounds 1-4: hipcc folded the cross-half step of the kernel's quad maximum away
+    (fyc_common.h::swap32_max), the running maximum ignored the keys of lanes 32..63 (quads 2, 3), the rescale never fired for them
+    and the probability became 2^height: infinite in f16 from 2^16, in bf16 from 2^128 - NaN rows; below that the result was right by
+    the grace of the exponent range.  Now every quad moves the maximum and the probabilities stay <= 2^6."""
+    T = DT[dt]
+    B, H, n, qsel = 1, 4, 448, 17
+    q, k = rnd((B * H, n, d), T, 1), rnd((B * H, n, d), T, 2)
+    qf, kf = q.float(), k.float()
+    unit = (qf[:, qsel] * qf[:, qsel]).sum(-1, keepdim=True) * d ** -0.5 * math.log2(math.e)       # score of key = query, log2 units
+    kf[:, key] = kf[:, key] + qf[:, qsel] * (height / unit)
+    q, k, vt = qf.to(T), kf.to(T), rnd((B * H, d, n), T, 3)
+    kw = dict(batch=B, heads=H, n_q=n, n_k=n, d=d, ldo=H * d, ldvt=n, scale=d ** -0.5)
+    o_h = torch.zeros(B * n, H * d, dtype=T, device="cuda")
+    hip.attention(q.cuda(), k.cuda(), vt.cuda(), o_h, **kw)
+    torch.cuda.synchronize()
+    o_e = torch.zeros(B * n, H * d, dtype=T)
+    emu.attention(q, k, vt, o_e, **kw)
+    close(o_h, o_e, f"attn {dt} d{d} spike of 2^{height} at key {key} (quad {key % 32 // 8})", 8e-3 if dt == "bf16" else 2e-3)
+    if height >= 40:                                   # the spiking query's output is that key's value row (the rest weighs < 2^-30)
+        got, ref = o_h.float().cpu().reshape(n, H, d)[qsel], vt.float()[:, :, key]
+        assert (got - ref).abs().max().item() < (6e-2 if dt == "bf16" else 8e-3)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 @pytest.mark.parametrize("clips,F,P,H,d", [(2, 16, 64, 8, 40), (1, 8, 16, 8, 8), (2, 4, 1, 8, 32), (1, 24, 9, 8, 80), (1, 16, 5, 8, 160), (1, 32, 4, 8, 16)])
 def test_temporal_attention(hip, emu, dt, clips, F, P, H, d):
