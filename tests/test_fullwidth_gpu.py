@@ -342,7 +342,7 @@ def test_vae_decode_full_width_vs_reference(golden_dir, dtype):
 # oracle/make_golden_full.py f16yard), and must in any case be well inside the bf16 drift of the same checkpoint (F16_VS_BF16_DRIFT):
 # an f16 mode that lost its three extra mantissa bits somewhere (a bf16 rounding left in a kernel) fails the second bound even where
 # the yardstick file is missing a checkpoint.
-F16_FACTOR = 1.5
+F16_FACTOR = 1.1           # measured 0.88 .. 0.93 x over the small forward, cfg1 (5 steps) and cfg2 (steps 0 / 4 / 24)
 F16_VS_BF16_DRIFT = 0.5
 
 
