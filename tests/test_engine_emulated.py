@@ -258,6 +258,28 @@ def test_sampler_trajectory_matches_reference_pipeline(golden_dir):
     assert (vid - g["videos"]).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("dtype,tol_traj,tol_video", [(torch.bfloat16, 7e-2, 1.5e-1), (torch.float16, 9e-3, 2e-2)])
+def test_sampler_and_vae_in_16_bit_modes(golden_dir, dtype, tol_traj, tol_video):
+    """the same 5-step run + decode with bf16 / f16 storage on the op emulator: the host side of the 16-bit modes (packing, the sampler's
+    f32 latents against 16-bit UNet I/O, the VAE engine) and the ~8x between the two formats (measured: bf16 1.4e-2 ... 5.1e-2 per step,
+    video 1.0e-1; f16 1.7e-3 ... 6.0e-3, video 1.3e-2)"""
+    g = _load(golden_dir, "pipeline_tiny.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["unet_weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, tiny_cfg(), dtype, "cpu"), ops=EmuOps())
+    traj = []
+    lat = DDIMSampler(eng, DDIMConfig()).sample(g["latents"], g["text_embeddings"], 5, 8.0, g["first_image_latents"],
+                                                g["first_images_mask"], fps=[2], flow=[4],
+                                                callback=lambda i, t, l: traj.append(l.clone()))
+    assert lat.dtype == torch.float32
+    traj = torch.stack(traj)
+    err = (traj - g["trajectory"]).flatten(1).norm(dim=1) / g["trajectory"].flatten(1).norm(dim=1)
+    assert err.max().item() < tol_traj, err
+    vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
+    sdv = W.make_weights(W.vae_decoder_state_shapes(Fn.VAEConfig(block_out_channels=(64, 128, 128, 128))), int(g["vae_weight_seed"]))
+    vae = VAEDecoderEngine(pack_vae_decoder(sdv, vcfg, dtype, "cpu"), ops=EmuOps())
+    assert (vae.decode_video(lat) - g["videos"]).abs().max().item() < tol_video
+
+
 def test_vae_decode_matches_golden(golden_dir):
     g = _load(golden_dir, "vae_tiny.npz")
     vcfg = VAEDecoderConfig(block_out_channels=(64, 128, 128, 128))
