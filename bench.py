@@ -15,8 +15,10 @@ scaling : weak - every rank denoises its own clips; the only collective is the o
 
 Adds to the JSON line: "roofline" (dominant kernel = the MFMA GEMM/implicit-conv family, timed per launch
 with HIP events in an instrumented extra pass; on every configuration's line), with --vae "roofline_vae"
-(the same family inside the VAE decode) and "cpu_baseline" (the CPU oracle, one DDIM step at the same
-resolution on a bounded number of frames, threads bound to one NUMA node; rank 0, N=1 only).
+(the same family inside the VAE decode), "cpu_baseline" (the CPU oracle: whole-clip DDIM steps at the same
+resolution, one untimed + --cpu-steps timed, threads bound to one NUMA node; rank 0, N=1 only) and "parity" (rel-L2 of THIS
+binary and dtype against the reference's own cfg2 trajectory, tests/golden/cfg2_trajectory.npz).
+`--gpus N` without a launcher re-executes itself under torch.distributed.run; a world size that differs from --gpus is an error.
 `metric` and `config.workload` are derived from the arguments: only the default arguments produce BASELINE.json's
 configs[1] line.
 """
@@ -83,22 +85,23 @@ def numa_node_cores(node: int = 0):
     return list(range(max(1, n // 2))), n
 
 
-CPU_THREADS_MAX = 32          # past ~32 threads the oracle's many small ops stop scaling (measurement)
-CPU_BUDGET_S = 30.0           # bounded sample: about this much timed CPU work
+CPU_THREADS_MAX = 32          # past ~32 threads the oracle's many small ops stop scaling (profiles/r04_cpu_baseline_thread_sweep.txt)
 REFERENCE_CPU_S_PER_FRAME = 6.5   # the reference's own CPU path, 8 cores, seconds per frame per DDIM step at 512^2
 
 
-def cpu_baseline(sd, frames, h, w, ddim_steps):
-    """The oracle (CPU port of the reference math, fp32) per BASELINE.md 3: CFG-pair UNet3D forwards (= DDIM steps) at the benchmark
-    resolution with the threads BOUND to the physical cores of NUMA node 0 (at most CPU_THREADS_MAX).  A 1-frame forward warms up
-    and calibrates; the timed forward then runs on as many of the clip's frames as fit ~CPU_BUDGET_S (the conv / spatial-attention
-    cost is linear in the frame count, the temporal attention is < 1 % of it), and frames/s = frames_timed / (ddim_steps x time)."""
+def cpu_baseline(sd, frames, h, w, ddim_steps, timed_steps=1):
+    """The oracle (CPU port of the reference math, fp32) on the STATED workload: CFG-pair UNet3D forwards (= DDIM
+    steps) of the whole clip - all `frames` frames, so the cross-frame GroupNorms and the temporal attention run on the benchmark's
+    own problem - at the benchmark resolution, threads BOUND to the physical cores of NUMA node 0 (at most CPU_THREADS_MAX).  One
+    untimed step at the same shape first (oneDNN primitive creation, allocator growth), then `timed_steps` timed ones;
+    frames/s = frames / (ddim_steps x seconds per step).  About 1.5 min per step on a 32-core node."""
     from oracle import functional as Fn  # test infrastructure: used only as the reported CPU baseline
     cfg = Fn.UNetConfig()
     g = torch.Generator().manual_seed(1)
     text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
     cores, logical = numa_node_cores(0)
+    node_cores = len(cores)
     cores = cores[:CPU_THREADS_MAX]
     before_threads = torch.get_num_threads()
     before_aff = os.sched_getaffinity(0)
@@ -106,23 +109,89 @@ def cpu_baseline(sd, frames, h, w, ddim_steps):
         os.sched_setaffinity(0, set(cores))
         torch.set_num_threads(len(cores))
 
-        def fwd(n, i):
-            x9 = torch.randn(2, cfg.conv_in_channels, n, h, w, generator=g)
+        def fwd(i):
+            x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g)
             t0 = time.time()
             with torch.no_grad():
                 Fn.unet3d_forward(sd, cfg, x9, torch.tensor(961 - 40 * i), text, fps, flow)
             return time.time() - t0
-        t1 = fwd(1, 0)
-        n = max(1, min(frames, int(CPU_BUDGET_S / max(t1, 1e-3))))
-        dt = fwd(n, 1)
+        t_warm = fwd(0)
+        times = [fwd(1 + i) for i in range(max(1, timed_steps))]
     finally:
         os.sched_setaffinity(0, before_aff)
         torch.set_num_threads(before_threads)
-    return dict(value=n / (ddim_steps * dt), unit="frames/s", cores=len(cores), kind="port", s_per_frame_per_ddim_step=round(dt / n, 2),
-                reference_cpu_s_per_frame_per_ddim_step=REFERENCE_CPU_S_PER_FRAME,
-                sample=f"1 DDIM step (CFG-pair UNet3D forward at {h * 8}x{w * 8}, fp32 oracle) on {n} of the {frames} frames in {dt:.1f}s = {dt / n:.2f} s/frame "
-                       f"(BASELINE.md: the reference's CPU path, 8 cores, {REFERENCE_CPU_S_PER_FRAME} s/frame), after a 1-frame warm-up ({t1:.1f}s); {len(cores)} threads bound to "
-                       f"physical cores of NUMA node 0 ({logical} logical cpus on the host); frames/s = {n} / ({ddim_steps} x {dt:.1f}s)")
+    dt = sum(times) / len(times)
+    return dict(value=frames / (ddim_steps * dt), unit="frames/s", cores=len(cores), cores_on_numa_node0=node_cores, logical_cpus_on_host=logical, kind="port",
+                s_per_frame_per_ddim_step=round(dt / frames, 2), reference_cpu_s_per_frame_per_ddim_step=REFERENCE_CPU_S_PER_FRAME,
+                sample=f"{len(times)} timed DDIM step(s) (CFG-pair UNet3D forward at {h * 8}x{w * 8}, fp32 oracle) on ALL {frames} frames of the clip, "
+                       f"{dt:.1f}s per step = {dt / frames:.2f} s/frame (BASELINE.md: the reference's CPU path, 8 cores, {REFERENCE_CPU_S_PER_FRAME} s/frame), after one "
+                       f"untimed step at the same shape ({t_warm:.1f}s); {len(cores)} threads bound to physical cores of NUMA node 0 ({node_cores} there, "
+                       f"{logical} logical cpus on the host); frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
+
+
+def parity_leg(args, dtype, device):
+    """rel-L2 of THIS library binary in THIS dtype against the real reference's own trajectory of the benchmarked workload
+    (tests/golden/cfg2_trajectory.npz: AnimationPipeline.__call__ of /root/reference on seeded weights and inputs, f32 and under
+    bf16 autocast, latents after DDIM steps 0 / 4 / 24; recipe oracle/make_golden_full.py cfg2).  One extra clip on the golden's
+    weights, after the timed region.  The seeded weight / input generators live under oracle/ (test infrastructure): they are used
+    here only to reproduce the golden's inputs - the checker, never the thing measured."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "cfg2_trajectory.npz")
+    if not os.path.exists(path):
+        return {"value": None, "note": "tests/golden/cfg2_trajectory.npz not present"}
+    from oracle import functional as Fn
+    from oracle import weights as W
+    g = np.load(path)
+    ocfg = Fn.UNetConfig()
+    sd = W.make_weights(W.unet_state_shapes(ocfg), seed=int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, UNet3DConfig(), dtype, device))
+    del sd
+    F, lat, steps = int(g["frames"]), int(g["lat"]), int(g["steps"])
+    inp = W.seeded_inputs(ocfg, 1, F, lat, lat, seed=int(g["input_seed"]))
+    keep = [int(k) for k in g["keep"]]
+    got = {}
+
+    def cb(i, t, l):
+        if i in keep:
+            got[i] = l.detach().float().cpu()
+    DDIMSampler(eng, DDIMConfig()).sample(inp["latents"], torch.from_numpy(g["text_embeddings"]), steps, 8.0, inp["first_image_latents"],
+                                          inp["first_images_mask"], fps=[2], flow=[4], callback=cb)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        b = torch.from_numpy(b)
+        return float((a - b).norm() / b.norm())
+    out = {"metric": "rel-L2 of the latents vs the reference pipeline's own run on identical seeds / inputs", "dtype": args.dtype,
+           "golden": "tests/golden/cfg2_trajectory.npz (oracle/make_golden_full.py cfg2: the real AnimationPipeline, 16f@512^2, 25 DDIM steps)",
+           "north_star_tolerance": 1e-3}
+    for i in keep:
+        out[f"step{i}_vs_ref_f32"] = float(f"{rel(got[i], g[f'step{i}_f32']):.3e}")
+        out[f"step{i}_ref_bf16_autocast_vs_ref_f32"] = float(f"{float(g[f'drift{i}']):.3e}")
+    out["value"] = out[f"step{keep[-1]}_vs_ref_f32"]
+    out["within_north_star_tolerance"] = bool(out["value"] <= 1e-3)
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def gpu_reference(args):
+    """The reference's OWN GPU path on this chip, beside the CPU number: the unmodified UNet3DConditionModel (byte copies under the
+    git-ignored oracle/_ref/, staged by oracle/stage_ref_scripts.py) in eager PyTorch-ROCm under torch.autocast, 1 untimed + 2 timed
+    CFG-pair forwards of the benchmark shape, as a SUBPROCESS (oracle/gpu_reference.py, test infrastructure): a crash or a timeout
+    there costs this field, never the line.  A reported baseline, not the target."""
+    import subprocess
+    if not (os.path.exists(os.path.join(ROOT, "oracle", "_ref", "animatediff", "models", "unet.py")) or os.path.isdir("/root/reference/animatediff")):
+        return {"value": None, "note": "reference model files not staged under oracle/_ref/ (python -m oracle.stage_ref_scripts, build container only)"}
+    cmd = [sys.executable, "-m", "oracle.gpu_reference", "--json", "--frames", str(args.frames), "--size", str(args.size), "--ddim-steps", str(args.ddim_steps),
+           "--dtype", args.dtype, "--attention", "sdpa", "--timed", "2"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=args.gpu_reference_timeout)
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"oracle.gpu_reference did not finish in {args.gpu_reference_timeout}s"}
+    for line in r.stdout.splitlines():
+        if line.startswith("GPU_REFERENCE "):
+            return json.loads(line[len("GPU_REFERENCE "):])
+    return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
 
 
 def workload_label(args):
@@ -134,6 +203,31 @@ def workload_label(args):
     if dt != "bf16" and key in names:
         label += f" at {dt} instead of the config's bf16"
     return label
+
+
+def _self_launch(n, argv):
+    """re-exec this very script (sys.argv[0]: bench.py, or the tests-side wrapper around it) under torch.distributed.run"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0]), *argv]
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr)
+    rc = subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    if rc != 0:
+        raise SystemExit(rc)
+    return None
+
+
+def rccl_ranks(device) -> int:
+    """ranks that actually took part in a collective on the data-path backend: an all-reduce of ones (1 without a process group)"""
+    if not torch.distributed.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    torch.distributed.all_reduce(t)
+    return int(round(float(t.item())))
 
 
 def main(argv=None, emulation=None):
@@ -154,13 +248,24 @@ def main(argv=None, emulation=None):
     ap.add_argument("--graph", action="store_true", help="replay DDIM steps 1..n-1 from one captured hipGraph (A/B vs eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=1, help="timed DDIM steps of the cpu_baseline leg (after one untimed step; BASELINE.md 3 asks for 2)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the `parity` field (one extra clip against tests/golden/cfg2_trajectory.npz)")
+    ap.add_argument("--no-gpu-reference", action="store_true",
+                    help="skip the `gpu_reference` leg (the UNMODIFIED reference UNet3D, eager PyTorch-ROCm under torch.autocast, from the byte copies under oracle/_ref/)")
+    ap.add_argument("--gpu-reference-timeout", type=int, default=420, help="seconds the gpu_reference subprocess may take")
     args = ap.parse_args(argv)
+    emulate = emulation is not None
 
+    # `python bench.py --gpus N` with no launcher around it: become the launcher (one rank per GPU over RCCL, rendezvous on
+    # 127.0.0.1) instead of silently running one rank - the reference shards inside the script it is handed
+    # (/root/reference/scripts/inference.py:44-51, 260)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args.gpus, argv if argv is not None else sys.argv[1:])
     rank, world, local = D.init_from_env()
     if world != args.gpus:
-        if rank == 0 and world > 1:
-            print(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
-    emulate = emulation is not None
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to print a line for a different job size")
+    if not emulate and torch.cuda.is_available() and torch.cuda.device_count() < (int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit(f"[bench] {torch.cuda.device_count()} HIP device(s) visible for {world} ranks on this node: one process drives one GPU")
     if emulate:
         from followyourclick_amd import ops as ops_mod
         ops_mod.impl = emulation["ops"]
@@ -212,6 +317,9 @@ def main(argv=None, emulation=None):
     sync()
     D.barrier()
     elapsed = D.max_over_ranks(time.time() - t0, device)
+    n_coll = rccl_ranks(device)
+    if n_coll != world:
+        raise SystemExit(f"[bench] an all-reduce of ones over the process group returned {n_coll}, expected {world} ranks")
     assert torch.isfinite(out).all(), "non-finite latents"
     # Host side of a DDIM step (~900 ctypes launches), outside the timed region: a SHORT run from an idle queue, so that the
     # host is timed queueing launches, not waiting for room in a full HIP queue (over a whole clip the call returns only a little
@@ -230,7 +338,7 @@ def main(argv=None, emulation=None):
         value = world * args.frames * args.steps / elapsed
         result = {
             "metric": f"denoised frames/sec, {args.frames}f x {args.size}^2 clip @ {args.ddim_steps} DDIM steps", "value": round(value, 3), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
+            "n_gpus": world, "rccl_ranks": n_coll, "collective_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "emulated" if emulate else "synthetic",
             "clips_per_sec": round(world * args.steps / elapsed, 4),
             "host_launch_ms_per_ddim_step": round(host_ms, 2), "gpu_ms_per_ddim_step": round(1000 * elapsed / (args.steps * args.ddim_steps), 2),
@@ -365,9 +473,20 @@ def main(argv=None, emulation=None):
                                       "kernel_families": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in sorted(vs.items(), key=lambda kv: -kv[1]["ms"])}}
         assert torch.isfinite(vid).all()
 
+    if rank == 0 and not emulate and not args.no_parity and (args.frames, args.size, args.ddim_steps, args.ip_tokens) == (16, 512, 25, 0):
+        try:
+            result["parity"] = parity_leg(args, dtype, device)
+        except Exception as e:  # a reported extra, never a reason to lose the throughput number
+            result["parity"] = {"value": None, "error": repr(e)[:200]}
+
+    if rank == 0 and world == 1 and not emulate and not args.no_gpu_reference and args.ip_tokens == 0:
+        result["gpu_reference"] = gpu_reference(args)
+        if result["gpu_reference"].get("value"):
+            result["gpu_reference"]["engine_over_reference"] = round(result["value"] / result["gpu_reference"]["value"], 2)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emulate and os.environ.get("FYC_BENCH_CPU", "1") != "0":
         try:
-            result["cpu_baseline"] = cpu_baseline(sd, args.frames, h, w, args.ddim_steps)
+            result["cpu_baseline"] = cpu_baseline(sd, args.frames, h, w, args.ddim_steps, args.cpu_steps)
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
             result["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
 

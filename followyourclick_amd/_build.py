@@ -15,7 +15,15 @@ CSRC = os.path.join(HERE, "csrc")
 EXTRA = os.environ.get("FYC_BUILD_EXTRA", "").split()
 LIB = os.path.abspath(os.environ.get("FYC_BUILD_LIB") or os.path.join(HERE, "libfyc_hip.so"))
 OBJ = os.path.join(HERE, "_obj") if not (EXTRA or os.environ.get("FYC_BUILD_LIB")) else LIB + ".obj"
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f16_plain.hip", "gemm_f16_conv.hip", "gemm_f16_act.hip", "gemm_f32.hip", "gemm_pp_plain.hip", "gemm_pp_conv.hip", "gemm_ov.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "attention_small_f16.hip", "attention_medium_f16.hip", "attention_large_f16.hip", "temporal_attn.hip", "temporal_block.hip", "temporal_block_rr.hip", "ff_block.hip", "panel_linear.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16_plain.hip", "gemm_bf16_conv.hip", "gemm_bf16_act.hip", "gemm_f16_plain.hip", "gemm_f16_conv.hip", "gemm_f16_act.hip", "gemm_f32.hip", "attention.hip", "attention_small.hip", "attention_medium.hip", "attention_large.hip", "attention_small_f16.hip", "attention_medium_f16.hip", "attention_large_f16.hip", "temporal_attn.hip", "temporal_block.hip", "temporal_block_rr.hip", "ff_block.hip", "panel_linear.hip", "norm.hip", "elementwise.hip"]
+# FYC_GEMM_VARIANTS=1: also build the round-4 main-loop experiments of tools/exp/gemm_variants/ (off by default, measured slower)
+VARIANTS = os.environ.get("FYC_GEMM_VARIANTS") == "1"
+VARIANT_DIR = os.path.join(HERE, "..", "tools", "exp", "gemm_variants")
+VARIANT_SOURCES = ["gemm_pp_plain.hip", "gemm_pp_conv.hip", "gemm_ov.hip"] if VARIANTS else []
+if VARIANTS:
+    EXTRA = EXTRA + ["-DFYC_GEMM_VARIANTS"]
+    if not os.environ.get("FYC_BUILD_LIB"):
+        raise SystemExit("FYC_GEMM_VARIANTS=1 needs FYC_BUILD_LIB=<path>: the experiment kernels are not part of the product library")
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file and every
 # kernel here fits in 256 registers), which removes the v_accvgpr_read/write traffic around the
 # softmax rescale and the epilogues (312 -> 0 such moves in the attention main loop).
@@ -48,7 +56,7 @@ def _hipcc() -> str:
 
 def _digest(path: str) -> str:
     h = hashlib.sha256()
-    for dep in [path, os.path.join(CSRC, "fyc_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "gemm_pp_kernel.h"), os.path.join(CSRC, "gemm_ov_kernel.h"), os.path.join(CSRC, "attention_kernel.h"), os.path.join(CSRC, "attention_groups.h"), os.path.join(HERE, "..", "include", "fyc.h")]:
+    for dep in [path, os.path.join(CSRC, "fyc_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "attention_kernel.h"), os.path.join(CSRC, "attention_groups.h"), os.path.join(HERE, "..", "include", "fyc.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(_flags(os.path.basename(path))).encode())
@@ -73,7 +81,7 @@ def source_digest() -> str:
 
 
 def _compile(src: str) -> str:
-    path = os.path.join(CSRC, src)
+    path = os.path.join(VARIANT_DIR if src in VARIANT_SOURCES else CSRC, src)
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     stamp = obj + ".sha"
     dig = _digest(path)
@@ -94,7 +102,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
     with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(_compile, SOURCES))
+        objs = list(ex.map(_compile, SOURCES + VARIANT_SOURCES))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)

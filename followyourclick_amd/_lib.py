@@ -192,6 +192,7 @@ def load() -> C.CDLL:
         lib.fyc_gemm_stat_layout.restype = C.c_int
         lib.fyc_gemm_workspace_bytes.argtypes = [C.POINTER(GemmArgs)]
         lib.fyc_gemm_workspace_bytes.restype = i64
+    if not ab_build or hasattr(lib, "fyc_gn_stats_workspace"):
         lib.fyc_gn_stats_workspace.argtypes = [C.POINTER(GnStatsArgs)]
         lib.fyc_gn_stats_workspace.restype = i64
     if not ab_build or hasattr(lib, "fyc_temporal_block_supported"):

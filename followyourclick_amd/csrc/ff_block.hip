@@ -119,8 +119,7 @@ __device__ __forceinline__ float halves_sum(float v) {
 #ifdef FF_BPERMUTE
   return v + __shfl_xor(v, 32);
 #else
-  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  return swap32_sum(v);          // (fyc_common.h: the two results of the swap must stay opaque to hipcc)
 #endif
 }
 

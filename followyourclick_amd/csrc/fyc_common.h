@@ -219,7 +219,10 @@ __device__ __forceinline__ f32x2 geglu_pair(f32x2 h, f32x2 g) {
 // (the optimised IR keeps extractvalue 0 only - it takes the two results of a swap of equal operands for equal values), so the
 // "maximum" silently covered half of the lanes.  Found in round 4 when the f16 attention overflowed: its running max ignored the keys
 // of lanes 32..63, the lazy rescale never fired for them and a late score 2^16 above the max became an infinite probability (bf16's
-// exponent range had hidden the same defect since round 1).  Sums through the same builtins are not affected (x + x is not x).
+// exponent range had hidden the same defect since round 1).  SUMS ARE AFFECTED THE SAME WAY (round-4 advice): with the swap's operand
+// held in one `unsigned` hipcc 7.2 emits `v_permlane32_swap v1, v2; v_add_f32 v1, v1, v1` = 2 * r[0] - the other lane half is dropped;
+// the row-panel kernels' sums were correct only because they happened to call __float_as_uint(v) twice.  swap32_sum / swap16_sum below
+// carry the same barrier; tests/test_build_checks.py disassembles both forms.
 __device__ __forceinline__ float swap32_max(float v) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   unsigned a = r[0], b = r[1];
@@ -231,6 +234,19 @@ __device__ __forceinline__ float swap16_max(float v) {
   unsigned a = r[0], b = r[1];
   asm volatile("" : "+v"(a), "+v"(b));
   return fmaxf(__uint_as_float(a), __uint_as_float(b));
+}
+
+__device__ __forceinline__ float swap32_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  unsigned a = r[0], b = r[1];
+  asm volatile("" : "+v"(a), "+v"(b));
+  return __uint_as_float(a) + __uint_as_float(b);
+}
+__device__ __forceinline__ float swap16_sum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  unsigned a = r[0], b = r[1];
+  asm volatile("" : "+v"(a), "+v"(b));
+  return __uint_as_float(a) + __uint_as_float(b);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

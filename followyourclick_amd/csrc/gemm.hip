@@ -1,7 +1,21 @@
 // Host entry of the GEMM family: argument validation, tile/ring selection, dispatch.
 // Kernel template: gemm_kernel.h; instantiations: gemm_bf16_plain.hip, gemm_bf16_conv.hip, gemm_f32.hip.
-#include "gemm_pp_kernel.h"
-#include "gemm_ov_kernel.h"
+// The round-4 main-loop experiments that measured slower on every shape (ping-pong wave groups, tile configs 21 / 22 / 23; epilogue
+// under the next tile's K loop, config 31) live in tools/exp/gemm_variants/ and are only part of a library built with
+// FYC_GEMM_VARIANTS=1 (python -m followyourclick_amd._build; tests: tools/exp/gemm_variants/test_gemm_variants_gpu.py).
+#ifdef FYC_GEMM_VARIANTS
+#include "../../tools/exp/gemm_variants/gemm_pp_kernel.h"
+#include "../../tools/exp/gemm_variants/gemm_ov_kernel.h"
+#else
+#include "gemm_kernel.h"
+namespace fycg {
+constexpr bool pp_cfg(int) { return false; }
+constexpr bool ov_cfg(int) { return false; }
+inline int run_pp_plain(const GemmP&, int, hipStream_t) { return -2; }
+inline int run_pp_conv(const GemmP&, int, hipStream_t) { return -2; }
+inline int run_ov(const GemmP&, int, hipStream_t) { return -2; }
+}  // namespace fycg
+#endif
 
 using fycg::GemmP;
 
@@ -83,6 +97,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   if (cfg == 22 && p.epilogue == FYC_EPI_GEGLU) cfg = 21;
   // ping-pong main loop (gemm_pp_kernel.h) for the 8-wave tiles: fyc_set_tuning key 9 = 1 keeps the one-phase loop, 2 forces the
   // ping-pong one wherever it is built; fyc_gemm() falls back to the one-phase twin when the problem does not qualify
+#ifdef FYC_GEMM_VARIANTS
   if (g_fyc_tuning[9] == 2 && tile <= 0 && g_fyc_tuning[1] <= 0) {
     if (cfg == 5) cfg = 21;
     else if (cfg == 6) cfg = 22;
@@ -91,6 +106,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // overlapped-epilogue kernel (gemm_ov_kernel.h, tile config 31 = 128x320): key 9 = 3 takes it for every N = 320 k problem the
   // library would give a 256x320 / 128x320 tile; fyc_gemm() falls back to 6 when the problem does not qualify
   if (g_fyc_tuning[9] == 3 && tile <= 0 && g_fyc_tuning[1] <= 0 && (cfg == 5 || cfg == 6) && p.epilogue == FYC_EPI_LINEAR) cfg = 31;
+#endif
   if (!((cfg == 1 && ns == 3) || (cfg == 2 && (ns == 3 || ns == 4) && p.mode == FYC_GEMM_PLAIN))) ns = 2;   // deeper rings: config 1 (3) and, for linears, config 2 (3, 4)
 }
 // the one-phase twin of a ping-pong tile config (same tile, same wave grid)
@@ -295,6 +311,9 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   const bool f16 = a->dtype == FYC_F16;
   // the ping-pong main loop is built for bf16 problems with the 16-byte epilogues, whole 64-element K tiles (at least two) and no batch
   const bool pp_ok = a->dtype == FYC_BF16 && p.wide && batch == 1 && a->act == FYC_ACT_NONE && a->K % 64 == 0 && a->K >= 128;
+#ifndef FYC_GEMM_VARIANTS
+  cfg = pp_twin(cfg);                                   // tile configs 21 / 22 / 23 / 31 are not in this build: their one-phase twins run
+#endif
   if (fycg::pp_cfg(cfg) && !pp_ok) cfg = pp_twin(cfg);
   if (fycg::ov_cfg(cfg)) {
     const int bm = tile_bm(cfg);
@@ -311,7 +330,9 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     if (sk > 1 && p.wide && a->workspace != nullptr && a->workspace_bytes >= (int64_t)sk * a->M * a->N * 4 && ((uintptr_t)a->workspace % 16) == 0) {
       GemmP q = p;
       q.splitk = sk; q.ws = (float*)a->workspace;
+#ifdef FYC_GEMM_VARIANTS
       if (scfg == 6 && g_fyc_tuning[9] == 2 && pp_ok) scfg = 22;
+#endif
       const int rc = fycg::pp_cfg(scfg) ? (a->mode == FYC_GEMM_PLAIN ? fycg::run_pp_plain(q, scfg, st) : fycg::run_pp_conv(q, scfg, st))
                      : f16 ? ((a->mode == FYC_GEMM_PLAIN) ? fycg::run_f16_plain(q, batch, scfg, 2, st) : fycg::run_f16_conv(q, batch, scfg, 2, st))
                      : (a->mode == FYC_GEMM_PLAIN) ? fycg::run_bf16_plain(q, batch, scfg, 2, st) : fycg::run_bf16_conv(q, batch, scfg, 2, st);

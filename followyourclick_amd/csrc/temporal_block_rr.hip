@@ -81,12 +81,7 @@ template <typename Frag> __device__ __forceinline__ Frag frag(const char* sl, in
 
 // reductions over the four 16-lane rows of a wave by v_permlane16_swap / v_permlane32_swap: plain VALU.  No LDS-queue instruction
 // (ds_bpermute = __shfl_xor) may sit between asm-issued DMAs: profiles/r03_ff_block_race.txt
-__device__ __forceinline__ float rows_sum(float v) {
-  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
+__device__ __forceinline__ float rows_sum(float v) { return swap32_sum(swap16_sum(v)); }   // (fyc_common.h: opaque swap results, as for the maxima)
 __device__ __forceinline__ float rows_max(float v) { return swap32_max(swap16_max(v)); }   // (fyc_common.h: the plain fmaxf form is miscompiled)
 template <typename T> __device__ __forceinline__ typename Pair16<T>::Vec8 op8(const f32x4& a, const f32x4& b) {          // two 4-row results -> one 8-slot operand
   return __builtin_bit_cast(typename Pair16<T>::Vec8, (u32x4){Pair16<T>::pack(a[0], a[1]), Pair16<T>::pack(a[2], a[3]), Pair16<T>::pack(b[0], b[1]), Pair16<T>::pack(b[2], b[3])});

@@ -61,8 +61,11 @@ def packed_tensors(P: Packed) -> List[tuple]:
 
 def _staging_device() -> Optional[torch.device]:
     """RCCL ("nccl") moves device memory only: host-resident tensors (a model that was loaded but not yet moved - the reference
-    calls `unet.load_state_dict` at scripts/inference.py:178 and `.to("cuda")` at :213) are staged through the current GPU."""
-    if dist.get_backend() == "nccl":
+    calls `unet.load_state_dict` at scripts/inference.py:178 and `.to("cuda")` at :213) are staged through the current GPU.
+    Decided by what the group can move, not by string equality with "nccl": a group opened elsewhere with the composite default
+    ("cpu:gloo,cuda:nccl") moves host tensors itself and needs no staging; a pure-nccl group does."""
+    backend = str(dist.get_backend())
+    if "nccl" in backend and "gloo" not in backend and "mpi" not in backend:
         return torch.device("cuda", torch.cuda.current_device())
     return None
 
@@ -85,7 +88,10 @@ def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> 
             if not bucket:
                 return
             dev = stage if stage is not None else bucket[0].device
-            flat = torch.cat([t.detach().reshape(-1).to(dev) for t in bucket])
+            if dist.get_rank() == src:
+                flat = torch.cat([t.detach().reshape(-1).to(dev) for t in bucket])
+            else:        # receivers do not upload what the broadcast overwrites (a full-model H2D per rank otherwise)
+                flat = torch.empty(sum(t.numel() for t in bucket), dtype=bucket[0].dtype, device=dev)
             dist.broadcast(flat, src=src)
             off = 0
             for t in bucket:
@@ -99,7 +105,7 @@ def broadcast_packed(P: Packed, src: int = 0, bucket_bytes: int = 256 << 20) -> 
             if nbytes >= bucket_bytes:
                 flush()
                 if stage is not None and t.device != stage:
-                    big = t.detach().to(stage)
+                    big = t.detach().to(stage) if dist.get_rank() == src else torch.empty(t.shape, dtype=t.dtype, device=stage)
                     dist.broadcast(big, src=src)
                     t.copy_(big)
                 else:

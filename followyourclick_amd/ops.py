@@ -336,7 +336,8 @@ class HipOps:
         key = ("gnws", rows, groups, rows_per_sample)
         need = self._q_cache.get(key)
         if need is None:
-            need = self._q_cache[key] = int(self.lib.fyc_gn_stats_workspace(C.byref(a)))
+            # (an older A/B library - FYC_LIB_PATH - may predate the entry point: it then reduces without a workspace)
+            need = self._q_cache[key] = int(self.lib.fyc_gn_stats_workspace(C.byref(a))) if hasattr(self.lib, "fyc_gn_stats_workspace") else 0
         if need > 0:     # chunk partial sums of the ordered (atomic-free) reduction: the split-K scratch buffer, same stream
             if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)

@@ -1,0 +1,124 @@
+"""The UNMODIFIED reference UNet3DConditionModel on the MI355X itself (eager PyTorch-ROCm), as the reference deploys it:
+`torch.autocast("cuda")` around the denoising loop (/root/reference/scripts/inference.py:294), memory-efficient attention asserted
+(:157-158).  TEST INFRASTRUCTURE - nothing under followyourclick_amd/ imports this file.
+
+Two uses:
+  * tests/test_reference_gpu.py: the same-device, same-precision yardstick.  The bf16 / f16 bounds of tests/test_fullwidth_gpu.py
+    are relative to a CPU EMULATION of autocast (oracle/autocast_emul.py); here the real autocast runs on the same chip as the
+    engine, which (i) validates that emulation and (ii) gives the engine a measured same-device drift to be held to.
+  * bench.py's `gpu_reference` leg: frames/s of the reference's own GPU path beside the CPU number (run as a subprocess of bench.py:
+    `python -m oracle.gpu_reference --json ...`), on random-init weights of the same architecture, synthetic inputs of the benchmark
+    shape, 1 untimed + N timed CFG-pair forwards (= DDIM steps), extrapolated to the clip.
+
+The model code is imported from the git-ignored byte copies under oracle/_ref/ (oracle/stage_ref_scripts.py; /root/reference does not
+exist on the GPU box) through oracle/refshim.py.  What is fabricated is the environment, never the reference:
+  * xformers is not installed in this image.  `attention="sdpa"` registers a stand-in `xformers` module whose
+    `ops.memory_efficient_attention(q, k, v, attn_bias)` is torch's fused scaled-dot-product attention - the reference then takes its
+    deployed `_memory_efficient_attention_xformers` branch (animatediff/models/attention.py:92-93, diffusers/models/attention.py:
+    649-678); `attention="eager"` leaves xformers absent and the reference materialises the scores (baddbmm + softmax).
+"""
+import argparse
+import importlib.machinery as _M
+import json
+import sys
+import time
+import types
+
+import torch
+
+
+def install_sdpa_xformers():
+    """a stand-in `xformers` package: memory_efficient_attention -> torch SDPA (same math: softmax(q k^T / sqrt(d) + bias) v)"""
+    if "xformers" in sys.modules and getattr(sys.modules["xformers"], "_fyc_stub", False):
+        return
+    import torch.nn.functional as F
+    xf = types.ModuleType("xformers")
+    xf.__spec__ = _M.ModuleSpec("xformers", None, is_package=True)
+    xf.__path__ = []
+    xf.__version__ = "0.0.0+sdpa-stand-in"
+    xf._fyc_stub = True
+    ops = types.ModuleType("xformers.ops")
+    ops.__spec__ = _M.ModuleSpec("xformers.ops", None)
+
+    def memory_efficient_attention(query, key, value, attn_bias=None, p=0.0, scale=None, op=None):
+        return F.scaled_dot_product_attention(query, key, value, attn_mask=attn_bias, dropout_p=p, scale=scale)
+    ops.memory_efficient_attention = memory_efficient_attention
+    xf.ops = ops
+    sys.modules["xformers"] = xf
+    sys.modules["xformers.ops"] = ops
+
+
+def build_reference_unet(device, max_len=24, attention="sdpa", seed=0, ocfg=None):
+    """the real animatediff.models.unet.UNet3DConditionModel at SD-1.5 widths with the seeded weights every golden uses"""
+    from . import functional as Fn
+    from . import refshim
+    from . import weights as W
+    if attention == "sdpa":
+        install_sdpa_xformers()
+    refshim.install()
+    if attention == "sdpa":
+        import diffusers.utils.import_utils as iu      # the reference's own module: package metadata of the stand-in does not exist
+        iu._xformers_available = True
+    from .make_golden import ref_unet
+    cfg = ocfg or (Fn.UNetConfig(temporal_position_encoding_max_len=max_len) if max_len != 24 else Fn.UNetConfig())
+    unet = ref_unet(cfg).eval()
+    unet.load_state_dict(W.make_weights(W.unet_state_shapes(cfg), seed=seed), strict=True)
+    unet = unet.to(device)
+    if attention == "sdpa":
+        unet.enable_xformers_memory_efficient_attention()
+    return cfg, unet
+
+
+def forward(unet, x9, t, text, fps, flow, autocast_dtype=None, **kw):
+    """one UNet3DConditionModel.forward as scripts/inference.py runs it: no_grad, torch.autocast("cuda", dtype) unless dtype is None (f32)"""
+    dev = next(unet.parameters()).device
+    args = (x9.to(dev), torch.as_tensor(t).to(dev), text.to(dev))
+    kws = dict(use_fps_condition=True, fps_tensor=fps.to(dev), flow_control=flow.to(dev), **kw)
+    with torch.no_grad():
+        if autocast_dtype is None:
+            return unet(*args, **kws).sample.float()
+        with torch.autocast("cuda", dtype=autocast_dtype):
+            return unet(*args, **kws).sample.float()
+
+
+def time_reference(frames=16, size=512, ddim_steps=25, dtype="bf16", attention="sdpa", timed=2):
+    dev = torch.device("cuda", 0)
+    t0 = time.time()
+    cfg, unet = build_reference_unet(dev, max_len=max(24, frames), attention=attention)
+    t_build = time.time() - t0
+    h = w = size // 8
+    g = torch.Generator().manual_seed(1)
+    text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    ac = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[dtype]
+    times = []
+    for i in range(1 + timed):
+        x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = forward(unet, x9, 961 - 40 * i, text, fps, flow, ac)
+        torch.cuda.synchronize()
+        times.append(time.time() - t0)
+        assert torch.isfinite(out).all()
+    dt = sum(times[1:]) / timed
+    return dict(value=round(frames / (ddim_steps * dt), 4), unit="frames/s", kind="reference",
+                s_per_ddim_step=round(dt, 4), first_step_s=round(times[0], 2), build_s=round(t_build, 1), dtype=dtype, attention=attention,
+                peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 1), torch=torch.__version__,
+                sample=f"the unmodified reference UNet3DConditionModel (oracle/_ref byte copies), eager PyTorch-ROCm under torch.autocast('cuda', {dtype}), "
+                       f"attention = {'torch SDPA behind a stand-in xformers module (the deployed branch)' if attention == 'sdpa' else 'materialised baddbmm + softmax (no xformers in this image)'}; "
+                       f"{timed} timed CFG-pair forwards (= DDIM steps) of {frames}f@{size}^2 after one untimed, {dt:.3f}s per step; frames/s = {frames} / ({ddim_steps} x {dt:.3f}s); "
+                       f"the guidance / scheduler arithmetic between forwards (< 0.1 % of a step) is not included")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=25)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--attention", default="sdpa", choices=["sdpa", "eager"])
+    ap.add_argument("--timed", type=int, default=2)
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    r = time_reference(a.frames, a.size, a.ddim_steps, a.dtype, a.attention, a.timed)
+    print("GPU_REFERENCE " + json.dumps(r) if a.json else r)

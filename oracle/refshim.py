@@ -18,7 +18,8 @@ import os
 import sys
 import types
 
-REFERENCE_ROOT = os.environ.get("FYC_REFERENCE_ROOT", "/root/reference")
+_STAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")      # byte copies written by oracle/stage_ref_scripts.py (git-ignored; travels to the GPU box)
+REFERENCE_ROOT = os.environ.get("FYC_REFERENCE_ROOT") or ("/root/reference" if os.path.isdir("/root/reference/animatediff") else _STAGED)
 
 
 def available() -> bool:

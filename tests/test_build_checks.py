@@ -72,6 +72,7 @@ def test_lane_swap_maximum_keeps_both_halves(tmp_path):
     src = tmp_path / "swapmax.hip"
     src.write_text('#include "%s"\n' % os.path.join(CSRC, "fyc_common.h") + '''
 __global__ void fixed(const float* in, float* out) { out[threadIdx.x] = swap32_max(swap16_max(in[threadIdx.x])); }
+__global__ void fsum(const float* in, float* out) { out[threadIdx.x] = swap32_sum(swap16_sum(in[threadIdx.x])); }
 __global__ void plain(const float* in, float* out) {          // the attention kernel's quad_max as it was written in rounds 1-4
   float mx = in[threadIdx.x];
   mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mx), 0x401F)));
@@ -94,6 +95,17 @@ __global__ void plain(const float* in, float* out) {          // the attention k
         a, b = m.group(2), m.group(3)
         # (canonicalising v_max x, x, x first, then the max of the two)
         assert re.search(rf"v_max_f32\w*\s+v\d+,\s*({a},\s*{b}|{b},\s*{a})\b", tail), f"the maximum after {m.group(0)} does not combine both results:\n{fixed}"
+    # the sums: same helpers, same requirement - the v_add after each swap reads BOTH of its registers (round-4 advice: with the operand
+    # held in one `unsigned`, hipcc 7.2 emits `v_add_f32 v1, v1, v1` = twice one half)
+    fsum = next(v for k, v in bodies.items() if "fsum" in k)
+    swaps = list(re.finditer(r"v_permlane(16|32)_swap_b32\w*\s+(v\d+),\s*(v\d+)", fsum))
+    assert len(swaps) == 2, fsum
+    for m in swaps:
+        tail = fsum[m.end():]
+        nxt = re.search(r"v_permlane(16|32)_swap", tail)
+        tail = tail[:nxt.start()] if nxt else tail
+        a, b = m.group(2), m.group(3)
+        assert re.search(rf"v_add_f32\w*\s+v\d+,\s*({a},\s*{b}|{b},\s*{a})\b", tail), f"the sum after {m.group(0)} does not combine both results:\n{fsum}"
     plain = next(v for k, v in bodies.items() if "plain" in k)
     m = re.search(r"v_permlane32_swap_b32\w*\s+(v\d+),\s*(v\d+)", plain)
     combined = m and re.search(rf"v_max_f32\w*\s+v\d+,\s*({m.group(1)},\s*{m.group(2)}|{m.group(2)},\s*{m.group(1)})\b", plain[m.end():])

@@ -158,6 +158,32 @@ def test_bench_entry_point_under_torch_distributed_run(tmp_path):
     assert d["metric"] == "denoised frames/sec, 2f x 64^2 clip @ 2 DDIM steps" and d["config"]["workload"].startswith("custom")
 
 
+def test_bench_plain_invocation_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (the form a driver may use for the scaling run): the script re-executes
+    itself under torch.distributed.run and the line says n_gpus 2 with 2 ranks counted by an all-reduce - never a silent N = 1
+    (round-4 review).  A launcher that starts a different number of ranks than --gpus is an error, not an override."""
+    import json
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    tail = ["--steps", "1", "--warmup", "1", "--frames", "2", "--size", "64", "--ddim-steps", "2", "--dtype", "f32"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_emulated.py"), "--gpus", "2", *tail], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo" and d["data"] == "emulated"
+    # one rank started for a 2-GPU request: non-zero exit, no JSON line
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29773",
+           os.path.join(ROOT, "tests", "bench_emulated.py"), "--gpus", "2", *tail]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "refusing" in r.stderr
+
+
 def test_bench_labels_follow_the_arguments():
     """only the default arguments claim BASELINE.json's configs[1] (round 3 stamped every line with it)"""
     import argparse

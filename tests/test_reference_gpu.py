@@ -1,0 +1,108 @@
+"""The same-device, same-precision yardstick: the UNMODIFIED reference UNet3DConditionModel on `cuda:0` (eager PyTorch-ROCm) under
+the real `torch.autocast("cuda")` (/root/reference/scripts/inference.py:294), imported from the git-ignored byte copies under
+oracle/_ref/ (oracle/stage_ref_scripts.py, oracle/gpu_reference.py - test infrastructure).
+
+  (i)  validates oracle/autocast_emul.py: every bf16 / f16 bound of tests/test_fullwidth_gpu.py is relative to a CPU EMULATION of
+       autocast's cast lists; here the real thing runs on the chip and its drift (autocast vs f32, same device) is compared with the
+       emulated drift the goldens store;
+  (ii) holds the engine to the MEASURED same-device drift: engine-16-bit vs the device's own f32 reference run must be no further than
+       SAME_DEVICE_FACTOR x (device autocast run vs device f32 run).
+
+Numbers go to gpurun_out/parity_report.txt (copied to profiles/).
+"""
+import os
+
+import pytest
+import torch
+
+from followyourclick_amd.engine import UNet3DConfig
+from followyourclick_amd.engine.unet3d import UNet3DEngine
+from followyourclick_amd.engine.weights import pack_unet
+from oracle import functional as Fn
+from oracle import weights as W
+
+from test_engine_gpu import _load, _nhwc, rel, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGED = os.path.join(ROOT, "oracle", "_ref", "animatediff", "models", "unet.py")
+# engine 16-bit mode vs the device's f32 reference run <= SAME_DEVICE_FACTOR x (the reference's own autocast run vs its f32 run, same
+# device).  The CPU-emulated rule is 1.1 x (tests/test_fullwidth_gpu.py, measured 0.88-0.95 x); the real autocast also keeps softmax /
+# norms in f32 but runs its GEMMs through other kernels (hipBLASLt / MIOpen, other accumulation orders), so the ratio is measured here
+# and the bound leaves the same ~15 % the emulated rule leaves.
+SAME_DEVICE_FACTOR = 1.15
+# the emulation is accepted as a yardstick when the drift it predicts is within this band of the drift measured on the device
+EMUL_BAND = (0.7, 1.4)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not (os.path.exists(STAGED) or os.path.isdir("/root/reference/animatediff")):
+        pytest.skip("reference model files not staged (python -m oracle.stage_ref_scripts, container only)")
+    from oracle import gpu_reference as G
+    cfg, unet = G.build_reference_unet(DEV, attention="sdpa")
+    yield G, cfg, unet
+    del unet
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def small_case(golden_dir, ref):
+    """the unet_full_small_fwd inputs, and the reference's three runs of them on the device"""
+    G, cfg, unet = ref
+    g = _load(golden_dir, "unet_full_small_fwd.npz")
+    F, H, Wd = int(g["frames"]), int(g["h"]), int(g["w"])
+    inp = W.seeded_inputs(Fn.UNetConfig(), 1, F, H, Wd, seed=int(g["input_seed"]))
+    x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+    runs = {}
+    for name, ac in (("f32", None), ("bf16", torch.bfloat16), ("f16", torch.float16)):
+        runs[name] = G.forward(unet, x9, int(g["timestep"]), inp["text"], g["fps"], g["flow"], ac).cpu()
+        assert torch.isfinite(runs[name]).all(), name
+    return g, inp, x9, runs
+
+
+def test_device_reference_reproduces_the_cpu_golden(small_case):
+    """the staged byte copies on PyTorch-ROCm compute what /root/reference computed on the CPU: f32 run vs the committed golden"""
+    g, inp, x9, runs = small_case
+    r = rel(runs["f32"], g["out_f32"])
+    report(f"same-device reference (F=4, 16x16) f32 on cuda vs CPU golden: {r:.3e}")
+    assert r < 1e-3, r       # (MIOpen / hipBLASLt f32 kernels may split K differently from oneDNN; measured value in the report)
+
+
+def test_real_autocast_validates_the_cpu_emulation(golden_dir, small_case):
+    g, inp, x9, runs = small_case
+    yard = _load(golden_dir, "f16_yardstick.npz") if os.path.exists(os.path.join(golden_dir, "f16_yardstick.npz")) else {}
+    d_bf16 = rel(runs["bf16"], runs["f32"])
+    d_f16 = rel(runs["f16"], runs["f32"])
+    e_bf16 = float(g["drift"])
+    report(f"same-device reference drift: torch.autocast(cuda, bf16) vs f32 {d_bf16:.3e} (CPU emulation predicted {e_bf16:.3e}, ratio {d_bf16 / e_bf16:.2f}); "
+           f"bf16 device run vs emulated bf16 run {rel(runs['bf16'], g['out_bf16']):.3e}")
+    assert EMUL_BAND[0] < d_bf16 / e_bf16 < EMUL_BAND[1], (d_bf16, e_bf16)
+    if "small_fwd_drift_f16" in yard:
+        e_f16 = float(yard["small_fwd_drift_f16"])
+        report(f"same-device reference drift: torch.autocast(cuda, f16) vs f32 {d_f16:.3e} (CPU emulation predicted {e_f16:.3e}, ratio {d_f16 / e_f16:.2f})")
+        assert EMUL_BAND[0] < d_f16 / e_f16 < EMUL_BAND[1], (d_f16, e_f16)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_engine_vs_same_device_reference(small_case, mode):
+    """the engine's 16-bit modes against the reference's runs ON THE SAME CHIP: no further from the f32 run than the reference's own
+    autocast run of that precision (x SAME_DEVICE_FACTOR); the distance between the two 16-bit runs is reported"""
+    g, inp, x9, runs = small_case
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
+    F, H, Wd = int(g["frames"]), int(g["h"]), int(g["w"])
+    sd = W.make_weights(W.unet_state_shapes(Fn.UNetConfig()), seed=int(g["weight_seed"]))
+    eng = UNet3DEngine(pack_unet(sd, UNet3DConfig(), dtype, DEV))
+    del sd
+    eng.prepare_context(inp["text"])
+    _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), 2)
+    out = eng.forward(_nhwc(x9, dtype), temb, 2, F, H, Wd).float().cpu().reshape(2, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+    assert torch.isfinite(out).all()
+    drift = rel(runs[mode], runs["f32"])
+    r32, r16 = rel(out, runs["f32"]), rel(out, runs[mode])
+    report(f"engine {mode} vs same-device reference (F=4, 16x16): vs ref-f32-on-cuda {r32:.3e} = {r32 / drift:.2f} x the reference's own "
+           f"{mode}-autocast drift on this chip ({drift:.3e}); vs ref-{mode}-autocast-on-cuda {r16:.3e}")
+    assert r32 < SAME_DEVICE_FACTOR * drift, (r32, drift)
+    del eng
+    torch.cuda.empty_cache()

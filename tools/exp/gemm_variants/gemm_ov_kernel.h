@@ -31,7 +31,7 @@
 // step must fit under a K loop), statistics per whole tile (cs_rows % 128 == 0), no split-K / row statistics / batch.  fyc_gemm()
 // falls back to the one-phase kernels for everything else.
 #pragma once
-#include "gemm_kernel.h"
+#include "../../../followyourclick_amd/csrc/gemm_kernel.h"
 
 namespace fycg {
 

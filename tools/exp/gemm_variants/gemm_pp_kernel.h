@@ -25,7 +25,7 @@
 // Per output tile the groups are re-aligned (X waits one barrier at the end, Y one at the start) so that the epilogue's own
 // barriers see all eight waves in the same place.
 #pragma once
-#include "gemm_kernel.h"
+#include "../../../followyourclick_amd/csrc/gemm_kernel.h"
 
 namespace fycg {
 

@@ -1,4 +1,4 @@
-"""a few fyc_ff_block launches at the 64x64-level shape, for rocprofv3 --pmc runs: python tools/ff_pmc.py [tuning9]"""
+"""a few fyc_ff_block launches at the 64x64-level shape, for rocprofv3 --pmc runs: python tools/ff_pmc.py"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,8 +9,6 @@ from followyourclick_amd.engine.weights import Packed, pack_ff_block
 T, DEV, C, HID, rows = torch.bfloat16, torch.device("cuda:0"), 320, 1280, 131072
 h = ops.get()
 h.ensure_init(DEV)
-if len(sys.argv) > 1:
-    h.set_tuning(9, int(sys.argv[1]))
 w1 = (torch.randn(2 * HID, C, device=DEV) * C ** -0.5).to(T)
 ff = Packed(w1=w1, b1=torch.randn(2 * HID, device=DEV) * 0.1, cs1=w1.float().sum(dim=1).contiguous(),
             po_w=(torch.randn(C, C + HID, device=DEV) * (C + HID) ** -0.5).to(T), po_b=torch.randn(C, device=DEV) * 0.1)

@@ -58,13 +58,8 @@ def main():
 
         res = {}
         for rnd in range(3):                    # interleaved rounds: variants see the same clocks
-            for name, fn, key, k9 in (("unfused (3 launches)", unfused, None, 0), ("ff_block", fused, 0, 0),):
-                if key is not None:
-                    h.set_tuning(8, key)
-                h.set_tuning(9, k9)
+            for name, fn in (("unfused (3 launches)", unfused), ("ff_block", fused)):     # (the round-3 scheduling bits behind tuning keys 8 / 9 are gone: those keys belong to the GEMM variants now)
                 res.setdefault(name, []).append(timed(fn, 2 * nb))
-        h.set_tuning(8, 0)
-        h.set_tuning(9, 0)
         for name, v in res.items():
             us = min(v)
             print(f"rows={rows:7d}  {name:40s} {us:8.1f} us (min of {['%.1f' % t for t in v]})  {flops / us / 1e6:7.0f} TFLOP/s", flush=True)
