@@ -25,7 +25,6 @@
 // f32 parity mode uses the same kernel with v_mfma_f32_16x16x4_f32 (exact f32, 1/16 rate).
 #pragma once
 #include <mutex>
-#include <type_traits>
 
 #include "fyc_common.h"
 
@@ -130,9 +129,6 @@ __device__ __forceinline__ float activate(float x, int act) {
   return act == FYC_ACT_GELU ? gelu_erf_f(x) : x / (1.0f + __expf(-1.702f * x));
 }
 
-#ifdef FYC_IL_GAP
-template <int TOTAL, int LOADS> constexpr int il_gap() { return (TOTAL * FYC_IL_GAP / 100 / LOADS) > 0 ? (TOTAL * FYC_IL_GAP / 100 / LOADS) : 1; }
-#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // swizzle key of an LDS row: 128-B rows (8 chunks) use row&7; 64-B rows (4 chunks) use a 4-entry table over (row>>2)&3 -
@@ -986,17 +982,14 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       if (FRAG_ALL) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // one 1-KiB DMA piece of K tile kt into ring stage `stage`: pieces [0, A_IT) are A rows, [A_IT, LOADS) weight rows
-  // (`live` false: the stream has ended - the piece reads the zero page into the ring stage nobody will consume, so that the
-  // interleaved main loop below stays one basic block)
-  auto issue_piece = [&](int piece, int kt, int stage, bool live = true) {
+  auto issue = [&](int kt, int stage) {
     char* sA = smem + stage * STAGE;
     char* sB = sA + A_BYTES;
     const int k0 = kt * BK;
-    if (piece < A_IT) { const T* s = src_a(piece, k0); glds16(live ? s : zero, sA + (piece * NT + wave * 64) * 16); }
-    else { const T* s = src_b(piece - A_IT, k0); glds16(live ? s : zero, sB + ((piece - A_IT) * NT + wave * 64) * 16); }
-  };
-  auto issue_tap_advance = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) glds16(src_a(it, k0), sA + (it * NT + wave * 64) * 16);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) glds16(src_b(it, k0), sB + (it * NT + wave * 64) * 16);
     if (MODE != FYC_GEMM_PLAIN) {  // K order = (128-B channel slab, ky, kx, channel): the 9 taps of a slab are adjacent
       if (RB == 128) {
         if (++tap == 9) { tap = 0; c0 += BK; }
@@ -1006,12 +999,6 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       }
     }
   };
-  auto issue = [&](int kt, int stage) {
-#pragma unroll
-    for (int pc = 0; pc < LOADS; ++pc) issue_piece(pc, kt, stage);
-    issue_tap_advance();
-  };
-
 
   // ---- main loop: NS-deep ring over the continuous K-tile stream, counted waits -------------------
   const int nwork = ntiles * S;
@@ -1019,41 +1006,6 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   int st_c = 0, st_i = 0;                 // stage being computed / issued
   int n_ahead = 0;                        // stream elements issued and not yet consumed
   auto begin_issue = [&]() { setup_issue(i_tile); i_kt = kt_begin(i_tile); i_kt_end = kt_end(i_tile); };
-#ifdef FYC_IL_GAP
-  // Interleaved K tile (round 5): the LOADS DMA pieces of the NEXT K tile are dealt out between the MFMAs of this one - piece q in
-  // front of MFMA number OFF + q * FYC_IL_GAP of the tile's KSTEPS * WTM * WTN - instead of being issued as one block behind the
-  // barrier.  A global_load_lds costs the issuing wave 100-185 cycles when the CU's vector-memory path is already busy with the
-  // other waves' pieces (profiles/r04_gemm_phase_trace.txt: 9 pieces per wave and K tile, back to back); spread over the tile, a
-  // piece arrives at that path every ~40 cycles instead of 72 at once.
-  auto compute_il = [&](int stage, bool live, auto offc) __attribute__((always_inline)) {
-    // FYC_IL_GAP = percentage of the tile's MFMAs the pieces are spread over (the rest is landing time before the next barrier)
-    constexpr int OFF = decltype(offc)::value, GAP = il_gap<KSTEPS * WTM * WTN, LOADS>();
-    const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * RB;
-    const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * RB;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      const int coff = ((4 * s + g) ^ sw) * 16;
-      Frag af[WTM], bf[WTN];
-#pragma unroll
-      for (int i = 0; i < WTM; ++i) af[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * RB + coff);
-#pragma unroll
-      for (int j = 0; j < WTN; ++j) bf[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * RB + coff);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < WTM; ++i)
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) {
-          const int n = (s * WTM + i) * WTN + j - OFF;
-          if (n >= 0 && n % GAP == 0 && n / GAP < LOADS) {
-            issue_piece(n / GAP, i_kt, st_i, live);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          acc[i][j] = Tr::mma(bf[j], af[i], acc[i][j]);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-#endif
   auto issue_next = [&]() {
     issue(i_kt, st_i);
     st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
@@ -1097,31 +1049,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       // every wave before this barrier, and the late DMAs still have a k-step of both waves to land.)
       // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
       const bool late = STAGGER && p.stagger && wave >= (WGM * WGN) / 2;
-#ifdef FYC_IL_GAP
-      if constexpr (sizeof(T) == 2 && NS == 2 && LOADS <= KSTEPS * WTM * WTN) {
-        // the two waves of a SIMD run the same stream: without a skew both wait for their fragment reads at the same time, twice per
-        // K tile, with the matrix pipe idle.  The upper half of the waves starts each K tile p.stagger - 1 x 64 cycles late, so that
-        // one wave's reads sit under its partner's MFMAs.
-        if (late) for (int q = 1; q < p.stagger; ++q) __builtin_amdgcn_s_sleep(1);
-        const bool live = i_tile < nwork;
-        compute_il(st_c, live, std::integral_constant<int, 0>());      // (one copy of the MFMA code: a second, offset one for the upper waves doubled the loop and spilled)
-        if (live) {
-          issue_tap_advance();
-          st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
-          ++n_ahead;
-          if (++i_kt == i_kt_end) {
-            i_tile += gridDim.x;
-            if (i_tile < nwork) begin_issue();
-          }
-        }
-      } else
-#endif
-      {
       if (!late && i_tile < nwork) issue_next();
       compute(st_c, 0, 1);
       if (late && i_tile < nwork) issue_next();
       compute(st_c, 1, KSTEPS);
-      }
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     }
     FYC_STAMP(p, wave, lane);
@@ -1185,9 +1116,6 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
   q.rb_slots = (WIDE && EPI == FYC_EPI_LINEAR && p.rowbias != nullptr && !q.rb_tile) ? rowbias_slots(BM, p.rows_per_batch) : 0;
   q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
-#ifdef FYC_IL_GAP
-  q.stagger = g_fyc_tuning[5] == 1 ? 0 : (g_fyc_tuning[5] > 1 ? g_fyc_tuning[5] : 5);   // interleaved loop: start skew of the upper waves in units of 64 cycles, + 1
-#endif
   q.res_acc = (WIDE && EPI == FYC_EPI_LINEAR && p.residual != nullptr && p.ln_stats == nullptr && !(q.splitk > 1)) ? 1 : 0;
 #ifdef FYC_TRACE
   q.trace = g_fyc_trace;

@@ -103,6 +103,9 @@ def sweep(h):
 def main():
     h = ops.get()
     h.ensure_init(DEV)
+    for kv in filter(None, os.environ.get("PROBE_TUNING", "").split(",")):      # e.g. PROBE_TUNING=5=3,0=1
+        k, v = kv.split("=")
+        h.set_tuning(int(k), int(v))
     if os.environ.get("PROBE_SWEEP"):
         return sweep(h)
     cases = [
