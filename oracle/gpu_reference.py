@@ -41,7 +41,17 @@ def install_sdpa_xformers():
     ops.__spec__ = _M.ModuleSpec("xformers.ops", None)
 
     def memory_efficient_attention(query, key, value, attn_bias=None, p=0.0, scale=None, op=None):
-        return F.scaled_dot_product_attention(query, key, value, attn_mask=attn_bias, dropout_p=p, scale=scale)
+        # f32 runs fall back to SDPA's materialising "math" path: cut the (batch x heads) axis so that one slice's scores stay below
+        # ~8 GiB (F = 32 at 96x96 would otherwise ask for 174 GB) - the same per-(batch, head) arithmetic
+        n = query.shape[0]
+        per = query.shape[-2] * key.shape[-2] * 4 * (2 if query.dtype == torch.float32 else 1)
+        step = n if query.dtype != torch.float32 else max(1, min(n, (8 << 30) // max(per, 1)))
+        if step >= n:
+            return F.scaled_dot_product_attention(query, key, value, attn_mask=attn_bias, dropout_p=p, scale=scale)
+        out = [F.scaled_dot_product_attention(query[i:i + step], key[i:i + step], value[i:i + step],
+                                              attn_mask=None if attn_bias is None else attn_bias[i:i + step], dropout_p=p, scale=scale)
+               for i in range(0, n, step)]
+        return torch.cat(out)
     ops.memory_efficient_attention = memory_efficient_attention
     xf.ops = ops
     sys.modules["xformers"] = xf
@@ -63,6 +73,11 @@ def build_reference_unet(device, max_len=24, attention="sdpa", seed=0, ocfg=None
     cfg = ocfg or (Fn.UNetConfig(temporal_position_encoding_max_len=max_len) if max_len != 24 else Fn.UNetConfig())
     unet = ref_unet(cfg).eval()
     unet.load_state_dict(W.make_weights(W.unet_state_shapes(cfg), seed=seed), strict=True)
+    if cfg.use_ip_cross_attention:          # the goldens feed projected image tokens directly (oracle/make_golden_full.py::ip)
+        class Proj(torch.nn.Module):
+            def forward(self, feat):
+                return feat
+        unet.image_proj_model = Proj()
     unet = unet.to(device)
     if attention == "sdpa":
         unet.enable_xformers_memory_efficient_attention()
@@ -79,6 +94,44 @@ def forward(unet, x9, t, text, fps, flow, autocast_dtype=None, **kw):
             return unet(*args, **kws).sample.float()
         with torch.autocast("cuda", dtype=autocast_dtype):
             return unet(*args, **kws).sample.float()
+
+
+SCHED_KW = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear", steps_offset=1,
+                clip_sample=False, prediction_type="v_prediction", rescale_betas_zero_snr=True)
+
+
+def reference_trajectory(unet, inp, num_steps, run_steps, autocast_dtype=None, guidance_scale=8.0, mask=None, ip_tokens=None, fps=2, flow=4):
+    """The first `run_steps` of a `num_steps`-step sampling run with the REAL UNet3DConditionModel and the REAL DDIMScheduler on the
+    device: the loop body of AnimationPipeline.__call__ (pipeline_animation.py:686-773: first-frame / mask concat, CFG duplication,
+    guidance, scheduler.step) around them, under `torch.autocast("cuda", dtype)` as the reference runs it (:686) or in f32.  The loop
+    body itself is pinned by the full-pipeline goldens (cfg1 / cfg2 / cfg5_trajectory.npz); here it lets the trajectories the CPU cannot
+    afford - BASELINE configs[3] and [4] at full shape - come from the reference's own modules on the chip under test.
+    Returns {step index: latents (cpu, f32)}."""
+    import contextlib
+    from diffusers.schedulers.scheduling_ddim import DDIMScheduler      # the reference's (oracle/refshim.py)
+    from . import functional as Fn
+    dev = next(unet.parameters()).device
+    sched = DDIMScheduler(**SCHED_KW)
+    sched.set_timesteps(num_steps)
+    lat = inp["latents"].clone().to(dev)
+    first = inp["first_image_latents"].to(dev)
+    m = (inp["first_images_mask"] if mask is None else mask).to(dev)
+    text = inp["text"].to(dev)
+    fps_t, flow_t = torch.tensor([fps, fps], device=dev), torch.tensor([flow, flow], device=dev)
+    kw = dict(use_fps_condition=True, fps_tensor=fps_t, flow_control=flow_t)
+    if ip_tokens is not None:
+        kw.update(use_ip_cross_attention=True, reference_images_clip_feat=ip_tokens.to(dev))
+    out = {}
+    ctx = torch.autocast("cuda", dtype=autocast_dtype) if autocast_dtype is not None else contextlib.nullcontext()
+    with torch.no_grad(), ctx:
+        for i, t in enumerate(sched.timesteps[:run_steps]):
+            x9 = torch.cat([Fn.build_model_input(lat, first, m)] * 2)
+            pred = unet(x9, t.to(dev), text, **kw).sample.to(lat.dtype)
+            u, c = pred.chunk(2)
+            pred = u + guidance_scale * (c - u)
+            lat = sched.step(pred, t, lat).prev_sample
+            out[i] = lat.detach().float().cpu()
+    return out
 
 
 def time_reference(frames=16, size=512, ddim_steps=25, dtype="bf16", attention="sdpa", timed=2):
