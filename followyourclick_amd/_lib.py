@@ -92,13 +92,14 @@ class CastArgs(C.Structure):
 class UnetInputArgs(C.Structure):
     _fields_ = [("latents", vp), ("mask", vp), ("first", vp), ("x", vp),
                 ("B", i32), ("F", i32), ("HW", i32), ("c_latent", i32), ("c_pad", i32), ("cfg_dup", i32), ("mask_frames", i32),
-                ("dtype", i32)]
+                ("dtype", i32), ("mode", i32)]
 
 
 class CfgDdimArgs(C.Structure):
     _fields_ = [("pred", vp), ("latents", vp), ("coef", vp),
                 ("B", i32), ("F", i32), ("HW", i32), ("c_latent", i32), ("ld", i32), ("cfg", i32), ("guidance", f32),
-                ("pred_type", i32), ("clip_sample", i32), ("dtype", i32), ("pred_single", vp), ("video_scale", f32)]
+                ("pred_type", i32), ("clip_sample", i32), ("dtype", i32), ("pred_single", vp), ("video_scale", f32),
+                ("variance_noise", vp), ("sigma", f32), ("clipped_model_output", i32)]
 
 
 class NchwInArgs(C.Structure):
@@ -160,7 +161,7 @@ MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set
         "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
-FYC_VERSION = 201        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
+FYC_VERSION = 202        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
 
 
 class FycError(RuntimeError):

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) cast_to_kernel(const T* __restrict__ x, f
 template <typename T>
 __global__ void __launch_bounds__(256) unet_input_kernel(const float* __restrict__ lat, const float* __restrict__ mask,
                                                          const float* __restrict__ first, T* __restrict__ x, int B, int F,
-                                                         int HW, int CL, int c_pad, int cfg_dup, int mask_frames) {
+                                                         int HW, int CL, int c_pad, int cfg_dup, int mask_frames, int mode) {
   const long long total = (long long)cfg_dup * B * F * HW;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int p = (int)(i % HW);
@@ -55,6 +55,11 @@ __global__ void __launch_bounds__(256) unet_input_kernel(const float* __restrict
     const int b = (int)((bf / F) % B);  // CFG duplicates share the same latents
     T* o = x + i * c_pad;
     for (int c = 0; c < CL; ++c) ElemIO<T>::st(o + c, lat[(((long long)b * CL + c) * F + f) * HW + p]);
+    if (mode == 1) {          // use_first_frame_condition_concat: the clean first-frame latents beside the latents of EVERY frame
+      for (int c = 0; c < CL; ++c) ElemIO<T>::st(o + CL + c, first ? first[((long long)b * CL + c) * HW + p] : 0.f);
+      for (int c = 2 * CL; c < c_pad; ++c) ElemIO<T>::st(o + c, 0.f);
+      continue;
+    }
     float m;
     if (mask) {
       const int mf = mask_frames > 1 ? f : 0;
@@ -73,7 +78,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ pred, float* __restrict__ lat,
                                                        const float* __restrict__ coef, int B, int F, int HW, int CL, int ld,
                                                        int cfg, float guidance, int pred_type, int clip,
-                                                       const T* __restrict__ single, float video_scale) {
+                                                       const T* __restrict__ single, float video_scale,
+                                                       const float* __restrict__ noise, float sigma, int reclip) {
   const float sa = coef[0], sb = coef[1], sap = coef[2], sbp = coef[3];
   const long long total = (long long)B * F * HW;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -96,7 +102,10 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T* __restrict__ pre
       else if (pred_type == 0) { x0 = (x - sb * v) / sa; eps = v; }
       else { x0 = v; eps = v; }
       if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-      *lp = sap * x0 + sbp * eps;
+      if (reclip) eps = (x - sa * x0) / sb;                        // use_clipped_model_output (scheduling_ddim.py:342-344)
+      float nx = sap * x0 + sbp * eps;
+      if (noise) nx += sigma * noise[(((long long)b * CL + c) * F + f) * HW + p];      // eta > 0 (:346-363)
+      *lp = nx;
     }
   }
 }
@@ -257,16 +266,17 @@ extern "C" int fyc_cast_to_f32(const fyc_cast_to_args* a, void* stream) {
 
 extern "C" int fyc_unet_input(const fyc_unet_input_args* a, void* stream) {
   FYC_REQUIRE(a && a->latents && a->x, "fyc_unet_input: null pointer");
-  FYC_REQUIRE(a->B > 0 && a->F > 0 && a->HW > 0 && a->c_latent > 0 && a->c_pad >= 2 * a->c_latent + 1, "fyc_unet_input: bad dims");
+  FYC_REQUIRE(a->B > 0 && a->F > 0 && a->HW > 0 && a->c_latent > 0 && a->c_pad >= 2 * a->c_latent + (a->mode == 1 ? 0 : 1), "fyc_unet_input: bad dims");
+  FYC_REQUIRE(a->mode == 0 || a->mode == 1, "fyc_unet_input: mode %d", a->mode);
   FYC_REQUIRE(a->cfg_dup == 1 || a->cfg_dup == 2, "fyc_unet_input: cfg_dup must be 1 or 2");
   FYC_REQUIRE(a->mask == nullptr || a->mask_frames == 1 || a->mask_frames == a->F, "fyc_unet_input: mask_frames must be 1 or F");
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)a->cfg_dup * a->B * a->F * a->HW;
   const int mf = a->mask ? a->mask_frames : 1;
   FYC_DT(a,
-         hipLaunchKernelGGL(unet_input_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (bf16_t*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf),
-         hipLaunchKernelGGL(unet_input_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (f16_t*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf),
-         hipLaunchKernelGGL(unet_input_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (float*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf));
+         hipLaunchKernelGGL(unet_input_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (bf16_t*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf, a->mode),
+         hipLaunchKernelGGL(unet_input_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (f16_t*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf, a->mode),
+         hipLaunchKernelGGL(unet_input_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, a->latents, a->mask, a->first, (float*)a->x, a->B, a->F, a->HW, a->c_latent, a->c_pad, a->cfg_dup, mf, a->mode));
   FYC_CHECK_LAUNCH("fyc_unet_input");
   return 0;
 }
@@ -276,12 +286,13 @@ extern "C" int fyc_cfg_ddim_step(const fyc_cfg_ddim_args* a, void* stream) {
   FYC_REQUIRE(a->B > 0 && a->F > 0 && a->HW > 0 && a->c_latent > 0 && a->ld >= a->c_latent, "fyc_cfg_ddim_step: bad dims");
   FYC_REQUIRE(a->pred_type >= 0 && a->pred_type <= 2, "fyc_cfg_ddim_step: pred_type %d", a->pred_type);
   FYC_REQUIRE(a->pred_single == nullptr || a->cfg, "fyc_cfg_ddim_step: pred_single needs classifier-free guidance (cfg = 1)");
+  FYC_REQUIRE(a->variance_noise == nullptr || a->sigma >= 0.f, "fyc_cfg_ddim_step: sigma %g", (double)a->sigma);
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)a->B * a->F * a->HW;
   FYC_DT(a,
-         hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const bf16_t*)a->pred_single, a->video_scale),
-         hipLaunchKernelGGL(cfg_ddim_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const f16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const f16_t*)a->pred_single, a->video_scale),
-         hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const float*)a->pred_single, a->video_scale));
+         hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const bf16_t*)a->pred_single, a->video_scale, a->variance_noise, a->sigma, a->clipped_model_output),
+         hipLaunchKernelGGL(cfg_ddim_kernel<f16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const f16_t*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const f16_t*)a->pred_single, a->video_scale, a->variance_noise, a->sigma, a->clipped_model_output),
+         hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)a->pred, a->latents, a->coef, a->B, a->F, a->HW, a->c_latent, a->ld, a->cfg, a->guidance, a->pred_type, a->clip_sample, (const float*)a->pred_single, a->video_scale, a->variance_noise, a->sigma, a->clipped_model_output));
   FYC_CHECK_LAUNCH("fyc_cfg_ddim_step");
   return 0;
 }

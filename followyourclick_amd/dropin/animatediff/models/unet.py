@@ -79,7 +79,7 @@ class UNet3DConditionModel(nn.Module):
             "center_input_sample": center_input_sample, "dual_cross_attention": dual_cross_attention,
             "use_linear_projection": use_linear_projection, "class_embed_type": class_embed_type, "num_class_embeds": num_class_embeds,
             "unet_use_cross_frame_attention": unet_use_cross_frame_attention, "unet_use_temporal_attention": unet_use_temporal_attention,
-            "use_pseudo_conv3d": use_pseudo_conv3d, "use_camera_motion_condition": use_camera_motion_condition,
+            "use_pseudo_conv3d": use_pseudo_conv3d,
             "use_text_encoder_2": use_text_encoder_2, "use_inflated_groupnorm": use_inflated_groupnorm,
             "use_temporal_conv": use_temporal_conv, "motion_module_decoder_only": motion_module_decoder_only,
             "use_rope_postion_encoding": mm.get("use_rope_postion_encoding", False), "add_temporal_lora": mm.get("add_temporal_lora", False),
@@ -106,7 +106,8 @@ class UNet3DConditionModel(nn.Module):
             motion_attention_blocks=len(blocks), temporal_position_encoding=bool(mm.get("temporal_position_encoding", False)),
             temporal_position_encoding_max_len=mm.get("temporal_position_encoding_max_len", 24), use_fps_condition=bool(use_fps_condition),
             use_first_frame_mask_condition_concat=bool(use_first_frame_mask_condition_concat),
-            use_first_frame_condition_concat=bool(use_first_frame_condition_concat), use_ip_cross_attention=bool(use_ip_cross_attention),
+            use_first_frame_condition_concat=bool(use_first_frame_condition_concat), use_camera_motion_condition=bool(use_camera_motion_condition),
+            use_ip_cross_attention=bool(use_ip_cross_attention),
             ip_scale=float(scale), ip_num_tokens=int(num_tokens))
         # diffusers' @register_to_config contract: every ctor kwarg is an attribute and a `.config` entry
         # (the pipeline reads unet.in_channels and unet.config.sample_size, reference pipeline_animation.py:586-587,639)
@@ -188,12 +189,23 @@ class UNet3DConditionModel(nn.Module):
                 reference_images_clip_feat=None, use_camera_motion_condition=False, camera_movement_type_tensor=None,
                 use_image_concat_training=False, use_text_encoder_2=False, encoder_hidden_states_2=None, use_fps_condition=False,
                 fps_tensor=None, first_images_mask=None, flow_control=None):
-        if use_first_frame_condition or use_first_frame_condition_concat or use_camera_motion_condition or use_text_encoder_2:
-            raise NotImplementedError("only the mask + first-frame concat conditioning path is implemented (SURVEY.md 8)")
+        if use_first_frame_condition or use_text_encoder_2:
+            raise NotImplementedError("use_first_frame_condition (through AnimationPipeline only) / use_text_encoder_2 are not available on the module's forward")
         if attention_mask is not None or class_labels is not None:
             raise NotImplementedError("attention_mask / class_labels are not used by the FollowYourClick path")
         eng = self._get_engine()
         cfg, o = self.engine_config, eng.ops
+        if use_first_frame_condition_concat:
+            # reference unet.py:580-586: the clean first-frame latents are repeated over the frames and concatenated to the sample;
+            # the `sample / 2` behind conv_in (:589-590) is part of the packed conv_in weights of a model built with the option
+            if not cfg.use_first_frame_condition_concat:
+                raise ValueError("use_first_frame_condition_concat=True needs a model built with use_first_frame_condition_concat")
+            if reference_images_latent is not None:
+                sample = torch.cat((sample, reference_images_latent.unsqueeze(2).repeat(1, 1, sample.shape[2], 1, 1).to(sample)), dim=1)
+        elif cfg.use_first_frame_condition_concat:
+            raise ValueError("this model halves conv_in's output (built with use_first_frame_condition_concat): call it with use_first_frame_condition_concat=True")
+        if use_camera_motion_condition and not cfg.use_camera_motion_condition:
+            raise ValueError("use_camera_motion_condition=True needs a model built with use_camera_motion_condition")
         B, C, F, H, W = sample.shape
         if C != cfg.conv_in_channels:
             raise ValueError(f"sample has {C} channels, the model expects {cfg.conv_in_channels}")
@@ -231,11 +243,15 @@ class UNet3DConditionModel(nn.Module):
             return v * n if len(v) == 1 else v
 
         t = vec(timestep, 1)
-        if len(t) != 1 and len(set(t)) != 1:
-            raise NotImplementedError("per-sample timesteps: all batch elements must share one timestep")
+        if len(t) not in (1, B):
+            raise ValueError(f"timestep has {len(t)} entries for a batch of {B}")
         fps = vec(fps_tensor, B) if (use_fps_condition and cfg.use_fps_condition) else None
         flow = vec(flow_control, B) if fps is not None else None
-        _, temb = eng.prepare_time_embeddings([t[0]], fps, flow, B)
+        camera = vec(camera_movement_type_tensor, B) if use_camera_motion_condition else None      # reference unet.py:498-508, 538-544
+        if len(set(t)) == 1:
+            _, temb = eng.prepare_time_embeddings([t[0]], fps, flow, B, camera=camera)
+        else:       # per-sample timesteps (reference unet.py:488-521 broadcasts a (B,) tensor): one embedding row per batch element
+            _, temb = eng.prepare_time_embeddings(t, fps, flow, 1, camera=camera)
         pred = eng.forward(x, temb, B, F, H, W)
         out = eng.new(B * F, cfg.out_channels, H * W, dtype=torch.float32)
         o.nhwc_to_nchw(pred, out, N=B * F, C_=cfg.out_channels, HW=H * W, ld=pred.shape[1])

@@ -185,9 +185,7 @@ class AnimationPipeline:
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
-        unsupported = dict(use_first_frame_condition_concat=use_first_frame_condition_concat,
-                           use_camera_motion_condition=use_camera_motion_condition,
-                           use_text_encoder_2=use_text_encoder_2, eta=eta != 0.0)
+        unsupported = dict(use_text_encoder_2=use_text_encoder_2)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"AnimationPipeline on the MI355X engine: {bad} not implemented (SURVEY.md 8 scope)")
@@ -195,8 +193,16 @@ class AnimationPipeline:
         if use_first_frame_mask_condition_concat != concat_model:
             raise ValueError(f"use_first_frame_mask_condition_concat={use_first_frame_mask_condition_concat} but the UNet was built "
                              f"with use_first_frame_mask_condition_concat={concat_model} ({self.unet.engine_config.conv_in_channels} input channels)")
-        if (use_first_frame_mask_condition_concat or use_first_frame_condition) and first_image_latents is None:
-            raise ValueError("first_image_latents is required with use_first_frame_mask_condition_concat / use_first_frame_condition")
+        concat2_model = bool(getattr(self.unet.engine_config, "use_first_frame_condition_concat", False))
+        if bool(use_first_frame_condition_concat) != concat2_model:
+            raise ValueError(f"use_first_frame_condition_concat={use_first_frame_condition_concat} but the UNet was built with "
+                             f"use_first_frame_condition_concat={concat2_model} ({self.unet.engine_config.conv_in_channels} input channels)")
+        if use_camera_motion_condition and not getattr(self.unet.engine_config, "use_camera_motion_condition", False):
+            raise ValueError("use_camera_motion_condition=True needs a UNet built with use_camera_motion_condition")
+        if use_camera_motion_condition and camera_movement_type is None:
+            raise ValueError("camera_movement_type is required with use_camera_motion_condition")
+        if (use_first_frame_mask_condition_concat or use_first_frame_condition or use_first_frame_condition_concat) and first_image_latents is None:
+            raise ValueError("first_image_latents is required with use_first_frame_mask_condition_concat / use_first_frame_condition(_concat)")
         if use_first_frame_condition and use_first_frame_mask_condition_concat:
             raise ValueError("use_first_frame_condition and use_first_frame_mask_condition_concat are alternatives (reference :691-693)")
         if use_first_frame_mask_condition_concat_image_partial_mask is not None and first_image_latents is not None:
@@ -254,7 +260,9 @@ class AnimationPipeline:
                                      first_image_latents=first_image_latents, first_images_mask=mask_final,
                                      fps=as_list(fps_tensor) if use_fps_condition else None,
                                      flow=as_list(flow_control) if use_fps_condition else None, ip_tokens=ip_tokens, callback=cb,
-                                     video_scale=float(video_scale or 0.0), first_frame_condition=bool(use_first_frame_condition))
+                                     video_scale=float(video_scale or 0.0), first_frame_condition=bool(use_first_frame_condition),
+                                     eta=float(eta), generator=generator,            # stochastic DDIM (reference :672, scheduling_ddim.py:336-365)
+                                     camera=as_list(camera_movement_type) if use_camera_motion_condition else None)
         if hasattr(bar, "close"):
             bar.close()
 

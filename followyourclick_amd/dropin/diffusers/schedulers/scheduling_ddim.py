@@ -71,9 +71,7 @@ class DDIMScheduler:
              generator=None, variance_noise=None, return_dict: bool = True):
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
-        if eta != 0.0:
-            raise NotImplementedError("DDIMScheduler.step on the MI355X engine: eta > 0 (stochastic DDIM) is not implemented")
-        sa, sb, sap, sbp = self.tables.step_coefficients(int(timestep), self.num_inference_steps)
+        sa, sb, sap, sbp, sigma = self.tables.step_coefficients(int(timestep), self.num_inference_steps, float(eta))
         if self.tables.pred_type == 1:
             x0, eps = sa * sample - sb * model_output, sa * model_output + sb * sample
         elif self.tables.pred_type == 0:
@@ -82,7 +80,16 @@ class DDIMScheduler:
             x0, eps = model_output, model_output
         if self.config.clip_sample:
             x0 = x0.clamp(-1, 1)
+        if use_clipped_model_output:                     # reference scheduling_ddim.py:342-344
+            eps = (sample - sa * x0) / sb
         prev = sap * x0 + sbp * eps
+        if eta > 0:                                      # :346-363
+            if variance_noise is not None and generator is not None:
+                raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` or"
+                                 " `variance_noise` stays `None`.")
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+            prev = prev + sigma * variance_noise
         if not return_dict:
             return (prev,)
         return DDIMSchedulerOutput(prev_sample=prev, pred_original_sample=x0)

@@ -29,6 +29,7 @@ class UNet3DConfig:
     temporal_position_encoding: bool = True
     temporal_position_encoding_max_len: int = 24
     use_fps_condition: bool = True
+    use_camera_motion_condition: bool = False      # camera_motion_embedding added to the time embedding (reference unet.py:134-137, 538-544)
     use_first_frame_mask_condition_concat: bool = True
     use_first_frame_condition_concat: bool = False
     use_ip_cross_attention: bool = False

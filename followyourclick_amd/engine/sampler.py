@@ -33,7 +33,7 @@ class DDIMSampler:
     def prepare(self, text_embeddings: Tensor, num_steps: int, batch: int, guidance_scale: float,
                 fps: Optional[Sequence[float]] = None, flow: Optional[Sequence[float]] = None,
                 ip_tokens: Optional[Tensor] = None, video_scale: float = 0.0, frames: int = 0,
-                first_frame_condition: bool = False) -> dict:
+                first_frame_condition: bool = False, eta: float = 0.0, camera: Optional[Sequence[float]] = None) -> dict:
         """text_embeddings: (cfg*batch, 77, D) with the unconditional half first (reference :397)."""
         u = self.unet
         cfg_on = guidance_scale > 1.0
@@ -70,14 +70,18 @@ class DDIMSampler:
             _, temb0 = u.prepare_time_embeddings([0], None, None, 1)
             extra["temb_first"] = temb0
         u.prepare_context(text_embeddings, ip_tokens)
-        emb, temb = u.prepare_time_embeddings(ts.tolist(), dup(fps), dup(flow), beff)
-        coef = self.tables.coefficient_table(num_steps).to(u.device)
+        emb, temb = u.prepare_time_embeddings(ts.tolist(), dup(fps), dup(flow), beff, camera=dup(camera))
+        coef_host = self.tables.coefficient_table(num_steps, eta)
+        coef = coef_host.to(u.device)
+        extra["sigma"] = coef_host[:, 4].tolist()           # eta > 0: per-step std of the added noise (0 for eta = 0)
         return dict(timesteps=ts, temb=temb.reshape(num_steps, beff, -1), coef=coef, cfg=cfg_on, beff=beff,
                     guidance=float(guidance_scale), steps=num_steps, batch=batch, ctx_main=u.ctx_cache, **extra)
 
     @torch.no_grad()
-    def step(self, st: dict, i: int, latents: Tensor, first_image_latents: Optional[Tensor], mask: Optional[Tensor]) -> None:
-        """one DDIM step, latents (B,4,F,h,w) f32 updated in place"""
+    def step(self, st: dict, i: int, latents: Tensor, first_image_latents: Optional[Tensor], mask: Optional[Tensor],
+             variance_noise: Optional[Tensor] = None, use_clipped_model_output: bool = False) -> None:
+        """one DDIM step, latents (B,4,F,h,w) f32 updated in place.  variance_noise (latents' shape, f32): the noise of a stochastic
+        step (eta > 0, reference scheduling_ddim.py:346-363), scaled by the step's sigma from `prepare(eta=...)`."""
         u, o = self.unet, self.unet.ops
         B, CL, F, H, W = latents.shape
         cp = pad_channels(u.cfg.conv_in_channels)
@@ -89,7 +93,9 @@ class DDIMSampler:
             o.unet_input(latents, mask, first_image_latents, x, B=B, F=F, HW=H * W, c_latent=CL, c_pad=cp, cfg_dup=dupn,
                          mask_frames=1)
         elif u.cfg.use_first_frame_condition_concat:
-            raise NotImplementedError("use_first_frame_condition_concat (reference pipeline_animation.py:705-706) is not implemented")
+            # the reference's UNet concatenates `reference_images_latent` (the clean first-frame latents) beside EVERY frame's latents
+            # (unet.py:580-586; pipeline_animation.py:705-706 passes the plain latents); conv_in's `/ 2` lives in its packed weights
+            o.unet_input(latents, None, first_image_latents, x, B=B, F=F, HW=H * W, c_latent=CL, c_pad=cp, cfg_dup=dupn, mode=1)
         else:
             # plain latents (the 2-D Stable Diffusion first-image path, reference pipeline_stable_diffusion.py:527-528)
             n = B * F * H * W
@@ -104,14 +110,18 @@ class DDIMSampler:
             u.ctx_cache = st["ctx_main"]
         o.cfg_ddim_step(pred, latents, st["coef"][i], B=B, F=F, HW=H * W, c_latent=CL, ld=pred.shape[1], cfg=st["cfg"],
                         guidance=st["guidance"], pred_type=self.tables.pred_type, clip_sample=self.clip_sample,
-                        pred_single=single, video_scale=st.get("video_scale", 0.0))
+                        pred_single=single, video_scale=st.get("video_scale", 0.0),
+                        variance_noise=variance_noise, sigma=st["sigma"][i] if variance_noise is not None else 0.0,
+                        clipped_model_output=use_clipped_model_output)
 
     @torch.no_grad()
     def sample(self, latents: Tensor, text_embeddings: Tensor, num_steps: int, guidance_scale: float,
                first_image_latents: Optional[Tensor] = None, first_images_mask: Optional[Tensor] = None,
                fps: Optional[Sequence[float]] = None, flow: Optional[Sequence[float]] = None,
                ip_tokens: Optional[Tensor] = None, callback: Optional[Callable] = None, callback_steps: int = 1,
-               use_graph: Optional[bool] = None, video_scale: float = 0.0, first_frame_condition: bool = False) -> Tensor:
+               use_graph: Optional[bool] = None, video_scale: float = 0.0, first_frame_condition: bool = False,
+               eta: float = 0.0, generator=None, use_clipped_model_output: bool = False,
+               camera: Optional[Sequence[float]] = None) -> Tensor:
         """use_graph: replay steps 1..n-1 from one captured hipGraph (None = the FYC_HIPGRAPH environment switch, default off).
         Measured on MI355X it buys nothing: at cfg2 the loop is GPU-bound (56 ms of kernels per step) and even the 2-D
         one-frame case (13.7 ms / step, ~700 small kernels) is bound by the kernels' own execution, not by launch overhead
@@ -125,13 +135,20 @@ class DDIMSampler:
             # mask for ALL frames = clamp(first_images_mask[:, :, 0:1]) (reference :632-635)
             mask = first_images_mask.to(u.device, torch.float32)[:, :, 0].reshape(B, 1, H * W).contiguous()
         st = self.prepare(text_embeddings, num_steps, B, guidance_scale, fps, flow, ip_tokens, video_scale=video_scale, frames=F,
-                          first_frame_condition=first_frame_condition)
+                          first_frame_condition=first_frame_condition, eta=eta, camera=camera)
         ts = st["timesteps"].tolist()
         if use_graph is None:
             use_graph = os.environ.get("FYC_HIPGRAPH", "0") == "1"
+        if eta > 0:
+            use_graph = False             # the noise of every step comes from the generator: nothing to replay
         if not (use_graph and latents.is_cuda and num_steps >= 3):
             for i, t in enumerate(ts):
-                self.step(st, i, latents, first, mask)
+                noise = None
+                if eta > 0:
+                    # drawn exactly as the reference's scheduler draws it (scheduling_ddim.py:355-361): on the latents' device, in
+                    # their dtype, from the caller's generator (or the device's global one)
+                    noise = torch.randn(latents.shape, generator=generator, device=latents.device, dtype=latents.dtype)
+                self.step(st, i, latents, first, mask, variance_noise=noise, use_clipped_model_output=use_clipped_model_output)
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, latents)
             return latents

@@ -56,12 +56,16 @@ class DDIMTables:
         ratio = self.cfg.num_train_timesteps // num_inference_steps
         return (torch.arange(0, num_inference_steps, dtype=torch.int64) * ratio).flip(0) + self.cfg.steps_offset
 
-    def step_coefficients(self, t: int, num_inference_steps: int) -> List[float]:
+    def step_coefficients(self, t: int, num_inference_steps: int, eta: float = 0.0) -> List[float]:
+        """{sqrt(abar_t), sqrt(1 - abar_t), sqrt(abar_prev), sqrt(1 - abar_prev - sigma^2), sigma} with sigma = eta * sqrt(variance_t)
+        (scheduling_ddim.py:229-236 `_get_variance`, :336-349): the same f32 tensor arithmetic as the reference, eta = 0 gives sigma = 0"""
         prev_t = t - self.cfg.num_train_timesteps // num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
-        return [float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_prev ** 0.5), float((1 - a_prev) ** 0.5)]
+        variance = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+        std = eta * variance ** 0.5
+        return [float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_prev ** 0.5), float((1 - a_prev - std ** 2) ** 0.5), float(std)]
 
-    def coefficient_table(self, num_inference_steps: int) -> torch.Tensor:
+    def coefficient_table(self, num_inference_steps: int, eta: float = 0.0) -> torch.Tensor:
         ts = self.timesteps(num_inference_steps).tolist()
-        return torch.tensor([self.step_coefficients(t, num_inference_steps) for t in ts], dtype=torch.float32)
+        return torch.tensor([self.step_coefficients(t, num_inference_steps, eta) for t in ts], dtype=torch.float32)

@@ -92,7 +92,8 @@ def unet_schema(cfg: UNet3DConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     s = _S()
     boc, temb, nb = cfg.block_out_channels, cfg.time_embed_dim, len(cfg.block_out_channels)
     s.conv("conv_in", boc[0], cfg.conv_in_channels, 3)
-    for name in ["time_embedding"] + (["fps_embedding", "motion_embedding"] if cfg.use_fps_condition else []):
+    for name in (["time_embedding"] + (["camera_motion_embedding"] if cfg.use_camera_motion_condition else [])
+                 + (["fps_embedding", "motion_embedding"] if cfg.use_fps_condition else [])):
         s.lin(name + ".linear_1", temb, boc[0])
         s.lin(name + ".linear_2", temb, temb)
     out = boc[0]

@@ -87,7 +87,7 @@ class UNet3DEngine(EngineBase):
 
     # ---- once per clip ---------------------------------------------------------------------
     def prepare_time_embeddings(self, timesteps: Sequence[int], fps: Optional[Sequence[float]], flow: Optional[Sequence[float]],
-                                batch: int):
+                                batch: int, camera: Optional[Sequence[float]] = None):
         """Returns (emb [S*batch, 1280] f32, temb [S*batch, temb_total] f32); row = step*batch + b.
         emb = time_embedding(sin t) + fps_embedding(sin fps_b) + motion_embedding(sin flow_b)
         (reference unet.py:526-558); temb = time_emb_proj(SiLU(emb)) of all ResNets (resnet.py:306-307)."""
@@ -101,10 +101,16 @@ class UNet3DEngine(EngineBase):
             o.silu_f32(h, a)
             return self.lin(a, m.w2, rows, bias=m.b2, residual=residual)
 
+        def per_row(v):        # one value per batch element, repeated over the steps - or already one per row (per-sample timesteps: S = rows, batch = 1)
+            s = sinusoid_host(v, c0)
+            return s if s.shape[0] == rows else s.repeat(S, 1)
+
         emb = mlp(P.emb["time_embedding"], sinusoid_host(timesteps, c0).repeat_interleave(batch, dim=0))
+        if cfg.use_camera_motion_condition and camera is not None:       # reference unet.py:538-544: added before the fps / motion embeddings
+            emb = mlp(P.emb["camera_motion_embedding"], per_row(camera), residual=emb)
         if cfg.use_fps_condition and fps is not None:
-            emb = mlp(P.emb["fps_embedding"], sinusoid_host(fps, c0).repeat(S, 1), residual=emb)
-            emb = mlp(P.emb["motion_embedding"], sinusoid_host(flow, c0).repeat(S, 1), residual=emb)
+            emb = mlp(P.emb["fps_embedding"], per_row(fps), residual=emb)
+            emb = mlp(P.emb["motion_embedding"], per_row(flow), residual=emb)
         act = self.new(rows, emb.shape[1], dtype=torch.float32)
         o.silu_f32(emb, act)
         temb = self.lin(act, P.temb_w, rows, bias=P.temb_b)
@@ -455,8 +461,8 @@ class UNet3DEngine(EngineBase):
             temb = temb.repeat_interleave(F, dim=0)            # one row per (clip, frame)
             temb[0::F] = temb_first
             g["temb_per_frame"] = True
-        if cfg.use_first_frame_condition_concat:
-            raise NotImplementedError("use_first_frame_condition_concat (sample/2 path, reference unet.py:589-590)")
+        # (use_first_frame_condition_concat, reference unet.py:580-590: the 8-channel input is built by fyc_unet_input mode 1 and the
+        # `sample / 2` behind conv_in is folded into its packed weights, engine/weights.py)
         frames = B * F
 
         def hw(gg):         # rows of one frame = one statistics sample of every producer

@@ -372,11 +372,15 @@ def pack_unet(sd: Dict[str, Tensor], cfg: UNet3DConfig, dtype, device) -> Packed
     sd = {k: v.detach().float().cpu() for k, v in sd.items()}
     nb = len(cfg.block_out_channels)
     P = Packed(cfg=cfg, dtype=dtype)
-    P["conv_in_w"] = pack_conv3x3(sd["conv_in.weight"], dtype, device)
-    P["conv_in_b"] = f32(sd["conv_in.bias"], device)
+    # use_first_frame_condition_concat: the reference halves conv_in's output (`sample = sample / 2`, unet.py:589-590) - folded into
+    # the packed weight and bias (a power of two: exact in every storage type)
+    half = 0.5 if cfg.use_first_frame_condition_concat else 1.0
+    P["conv_in_w"] = pack_conv3x3(sd["conv_in.weight"] * half, dtype, device)
+    P["conv_in_b"] = f32(sd["conv_in.bias"] * half, device)
     # time / fps / flow embedding MLPs stay f32 (M = batch rows only; precision matters, FLOPs do not)
     emb = {}
-    for name in ["time_embedding"] + (["fps_embedding", "motion_embedding"] if cfg.use_fps_condition else []):
+    for name in (["time_embedding"] + (["camera_motion_embedding"] if cfg.use_camera_motion_condition else [])
+                 + (["fps_embedding", "motion_embedding"] if cfg.use_fps_condition else [])):
         emb[name] = Packed(w1=f32(sd[name + ".linear_1.weight"], device), b1=f32(sd[name + ".linear_1.bias"], device),
                            w2=f32(sd[name + ".linear_2.weight"], device), b2=f32(sd[name + ".linear_2.bias"], device))
     P["emb"] = emb

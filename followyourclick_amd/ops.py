@@ -431,17 +431,21 @@ class HipOps:
         self._call("fyc_cast_to_f32", a)
 
     def unet_input(self, latents: Tensor, mask: Optional[Tensor], first: Optional[Tensor], x: Tensor, *, B: int, F: int,
-                   HW: int, c_latent: int, c_pad: int, cfg_dup: int, mask_frames: int = 1) -> None:
+                   HW: int, c_latent: int, c_pad: int, cfg_dup: int, mask_frames: int = 1, mode: int = 0) -> None:
         self.ensure_init(latents.device)
         a = L.UnetInputArgs()
         a.latents, a.mask, a.first, a.x = _f32(latents, "latents"), _f32(mask, "mask"), _f32(first, "first"), _p(x)
-        a.B, a.F, a.HW, a.c_latent, a.c_pad, a.cfg_dup, a.mask_frames, a.dtype = B, F, HW, c_latent, c_pad, cfg_dup, mask_frames, _dt(x)
+        a.B, a.F, a.HW, a.c_latent, a.c_pad, a.cfg_dup, a.mask_frames, a.dtype, a.mode = B, F, HW, c_latent, c_pad, cfg_dup, mask_frames, _dt(x), mode
         self._call("fyc_unet_input", a)
 
     def cfg_ddim_step(self, pred: Tensor, latents: Tensor, coef: Tensor, *, B: int, F: int, HW: int, c_latent: int,
                       ld: int, cfg: bool, guidance: float, pred_type: int, clip_sample: bool,
-                      pred_single: Optional[Tensor] = None, video_scale: float = 0.0) -> None:
+                      pred_single: Optional[Tensor] = None, video_scale: float = 0.0, variance_noise: Optional[Tensor] = None,
+                      sigma: float = 0.0, clipped_model_output: bool = False) -> None:
         a = L.CfgDdimArgs()
+        if variance_noise is not None and variance_noise.numel() != latents.numel():
+            raise ValueError("cfg_ddim_step: variance_noise must have the latents' shape")
+        a.variance_noise, a.sigma, a.clipped_model_output = _f32(variance_noise, "variance_noise"), float(sigma), int(clipped_model_output)
         if pred_single is not None and pred_single.dtype != pred.dtype:
             raise TypeError("cfg_ddim_step: pred_single dtype differs from pred")
         a.pred_single, a.video_scale = _p(pred_single), video_scale

@@ -59,6 +59,7 @@ class UNetConfig:
     motion_attention_blocks: int = 2     # ("Temporal_Self", "Temporal_Self")
     temporal_position_encoding_max_len: int = 24
     use_fps_condition: bool = True
+    use_camera_motion_condition: bool = False   # unet.py:134-137, 538-544
     use_first_frame_mask_condition_concat: bool = True
     use_first_frame_condition_concat: bool = False
     use_ip_cross_attention: bool = False
@@ -127,11 +128,13 @@ def timestep_mlp(sd: SD, p: str, x: Tensor) -> Tensor:
 
 
 def unet_time_embedding(sd: SD, cfg: UNetConfig, t: Tensor, fps: Optional[Tensor], flow: Optional[Tensor],
-                        dtype=torch.float32) -> Tensor:
-    """emb = time_embedding(sin(t)) + fps_embedding(sin(fps)) + motion_embedding(sin(flow))
+                        dtype=torch.float32, camera: Optional[Tensor] = None) -> Tensor:
+    """emb = time_embedding(sin(t)) [+ camera_motion_embedding(sin(camera type))] + fps_embedding(sin(fps)) + motion_embedding(sin(flow))
     (unet.py:526-558)."""
     c0 = cfg.block_out_channels[0]
     emb = timestep_mlp(sd, "time_embedding", sinusoid(t, c0).to(dtype))
+    if cfg.use_camera_motion_condition and camera is not None:      # unet.py:538-544
+        emb = emb + timestep_mlp(sd, "camera_motion_embedding", sinusoid(camera, c0).to(dtype))
     if cfg.use_fps_condition and fps is not None:
         emb = emb + timestep_mlp(sd, "fps_embedding", sinusoid(fps, c0).to(dtype))
         emb = emb + timestep_mlp(sd, "motion_embedding", sinusoid(flow, c0).to(dtype))
@@ -313,7 +316,8 @@ def _has_motion(cfg: UNetConfig, res: int) -> bool:
 def unet3d_forward(sd: SD, cfg: UNetConfig, sample: Tensor, timestep: Tensor, ctx: Tensor,
                    fps: Optional[Tensor] = None, flow: Optional[Tensor] = None,
                    ip_tokens: Optional[Tensor] = None, taps: Optional[dict] = None,
-                   use_first_frame_condition: bool = False) -> Tensor:
+                   use_first_frame_condition: bool = False, camera: Optional[Tensor] = None,
+                   reference_images_latent: Optional[Tensor] = None) -> Tensor:
     """UNet3DConditionModel.forward (unet.py:422-672).
 
     sample: (B, conv_in_channels, F, h, w); timestep: scalar/(B,) int; ctx: (B, 77, D);
@@ -324,7 +328,10 @@ def unet3d_forward(sd: SD, cfg: UNetConfig, sample: Tensor, timestep: Tensor, ct
     t = timestep.reshape(-1).expand(B) if timestep.dim() <= 1 else timestep
     if use_first_frame_condition:      # unet.py:523-524: one extra embedding row for timestep 0 (the clean first frame)
         t = torch.cat([t, torch.zeros(1, dtype=t.dtype)])
-    emb = unet_time_embedding(sd, cfg, t, fps, flow, sample.dtype)
+    emb = unet_time_embedding(sd, cfg, t, fps, flow, sample.dtype, camera=camera)
+    if cfg.use_first_frame_condition_concat and reference_images_latent is not None:
+        # unet.py:580-586: the clean first-frame latents, repeated over the frames, beside the sample
+        sample = torch.cat((sample, reference_images_latent.unsqueeze(2).repeat(1, 1, sample.shape[2], 1, 1)), dim=1)
     if cfg.use_ip_cross_attention:
         ctx = torch.cat([ctx, ip_tokens], dim=1)
     g, eps = cfg.norm_num_groups, cfg.norm_eps
@@ -422,8 +429,9 @@ def ddim_timesteps(c: DDIMConfig, n: int) -> Tensor:
     return torch.arange(0, n, dtype=torch.int64).mul(ratio).flip(0) + c.steps_offset
 
 
-def ddim_step(c: DDIMConfig, abar: Tensor, n: int, model_output: Tensor, t: int, sample: Tensor) -> Tensor:
-    """DDIMScheduler.step with eta=0 (scheduling_ddim.py:254-376)."""
+def ddim_step(c: DDIMConfig, abar: Tensor, n: int, model_output: Tensor, t: int, sample: Tensor, eta: float = 0.0,
+              variance_noise: Optional[Tensor] = None, use_clipped_model_output: bool = False) -> Tensor:
+    """DDIMScheduler.step (scheduling_ddim.py:254-376); eta > 0 needs the caller's `variance_noise` (:346-363)."""
     prev_t = t - c.num_train_timesteps // n
     a_t = abar[t]
     a_prev = abar[prev_t] if prev_t >= 0 else (torch.tensor(1.0) if c.set_alpha_to_one else abar[0])
@@ -440,7 +448,14 @@ def ddim_step(c: DDIMConfig, abar: Tensor, n: int, model_output: Tensor, t: int,
         raise ValueError(c.prediction_type)
     if c.clip_sample:
         x0 = x0.clamp(-1, 1)
-    return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+    variance = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)          # _get_variance, :229-236
+    std = eta * variance ** 0.5
+    if use_clipped_model_output:                                         # :342-344
+        eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+    prev = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps
+    if eta > 0:
+        prev = prev + variance ** 0.5 * eta * variance_noise
+    return prev
 
 
 # --------------------------------------------------------------------------------------
@@ -467,7 +482,8 @@ def denoise(sd: SD, cfg: UNetConfig, sched: DDIMConfig, latents: Tensor, text_em
             guidance_scale: float, first_image_latents: Optional[Tensor] = None,
             first_images_mask: Optional[Tensor] = None, fps: Optional[Tensor] = None,
             flow: Optional[Tensor] = None, ip_tokens: Optional[Tensor] = None,
-            callback=None, video_scale: float = 0.0, use_first_frame_condition: bool = False) -> Tensor:
+            callback=None, video_scale: float = 0.0, use_first_frame_condition: bool = False, eta: float = 0.0,
+            variance_noises=None, camera: Optional[Tensor] = None) -> Tensor:
     """The DDIM loop of AnimationPipeline.__call__ with use_first_frame_mask_condition_concat
     and classifier-free guidance: text_embeddings is cat[uncond, cond] (2B,77,D)
     (pipeline_animation.py:397, 690-773)."""
@@ -481,12 +497,13 @@ def denoise(sd: SD, cfg: UNetConfig, sched: DDIMConfig, latents: Tensor, text_em
         elif cfg.use_first_frame_mask_condition_concat:
             x = build_model_input(latents, first_image_latents, first_images_mask)
         else:
-            x = latents
+            x = latents                  # (use_first_frame_condition_concat: the UNet concatenates reference_images_latent itself)
         if cfg_on:
             x = torch.cat([x] * 2)
         dup = (lambda v: torch.cat([v] * 2) if (cfg_on and v is not None) else v)
         pred = unet3d_forward(sd, cfg, x, torch.tensor(t), text_embeddings, dup(fps), dup(flow), ip_tokens,
-                              use_first_frame_condition=use_first_frame_condition)
+                              use_first_frame_condition=use_first_frame_condition, camera=dup(camera),
+                              reference_images_latent=dup(first_image_latents) if cfg.use_first_frame_condition_concat else None)
         single = None
         if video_scale > 0:
             # per-frame prediction (pipeline_animation.py:738-752): frames as one-frame clips; the text batch is
@@ -502,7 +519,8 @@ def denoise(sd: SD, cfg: UNetConfig, sched: DDIMConfig, latents: Tensor, text_em
                 pred = single + video_scale * (u - single) + guidance_scale * (c - u)
             else:
                 pred = u + guidance_scale * (c - u)
-        latents = ddim_step(sched, abar, num_steps, pred, t, latents)
+        latents = ddim_step(sched, abar, num_steps, pred, t, latents, eta=eta,
+                            variance_noise=None if variance_noises is None else variance_noises[i])
         if callback is not None:
             callback(i, t, latents)
     return latents

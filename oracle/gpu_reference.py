@@ -41,11 +41,12 @@ def install_sdpa_xformers():
     ops.__spec__ = _M.ModuleSpec("xformers.ops", None)
 
     def memory_efficient_attention(query, key, value, attn_bias=None, p=0.0, scale=None, op=None):
-        # f32 runs fall back to SDPA's materialising "math" path: cut the (batch x heads) axis so that one slice's scores stay below
-        # ~8 GiB (F = 32 at 96x96 would otherwise ask for 174 GB) - the same per-(batch, head) arithmetic
+        # SDPA may take its materialising "math" path: cut the (batch x heads) axis so that one slice's scores stay below ~8 GiB
+        # (F = 32 at 96x96 would otherwise ask for 174 GB in f32) - the same per-(batch, head) arithmetic
+        # (16-bit inputs as well: on this ROCm build SDPA takes the materialising path for d = 40 at 9 216 tokens too - 162 GiB asked for)
         n = query.shape[0]
-        per = query.shape[-2] * key.shape[-2] * 4 * (2 if query.dtype == torch.float32 else 1)
-        step = n if query.dtype != torch.float32 else max(1, min(n, (8 << 30) // max(per, 1)))
+        per = query.shape[-2] * key.shape[-2] * query.element_size() * 2
+        step = max(1, min(n, (8 << 30) // max(per, 1)))
         if step >= n:
             return F.scaled_dot_product_attention(query, key, value, attn_mask=attn_bias, dropout_p=p, scale=scale)
         out = [F.scaled_dot_product_attention(query[i:i + step], key[i:i + step], value[i:i + step],
@@ -163,8 +164,57 @@ def time_reference(frames=16, size=512, ddim_steps=25, dtype="bf16", attention="
                        f"the guidance / scheduler arithmetic between forwards (< 0.1 % of a step) is not included")
 
 
+def dump(what, out):
+    """tests/test_reference_gpu.py runs the reference in a SUBPROCESS (`python -m oracle.gpu_reference --dump <what> --out file.pt`):
+    the reference's `animatediff` / `diffusers` packages and the product's drop-in packages of the same names cannot live in one
+    interpreter.  Inputs are re-derived from the goldens' seeds on both sides; only the reference's outputs cross the file."""
+    import os
+    import numpy as np
+    from . import functional as Fn
+    from . import weights as W
+    dev = torch.device("cuda", 0)
+    golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    t0 = time.time()
+    if what == "small":          # the unet_full_small_fwd inputs in f32 and under the real bf16 / f16 autocast
+        g = np.load(os.path.join(golden, "unet_full_small_fwd.npz"))
+        cfg, unet = build_reference_unet(dev, attention="sdpa")
+        inp = W.seeded_inputs(Fn.UNetConfig(), 1, int(g["frames"]), int(g["h"]), int(g["w"]), seed=int(g["input_seed"]))
+        x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+        res = {name: forward(unet, x9, int(g["timestep"]), inp["text"], torch.from_numpy(g["fps"]), torch.from_numpy(g["flow"]), ac).cpu()
+               for name, ac in (("f32", None), ("bf16", torch.bfloat16), ("f16", torch.float16))}
+    else:
+        frames, lat, num_steps, run_steps, seed, ocfg, mask, use_ip = TRAJECTORIES[what]()
+        _, unet = build_reference_unet(dev, attention="sdpa", ocfg=ocfg)
+        inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
+        res = {name: reference_trajectory(unet, inp, num_steps, run_steps, ac, mask=mask, ip_tokens=inp["ip_tokens"] if use_ip else None)
+               for name, ac in (("f32", None), ("bf16", torch.bfloat16))}
+    res["seconds"] = time.time() - t0
+    torch.save(res, out)
+
+
+def rectangle_mask(lat):
+    mask = torch.zeros(1, 1, 1, lat, lat)
+    mask[..., lat // 4: 3 * lat // 4, lat // 4: 3 * lat // 4] = 1.0          # the centred rectangle of SURVEY.md 8d (a SAM box stand-in)
+    return mask
+
+
+def _traj_cfg3():
+    from . import functional as Fn      # BASELINE configs[3]: 32 frames at 768x768, the first 2 steps of the 50-step schedule
+    return 32, 96, 50, 2, 64, Fn.UNetConfig(temporal_position_encoding_max_len=32), None, False
+
+
+def _traj_cfg4ip():
+    from . import functional as Fn      # BASELINE configs[4]: 16 frames at 512x512 + 16 IP tokens + region mask, the first 2 of 25 steps
+    return 16, 64, 25, 2, 65, Fn.UNetConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7), rectangle_mask(64), True
+
+
+TRAJECTORIES = {"cfg3": _traj_cfg3, "cfg4ip": _traj_cfg4ip}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--dump", default=None, choices=["small", "cfg3", "cfg4ip"])
+    ap.add_argument("--out", default=None)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=25)
@@ -173,5 +223,8 @@ if __name__ == "__main__":
     ap.add_argument("--timed", type=int, default=2)
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
+    if a.dump:
+        dump(a.dump, a.out)
+        sys.exit(0)
     r = time_reference(a.frames, a.size, a.ddim_steps, a.dtype, a.attention, a.timed)
     print("GPU_REFERENCE " + json.dumps(r) if a.json else r)

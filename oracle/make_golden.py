@@ -33,15 +33,22 @@ MM_KW = dict(num_attention_heads=8, num_transformer_block=1, attention_block_typ
 
 def ref_unet(cfg: Fn.UNetConfig):
     from animatediff.models.unet import UNet3DConditionModel
+    extra = {}
+    if cfg.use_first_frame_condition_concat:
+        extra["use_first_frame_condition_concat"] = True
+    if cfg.use_camera_motion_condition:
+        extra["use_camera_motion_condition"] = True
     return UNet3DConditionModel(
         sample_size=cfg.sample_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
         block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
         cross_attention_dim=cfg.cross_attention_dim, attention_head_dim=cfg.attention_head_dim,
         norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps, act_fn="silu", use_linear_projection=False,
         use_motion_module=True, motion_module_resolutions=(1, 2, 4, 8), unet_use_cross_frame_attention=False,
-        unet_use_temporal_attention=False, use_fps_condition=True, use_first_frame_mask_condition_concat=True,
+        unet_use_temporal_attention=False, use_fps_condition=True,
+        use_first_frame_mask_condition_concat=cfg.use_first_frame_mask_condition_concat and not cfg.use_first_frame_condition_concat,
         motion_module_type="Vanilla", motion_module_kwargs=dict(MM_KW, temporal_position_encoding_max_len=cfg.temporal_position_encoding_max_len),
-        use_ip_cross_attention=cfg.use_ip_cross_attention, num_tokens=cfg.ip_num_tokens, scale=cfg.ip_scale)
+        use_ip_cross_attention=cfg.use_ip_cross_attention, num_tokens=cfg.ip_num_tokens, scale=cfg.ip_scale,
+        **extra)
 
 
 def ref_vae(vcfg: Fn.VAEConfig):

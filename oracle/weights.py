@@ -104,7 +104,8 @@ def unet_state_shapes(cfg: UNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     temb = cfg.time_embed_dim
     nb = len(boc)
     _conv(s, "conv_in", boc[0], cfg.conv_in_channels, 3)
-    for name in ["time_embedding"] + (["fps_embedding", "motion_embedding"] if cfg.use_fps_condition else []):
+    for name in (["time_embedding"] + (["camera_motion_embedding"] if cfg.use_camera_motion_condition else [])
+                 + (["fps_embedding", "motion_embedding"] if cfg.use_fps_condition else [])):
         _lin(s, name + ".linear_1", temb, boc[0])
         _lin(s, name + ".linear_2", temb, temb)
     out = boc[0]

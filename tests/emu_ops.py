@@ -512,10 +512,16 @@ class EmuOps:
     def cast_to_f32(self, x, y, *, rows, cols, ld):
         _flat(y)[: rows * cols].reshape(rows, cols).copy_(_flat(x)[: rows * ld].reshape(rows, ld)[:, :cols].float())
 
-    def unet_input(self, latents, mask, first, x, *, B, F, HW, c_latent, c_pad, cfg_dup, mask_frames=1):
+    def unet_input(self, latents, mask, first, x, *, B, F, HW, c_latent, c_pad, cfg_dup, mask_frames=1, mode=0):
         lat = latents.reshape(B, c_latent, F, HW)
         out = torch.zeros(B, F, HW, c_pad)
         out[..., :c_latent] = lat.permute(0, 2, 3, 1)
+        if mode == 1:      # use_first_frame_condition_concat (reference unet.py:580-586): first-frame latents beside every frame
+            if first is not None:
+                out[..., c_latent: 2 * c_latent] = first.reshape(B, 1, c_latent, HW).permute(0, 1, 3, 2)
+            out = torch.cat([out] * cfg_dup, dim=0)
+            _flat(x)[: out.numel()].reshape(out.shape).copy_(out.to(x.dtype))
+            return
         if mask is not None:
             m = mask.reshape(B, mask_frames, HW).clamp(0, 1)
             out[..., c_latent] = m if mask_frames > 1 else m.expand(B, F, HW)
@@ -527,7 +533,7 @@ class EmuOps:
         _flat(x)[: out.numel()].reshape(out.shape).copy_(out.to(x.dtype))
 
     def cfg_ddim_step(self, pred, latents, coef, *, B, F, HW, c_latent, ld, cfg, guidance, pred_type, clip_sample,
-                      pred_single=None, video_scale=0.0):
+                      pred_single=None, video_scale=0.0, variance_noise=None, sigma=0.0, clipped_model_output=False):
         n = (2 if cfg else 1) * B * F * HW
         p = _flat(pred)[: n * ld].reshape(-1, B, F, HW, ld)[..., :c_latent].float()
         v = p[0] + guidance * (p[1] - p[0]) if cfg else p[0]
@@ -545,7 +551,12 @@ class EmuOps:
             x0, eps = v, v
         if clip_sample:
             x0 = x0.clamp(-1, 1)
-        x.copy_(sap * x0 + sbp * eps)
+        if clipped_model_output:                                   # scheduling_ddim.py:342-344
+            eps = (x - sa * x0) / sb
+        nx = sap * x0 + sbp * eps
+        if variance_noise is not None:                             # eta > 0 (:346-363)
+            nx = nx + sigma * variance_noise.reshape(B, c_latent, F, HW).float()
+        x.copy_(nx)
 
     def nchw_to_nhwc(self, z, x, *, N, C_, HW, c_pad, scale):
         out = torch.zeros(N, HW, c_pad)

@@ -18,13 +18,14 @@ def test_bench_under_torch_distributed_run_on_one_gpu():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29781",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--frames", "2", "--size", "64", "--ddim-steps", "2",
-           "--no-cpu-baseline", "--no-roofline"]
+           "--no-cpu-baseline", "--no-roofline", "--no-gpu-reference"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["data"] == "synthetic"
+    assert d["rccl_ranks"] == 1 and d["collective_backend"] == "nccl"       # the all-reduce of ones went through RCCL
     # the packed weights went through dist.broadcast on the nccl backend (bytes moved > 0 only with a live process group)
     assert "weight broadcast 0.00 GiB" not in d["config"]["parallelism"], d["config"]["parallelism"]
 

@@ -118,8 +118,11 @@ def test_pipeline_argument_errors(dropin):
     with pytest.raises(ValueError, match="Unexpected latents shape"):
         pipe("x", video_length=4, height=64, width=64, latents=torch.zeros(1, 4, 3, 8, 8), use_first_frame_mask_condition_concat=True,
              first_image_latents=torch.zeros(1, 4, 8, 8))
-    with pytest.raises(NotImplementedError):
-        pipe("x", video_length=4, height=64, width=64, use_first_frame_condition_concat=True)
+    with pytest.raises(ValueError, match="built"):        # ... nor the 8-channel first-frame concat (supported since round 5 on a model built for it)
+        pipe("x", video_length=4, height=64, width=64, use_first_frame_condition_concat=True, first_image_latents=torch.zeros(1, 4, 8, 8))
+    with pytest.raises(ValueError, match="use_camera_motion_condition"):
+        pipe("x", video_length=4, height=64, width=64, use_first_frame_mask_condition_concat=True, first_image_latents=torch.zeros(1, 4, 8, 8),
+             use_camera_motion_condition=True, camera_movement_type=torch.tensor([1]))
     with pytest.raises(ValueError, match="first_image_latents is required"):
         pipe("x", video_length=4, height=64, width=64, use_first_frame_mask_condition_concat=True)
     with pytest.raises(ValueError, match="built"):        # a 9-channel (concat) UNet cannot run the 4-channel first-frame mode

@@ -84,6 +84,9 @@ def test_full_width_forward_vs_reference(golden_dir, engines):
             assert r16 < BF16_VS_BF16 * drift, (r16, drift)
 
 
+@pytest.mark.skipif(os.environ.get("FYC_SLOW_TESTS") != "1", reason="40-50 s, most of it the CPU oracle inside the test; superseded in the default run by "
+                    "tests/test_reference_gpu.py::test_cfg4_full_shape_ip_trajectory_vs_device_reference (the REAL reference's deployed IP branch on the chip, "
+                    "multi-step, full shape): FYC_SLOW_TESTS=1")
 def test_full_width_ip_adapter_forward_vs_oracle(golden_dir):
     """BASELINE configs[4] (16 IP tokens) at SD-1.5 widths.  The reference's CPU path runs attn2 at the IP weight as softmax
     temperature (SURVEY headline 6), the deployed xformers path does not: tests/test_oracle_golden.py pins the oracle WITH that
@@ -263,6 +266,9 @@ def test_cfg4_full_shape_forward_vs_reference(golden_dir, full_sd):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.skipif(os.environ.get("FYC_SLOW_TESTS") != "1", reason="40-50 s, most of it the CPU oracle inside the test; superseded in the default run by "
+                    "tests/test_reference_gpu.py::test_cfg4_full_shape_ip_trajectory_vs_device_reference (the REAL reference's deployed IP branch on the chip, "
+                    "multi-step, full shape): FYC_SLOW_TESTS=1")
 def test_cfg5_full_shape_forward_vs_oracle(golden_dir):
     """BASELINE configs[4] at its real shape (VERDICT r3 missing 3): one CFG-pair forward at 16 frames on a 64x64 latent with 16 IP
     tokens, the rectangle region mask and the first-frame latent concat (pipeline_animation.py:676-680, 716-723; animatediff/models/
