@@ -102,7 +102,7 @@ def test_cfg5_ip_mask_trajectory_full_width(golden_dir):
     cfg_q = Fn.UNetConfig(ip_reference_cpu_scale_quirk=True, **kw)
     sd = W.make_weights(W.unet_state_shapes(cfg_q), int(g["weight_seed"]))
     inp = W.seeded_inputs(cfg_q, 1, F, lat, lat, seed=int(g["input_seed"]))
-    for cfg, key, tol in ((cfg_q, "ref_f32", 2e-4), (Fn.UNetConfig(**kw), "oracle_noquirk", 1e-6)):
+    for cfg, key, tol in ((cfg_q, "ref_f32", 2e-4), (Fn.UNetConfig(**kw), "oracle_noquirk", 1e-5)):      # (the oracle against its own stored run: 0 with the thread count of the run that stored it, ~2e-6 with another - oneDNN splits reductions by thread count)
         traj = {}
         with torch.no_grad():
             Fn.denoise(sd, cfg, Fn.DDIMConfig(), inp["latents"].clone(), g["text_embeddings"], steps, 8.0, inp["first_image_latents"], g["first_images_mask"],
