@@ -179,7 +179,9 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.fyc_version.restype = C.c_int
     ab_build = bool(os.environ.get("FYC_LIB_PATH"))      # an older library for A/B timing (tools/): newer entry points may be absent
-    if lib.fyc_version() // 100 != FYC_VERSION // 100 and not ab_build:
+    # (the whole number, not only the major: minor 2 appended fields to two argument structs - an older library would ignore them
+    # silently, a newer one would read past a shorter struct)
+    if lib.fyc_version() != FYC_VERSION and not ab_build:
         raise FycError(f"{LIB_PATH} reports ABI version {lib.fyc_version()}, this binding was written against {FYC_VERSION}: argument structs differ "
                        "between major versions - rebuild the library (`python -m followyourclick_amd._build`)")
     lib.fyc_last_error.restype = C.c_char_p
