@@ -38,12 +38,20 @@ AGPR_SOURCES = {"ff_block.hip", "panel_linear.hip", "temporal_block_rr.hip"}
 NO_SLP_SOURCES = set(filter(None, os.environ.get("FYC_NO_SLP", "ff_block.hip").split(",")))
 
 
+# attention: no NaN ever enters the softmax (masked keys are -inf, scores are finite products of finite operands), and hipcc otherwise puts an
+# sNaN-quieting `v_max_f32 x, x, x` in front of every running-maximum operand - 16 instructions per 64-key tile in a loop that is bound by
+# instruction issue (profiles/r05_attention_pmc.txt)
+NO_NAN_SOURCES = {s for s in SOURCES if s.startswith("attention")}
+
+
 def _flags(src: str):
     fl = FLAGS
     if src in AGPR_SOURCES:
         fl = [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form=1")]
     if src in NO_SLP_SOURCES:
         fl = fl + ["-fno-slp-vectorize"]
+    if src in NO_NAN_SOURCES and os.environ.get("FYC_ATTN_HONOR_NANS") != "1":
+        fl = fl + ["-fno-honor-nans"]
     return fl + EXTRA
 
 

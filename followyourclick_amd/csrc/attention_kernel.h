@@ -79,6 +79,41 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifndef FYC_ATTN_BUILTIN_ISSUE
+// The (up to) four exec-masked DMAs of a full K / V^T tile as ONE statement: the lane masks are computed once per kernel (SGPR pairs), a DMA
+// whose mask is empty in this wave is branched over (so that the counted vmcnt waits stay exact), M0 and EXEC leave as they came.  The
+// compiler's form - v_cmp + s_and_saveexec + s_cbranch + 64-bit address add + s_mov m0 + s_nop + DMA + s_or exec per DMA - is ~50 instructions
+// per tile, ~35 of them SALU, in a loop that is bound by instruction issue (profiles/r05_attention_pmc.txt); this is 24.  Measured
+// (profiles/r05_attention_instruction_diet_ab.txt, d = 40, N = 4096): 665 -> 693 TFLOP/s without the s_setprio pairs and the sNaN-quieting
+// maxima, -> 708-717 with this statement.  -DFYC_ATTN_BUILTIN_ISSUE rebuilds the compiler's form.
+__device__ __forceinline__ void dma4_masked(unsigned long long m0_, unsigned long long m1_, unsigned long long m2_, unsigned long long m3_,
+                                            unsigned o0, unsigned o1, unsigned o2, unsigned o3,
+                                            const char* b0, const char* b1, const char* b2, const char* b3,
+                                            unsigned l0, unsigned l1, unsigned l2, unsigned l3) {
+  unsigned keep_m0;
+  unsigned long long keep_exec;
+  asm volatile("s_mov_b32 %[km0], m0\n\ts_mov_b64 %[kex], exec\n\t"
+               "s_mov_b64 exec, %[ma]\n\ts_cbranch_execz 1f\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oa], %[ba]\n"
+               "1:\n\ts_mov_b64 exec, %[mb]\n\ts_cbranch_execz 2f\n\ts_mov_b32 m0, %[lb]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ob], %[bb]\n"
+               "2:\n\ts_mov_b64 exec, %[mc]\n\ts_cbranch_execz 3f\n\ts_mov_b32 m0, %[lc]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oc], %[bc]\n"
+               "3:\n\ts_mov_b64 exec, %[md]\n\ts_cbranch_execz 4f\n\ts_mov_b32 m0, %[ld]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[od], %[bd]\n"
+               "4:\n\ts_mov_b64 exec, %[kex]\n\ts_mov_b32 m0, %[km0]"
+               : [km0] "=&s"(keep_m0), [kex] "=&s"(keep_exec)
+               : [ma] "s"(m0_), [mb] "s"(m1_), [mc] "s"(m2_), [md] "s"(m3_), [oa] "v"(o0), [ob] "v"(o1), [oc] "v"(o2), [od] "v"(o3),
+                 [ba] "s"(b0), [bb] "s"(b1), [bc] "s"(b2), [bd] "s"(b3), [la] "s"(l0), [lb] "s"(l1), [lc] "s"(l2), [ld] "s"(l3)
+               : "memory");
+}
+#endif
+
+// Round 5: the loop is bound by instruction ISSUE (profiles/r05_attention_pmc.txt: 150 instructions per 21 MFMAs, three waves per SIMD whose
+// issue-active time adds up to the kernel's duration), so instructions that only re-order work between the waves of a SIMD are pure cost:
+// the s_setprio pairs around the MFMA groups (8 per 64-key tile) are compiled in only with -DFYC_ATTN_SETPRIO.
+#ifdef FYC_ATTN_SETPRIO
+#define FYC_ATTN_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define FYC_ATTN_PRIO(x) do { } while (0)
+#endif
+
 constexpr float RESCALE_THR = 6.0f;   // log2 units: probabilities stay <= 64 between moves of the running max
 
 // max over the 4 lane quads that share a query column: xor 16 inside each 32-lane half (ds_swizzle bit mode, no LDS
@@ -158,6 +193,16 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
     my_loads += __builtin_amdgcn_ballot_w64(v_off[it] != NODATA) != 0 ? 1 : 0;
   }
   my_loads = __builtin_amdgcn_readfirstlane(my_loads);
+#ifndef FYC_ATTN_BUILTIN_ISSUE
+  unsigned long long dmask[4] = {0ull, 0ull, 0ull, 0ull};      // data lanes of the (K_IT + V_IT <= 4) DMAs of a full tile, this wave
+  if (K_IT + V_IT <= 4) {
+#pragma unroll
+    for (int it = 0; it < K_IT; ++it) dmask[it] = __builtin_amdgcn_ballot_w64(k_off[it] != NODATA);
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) dmask[K_IT + it] = __builtin_amdgcn_ballot_w64(v_off[it] != NODATA);
+  }
+  const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#endif
   char* const offs_lds = smem + NS * STAGE + tid * 16;
   if (OFFS_IN_LDS) {
     u32x4 o4 = {NODATA, NODATA, NODATA, NODATA};
@@ -187,6 +232,16 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
     char* sV = sK + K_BYTES;
     const char* kb = reinterpret_cast<const char*>(K) + (long long)tile * (KB * 2) * p.d;
     const char* vb = reinterpret_cast<const char*>(VT) + (long long)tile * (KB * 2);
+#ifndef FYC_ATTN_BUILTIN_ISSUE
+    if constexpr (OFFS_IN_LDS) {
+      const u32x4 o4 = *reinterpret_cast<const u32x4*>(offs_lds);
+      const unsigned lk = lds_ring + stage * STAGE + wave * 1024, lv = lk + K_BYTES;
+      auto base = [&](int i) { return i < K_IT ? kb : vb; };
+      auto ldst = [&](int i) { return i < K_IT ? lk + i * 4096 : lv + (i - K_IT) * 4096; };
+      dma4_masked(dmask[0], dmask[1], dmask[2], dmask[3], o4[0], o4[1], o4[2], o4[3], base(0), base(1), base(2), base(3), ldst(0), ldst(1), ldst(2), ldst(3));
+      return;
+    }
+#endif
     unsigned ko[K_IT], vo[V_IT];
     if (OFFS_IN_LDS) {
       const u32x4 o4 = *reinterpret_cast<const u32x4*>(offs_lds);
@@ -335,7 +390,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
           kt4[t] = *reinterpret_cast<const s16x4*>(kr[t] + (KXOR ? (chunk ^ (krow & 7)) : chunk) * 16 + (g & 1) * 8);
         }
       }
-      __builtin_amdgcn_s_setprio(1);
+      FYC_ATTN_PRIO(1);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -358,7 +413,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) s[t][qt] = AttnMma<T>::k32(kf[ks], qf[qt][ks], s[t][qt]);
       }
-      __builtin_amdgcn_s_setprio(0);
+      FYC_ATTN_PRIO(0);
     };
     auto softmax_pv = [&](int kb, f32x4 (&s)[2][QT], f32x4 (&sn)[2][QT], bool has_next) {
       // ---- online softmax; lane holds keys kb*32 + 8g + 4t + r of query r16.  MSUB: s already is score - m_run.
@@ -442,7 +497,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
         pf[qt] = __builtin_bit_cast(Frag, pk);
       }
       // ---- O^T += V^T P^T  (row d of V^T is all ones: O^T[d] accumulates the row sums)
-      __builtin_amdgcn_s_setprio(1);
+      FYC_ATTN_PRIO(1);
 #pragma unroll
       for (int dv = 0; dv < DVT; ++dv) {
         const int vrow = dv * 16 + r16;
@@ -451,7 +506,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][dv] = AttnMma<T>::k32(vf, pf[qt], o[qt][dv]);
       }
-      __builtin_amdgcn_s_setprio(0);
+      FYC_ATTN_PRIO(0);
     };
     const int nb = (tile * KB + 32 < p.n_k) ? 2 : 1;      // 32-key blocks of this tile that hold keys (uniform)
     f32x4 s0[2][QT], s1[2][QT];

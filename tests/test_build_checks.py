@@ -112,3 +112,33 @@ __global__ void plain(const float* in, float* out) {          // the attention k
     if combined:
         pytest.skip("this hipcc compiles the plain fmaxf form correctly: the asm barrier in swap32_max / swap16_max is no longer needed")
     # (hipcc 7.2.0: the plain form stores the swap's first result unreduced - the defect the helpers exist for)
+
+
+def test_attention_issue_statement_restores_m0_and_exec(tmp_path):
+    """round 5: the d <= 48 attention kernels issue the DMAs of a full K / V^T tile from ONE asm statement that rewrites EXEC (precomputed lane
+    masks) and M0 (LDS destination).  Both are compiler-owned: the statement must save them first and restore them last, every masked DMA must
+    sit behind its `s_cbranch_execz` (an instruction with an empty mask would not count in vmcnt and break the counted waits), and the
+    sNaN-quieting `v_max_f32 x, x, x` the no-NaN build flag exists to remove must be gone from the loop."""
+    asm = _device_asm("attention_small.hip", tmp_path)
+    kernels = {k: v for k, v in _kernel_bodies(asm).items() if "fyc_attn_kernel" in k}
+    assert kernels
+    checked = 0
+    for name, body in kernels.items():
+        for stmt in re.findall(r";;#ASMSTART(.*?);;#ASMEND", body, flags=re.S):
+            if "global_load_lds" not in stmt or "s_mov_b64 exec" not in stmt:
+                continue
+            lines = [l.strip() for l in stmt.strip().split("\n") if l.strip()]
+            m0 = re.match(r"s_mov_b32 (s\d+), m0", lines[0])
+            ex = re.match(r"s_mov_b64 (s\[\d+:\d+\]), exec", lines[1])
+            assert m0 and ex, f"{name}: the statement does not start by saving M0 and EXEC:\n{stmt}"
+            assert lines[-2] == f"s_mov_b64 exec, {ex.group(1)}" and lines[-1] == f"s_mov_b32 m0, {m0.group(1)}", f"{name}: M0 / EXEC not restored:\n{stmt}"
+            dmas = [i for i, l in enumerate(lines) if l.startswith("global_load_lds_dwordx4")]
+            assert len(dmas) == 4
+            for i in dmas:
+                assert lines[i - 1] == "s_nop 0" and lines[i - 2].startswith("s_mov_b32 m0,") and lines[i - 3].startswith("s_cbranch_execz") \
+                    and lines[i - 4].startswith("s_mov_b64 exec,"), f"{name}: DMA not behind mask / branch / M0 / wait state:\n{stmt}"
+            checked += 1
+        canon = re.findall(r"v_max_f32_e32 (v\d+), (v\d+), (v\d+)", body)
+        assert not [c for c in canon if c[1] == c[2]], f"{name}: sNaN-quieting v_max_f32 x, x, x is back (is -fno-honor-nans still on the attention sources?)"
+        assert "s_setprio" not in body, f"{name}: s_setprio in an issue-bound loop (-DFYC_ATTN_SETPRIO builds it)"
+    assert checked >= len(kernels), (checked, len(kernels))      # at least one such statement per kernel (prologue + loop)
