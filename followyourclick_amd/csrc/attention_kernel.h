@@ -25,6 +25,8 @@
 //   * the running max is only moved when a score exceeds it by more than RESCALE_THR (p stays <= 2^THR), checked with
 //     a wave-uniform ballot: the O^T rescale runs in the first tiles only.
 #pragma once
+#include <type_traits>
+
 #include "fyc_common.h"
 
 namespace fyca {
@@ -126,7 +128,7 @@ __device__ __forceinline__ float quad_max(float mx) {
 // DP16: padded head dim / 16 (K-dim of QK^T).  DVT: 16-row blocks of O^T = d/16 + 1 (the extra row at index d is l).
 // DVT == DP16 <=> d % 16 == 8: index d is a free padding slot of the head dim, used for the in-MFMA max subtraction.
 template <typename T, int DP16, int DVT, int QT>
-__global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
+__global__ void __launch_bounds__(256, (DP16 == 3 && DVT == 3 && QT == 3) ? 3 : 1) fyc_attn_kernel(const AttnP p) {   // (d = 40, the 5-ms shape: held to the 168 registers of three waves per SIMD)
   typedef typename Pair16<T>::Vec8 Frag;
   const unsigned short* const fyc_ones = ones_table<T>();
   constexpr int KS = DP16 / 2;           // full 32-wide k-steps
@@ -359,14 +361,23 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
   bool started = false;   // the first key block always fixes the running max (scores may sit anywhere)
 
   int st_c = 0, st_i = (ntiles > 1) ? 2 : 1;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    wait_dyn(tile + 1 < ntiles ? loads_of(tile + 1) : 0);      // tile landed; the next one may stay in flight
+  // One tile of the key loop.  STEADY (round 5, the issue-bound loop's instruction diet): tile + 2 is a FULL tile - so is tile + 1, nothing is
+  // ragged, both 32-key blocks hold keys - and every per-tile question the general body asks (is there a tile to issue, which issue path, is
+  // this the ragged tile, one block or two) is answered at compile time: the steady-state loop below carries none of those compares / branches.
+  auto tile_body = [&](const int tile, auto steady_c) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady_c)::value;
+    // tile landed; the next one may stay in flight.  (Steady state: most waves issue all LOADS instructions of a tile - one compare instead of
+    // the 13-way switch of wait_dyn, whose compare tree costs ~8 scalar instructions per tile)
+    if (STEADY && my_loads == LOADS) wait_vmcnt<LOADS>();
+    else if (STEADY) wait_dyn(my_loads);
+    else wait_dyn(tile + 1 < ntiles ? loads_of(tile + 1) : 0);
     __builtin_amdgcn_s_barrier();
-    if (tile + 2 < ntiles) { issue(tile + 2, st_i); st_i = (st_i + 1 == NS) ? 0 : st_i + 1; }
+    if (STEADY) { issue_full(tile + 2, st_i); st_i = (st_i + 1 == NS) ? 0 : st_i + 1; }
+    else if (tile + 2 < ntiles) { issue(tile + 2, st_i); st_i = (st_i + 1 == NS) ? 0 : st_i + 1; }
     const char* sK = smem + st_c * STAGE;
     const char* sV = sK + K_BYTES;
     st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
-    const bool tail = (tile * KB + KB > p.n_k);
+    const bool tail = STEADY ? false : (tile * KB + KB > p.n_k);
     // Two 32-key blocks per tile, software-pipelined inside the wave: both blocks' QK^T MFMAs are issued before the first
     // block's softmax, so the matrix pipe works on block 1's scores while the VALU does block 0's exponentials, and block 0's
     // PV MFMAs run under block 1's softmax (a wave issues in order: without this its MFMA and VALU phases simply add up -
@@ -508,7 +519,7 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
       }
       FYC_ATTN_PRIO(0);
     };
-    const int nb = (tile * KB + 32 < p.n_k) ? 2 : 1;      // 32-key blocks of this tile that hold keys (uniform)
+    const int nb = STEADY ? 2 : ((tile * KB + 32 < p.n_k) ? 2 : 1);      // 32-key blocks of this tile that hold keys (uniform)
     f32x4 s0[2][QT], s1[2][QT];
     if constexpr (PIPE) {
       qk(0, s0);
@@ -520,7 +531,13 @@ __global__ void __launch_bounds__(256) fyc_attn_kernel(const AttnP p) {
       softmax_pv(0, s0, s1, false);
       if (nb > 1) { qk(1, s0); softmax_pv(1, s0, s1, false); }
     }
-  }
+  };
+  const int n_steady = nfull > 2 ? nfull - 2 : 0;          // tiles t with t + 2 < nfull
+  int tile = 0;
+#ifndef FYC_ATTN_ONE_LOOP
+  for (; tile < n_steady; ++tile) tile_body(tile, std::true_type());
+#endif
+  for (; tile < ntiles; ++tile) tile_body(tile, std::false_type());
 
   // ---- epilogue: lane holds O[query r16][dv*16 + 4g + r]; l = O^T[d] sits in quad (d%16)/4, register 0 of the last block
   const int lsrc = ((p.d & 15) >> 2) * 16 + r16;

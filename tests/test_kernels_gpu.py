@@ -263,12 +263,14 @@ def test_attention_peaked_softmax(hip, emu):
     close(o_h, o_e, "attn peaked", 6e-3)
 
 
+@pytest.mark.parametrize("nk", [150, 330])
 @pytest.mark.parametrize("d", list(range(8, 161, 8)))
-def test_attention_every_head_dim(hip, emu, d):
+def test_attention_every_head_dim(hip, emu, d, nk):
     """every supported head dim (multiples of 8 up to 160): 32-wide + 16-wide k-steps, the in-MFMA max subtraction (d % 16 == 8)
-    and the plain one, the row of ones that carries the softmax denominator; 2.5 key tiles with a ragged tail"""
+    and the plain one, the row of ones that carries the softmax denominator; 2.5 key tiles with a ragged tail (no steady-state tile) and
+    5.2 key tiles (three tiles of the steady-state loop of round 5, then the general one)"""
     T = torch.bfloat16
-    B, H, nq, nk = 2, 3, 80, 150
+    B, H, nq = 2, 3, 80
     ldvt = ((nk + 7) // 8) * 8
     q, k = rnd((B * H, nq, d), T, 11), rnd((B * H, nk, d), T, 12)
     vt = torch.zeros(B * H, d, ldvt, dtype=T)
