@@ -27,6 +27,9 @@ import types
 import torch
 
 
+SCORE_BYTES_LIMIT = 8 << 30      # scores (+ their softmax copy) one SDPA call of the stand-in may materialise
+
+
 def install_sdpa_xformers():
     """a stand-in `xformers` package: memory_efficient_attention -> torch SDPA (same math: softmax(q k^T / sqrt(d) + bias) v)"""
     if "xformers" in sys.modules and getattr(sys.modules["xformers"], "_fyc_stub", False):
@@ -46,7 +49,7 @@ def install_sdpa_xformers():
         # (16-bit inputs as well: on this ROCm build SDPA takes the materialising path for d = 40 at 9 216 tokens too - 162 GiB asked for)
         n = query.shape[0]
         per = query.shape[-2] * key.shape[-2] * query.element_size() * 2
-        step = max(1, min(n, (8 << 30) // max(per, 1)))
+        step = max(1, min(n, SCORE_BYTES_LIMIT // max(per, 1)))
         if step >= n:
             return F.scaled_dot_product_attention(query, key, value, attn_mask=attn_bias, dropout_p=p, scale=scale)
         out = [F.scaled_dot_product_attention(query[i:i + step], key[i:i + step], value[i:i + step],
