@@ -161,7 +161,7 @@ MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set
         "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
-FYC_VERSION = 202        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
+FYC_VERSION = 300        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
 
 
 class FycError(RuntimeError):
@@ -179,8 +179,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.fyc_version.restype = C.c_int
     ab_build = bool(os.environ.get("FYC_LIB_PATH"))      # an older library for A/B timing (tools/): newer entry points may be absent
-    # (the whole number, not only the major: minor 2 appended fields to two argument structs - an older library would ignore them
-    # silently, a newer one would read past a shorter struct)
+    # (the whole number, not only the major: this binding mirrors exactly one header)
     if lib.fyc_version() != FYC_VERSION and not ab_build:
         raise FycError(f"{LIB_PATH} reports ABI version {lib.fyc_version()}, this binding was written against {FYC_VERSION}: argument structs differ "
                        "between major versions - rebuild the library (`python -m followyourclick_amd._build`)")

@@ -29,8 +29,8 @@ extern "C" {
 /* ABI version = major * 100 + minor.  A host compiled against this header MUST compare fyc_version() with FYC_VERSION before its first
  * call and refuse a library whose MAJOR differs: argument structs grow at the end between majors (round 3 appended `wstream` to
  * fyc_temporal_block_args and widened the tuning table to 16 keys without bumping the number: a round-2 host would have passed a short
- * struct whose missing tail the library reads as a pointer).  History: 100 = rounds 1-3 (see above), 200 = round 4, 201 = FYC_F16, 202 = round 5 (fields appended to fyc_cfg_ddim_args and fyc_unet_input_args: a 201 host passes a shorter struct - rebuild both sides together). */
-#define FYC_VERSION 202
+ * struct whose missing tail the library reads as a pointer).  History: 100 = rounds 1-3 (see above), 200 = round 4, 201 = FYC_F16, 300 = round 5: fields were APPENDED to two argument structs - variance_noise / sigma / clipped_model_output behind the DDIM step's arguments, mode behind the UNet input's - a struct change, hence a new major: a 2xx host passes shorter structs whose missing tail this library would read. */
+#define FYC_VERSION 300
 
 /* FYC_F16 (minor version 1): IEEE half storage with f32 accumulation - every op that takes FYC_BF16 takes it, same layouts, same
  * packed weight streams (16-bit elements), v_mfma_*_f16 instead of v_mfma_*_bf16; the packers cast to the `dtype` they are given */
@@ -259,7 +259,7 @@ typedef struct {
   const float* latents; const float* mask; const float* first; void* x;
   int32_t B, F, HW, c_latent, c_pad, cfg_dup, mask_frames;
   int32_t dtype;
-  /* (minor version 2) mode 0: [latents | mask | first-frame block at frame 0] (use_first_frame_mask_condition_concat, pipeline_animation.py:
+  /* (version 300) mode 0: [latents | mask | first-frame block at frame 0] (use_first_frame_mask_condition_concat, pipeline_animation.py:
    * 693-704); mode 1: [latents | first-frame latents repeated on EVERY frame] (use_first_frame_condition_concat, unet.py:580-586: the
    * UNet itself concatenates `reference_images_latent`), `mask` unused */
   int32_t mode;
@@ -279,7 +279,7 @@ typedef struct {
   /* optional third prediction (pipeline_animation.py:738-760, `video_scale > 0`): per-frame ("single frame") unconditional
    * prediction [B*F][HW][ld];  v = single + video_scale * (uncond - single) + guidance * (cond - uncond).  NULL = plain CFG. */
   const void* pred_single; float video_scale;
-  /* (minor version 2) stochastic DDIM, eta > 0 (scheduling_ddim.py:336-365): prev = ... + sigma * variance_noise, with
+  /* (version 300) stochastic DDIM, eta > 0 (scheduling_ddim.py:336-365): prev = ... + sigma * variance_noise, with
    * sigma = eta * sqrt(variance_t) and coef[3] = sqrt(1 - abar_prev - sigma^2) both computed by the host; variance_noise has the
    * latents' shape and layout (B,4,F,h,w) f32 (the caller draws it: torch.randn(..., generator) as the reference does).  NULL = eta 0.
    * clipped_model_output != 0: `use_clipped_model_output` (:342-344) - the noise direction is re-derived from the (clipped)
