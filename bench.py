@@ -388,18 +388,23 @@ def main(argv=None, emulation=None):
             import glob
             import hashlib
             from followyourclick_amd import _lib as L_
-            from followyourclick_amd._build import source_digest
+            from followyourclick_amd._build import family_digest, source_digest
             with open(L_.LIB_PATH, "rb") as f:
                 digest = hashlib.sha256(f.read()).hexdigest()
             # the loaded library is a build of the sources in the tree unless FYC_LIB_PATH points elsewhere (A/B builds)
             src_digest = source_digest() if not os.environ.get("FYC_LIB_PATH") else None
+            fam_digest = family_digest("gemm") if not os.environ.get("FYC_LIB_PATH") else None
             for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
                 try:
                     doc = json.load(open(tpath))
                     same_binary = doc.get("lib_sha256") == digest
-                    if same_binary or (src_digest and doc.get("source_sha256") == src_digest):
+                    same_sources = bool(src_digest) and doc.get("source_sha256") == src_digest
+                    same_family = bool(fam_digest) and doc.get("gemm_family_source_sha256") == fam_digest
+                    if same_binary or same_sources or same_family:
                         traffic = round(doc["families"]["gemm"]["hbm_bytes_per_launch"])
-                        ident = f"this library binary (sha256 {digest[:12]})" if same_binary else f"a build of these same kernel sources and flags (source digest {src_digest[:12]})"
+                        ident = (f"this library binary (sha256 {digest[:12]})" if same_binary
+                                 else f"a build of these same kernel sources and flags (source digest {src_digest[:12]})" if same_sources
+                                 else f"a build whose GEMM-family sources and flags are those of the profiled library (family digest {fam_digest[:12]}; another family's source changed since)")
                         traffic_note = (f"avg HBM bytes per fyc_gemm_kernel launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE on "
                                         f"{ident}, {os.path.relpath(tpath, ROOT)}")
                         break

@@ -88,6 +88,25 @@ def source_digest() -> str:
     return h.hexdigest()
 
 
+def family_digest(family: str = "gemm") -> str:
+    """sha256 over what ONE kernel family is compiled from (its sources, the headers they include below csrc/, their flags): the
+    identity a per-family profile is matched by - `roofline.traffic` is a fact about fyc_gemm_kernel and stays valid when another family's
+    source (the attention kernel, round 5) changes after the PMC passes were taken.  include/fyc.h is left out on purpose: it changes with
+    every ABI note; a change of the family's own argument struct shows up in the family's sources that use it."""
+    if family != "gemm":
+        raise ValueError(family)
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.startswith("gemm") and f.endswith((".hip", ".h"))) + ["fyc_common.h"]
+    for f in files:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    for src in SOURCES:
+        if src.startswith("gemm"):
+            h.update((src + " " + " ".join(_flags(src))).encode())
+    return h.hexdigest()
+
+
 def _compile(src: str) -> str:
     path = os.path.join(VARIANT_DIR if src in VARIANT_SOURCES else CSRC, src)
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))

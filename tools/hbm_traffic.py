@@ -59,8 +59,8 @@ def main(fetch_dir, write_dir, out_path):
         fams[fam] = {"launches": n, "fetch_bytes_per_launch": 2.0 * sf / max(nf, 1), "write_bytes_per_launch": sw / max(nw, 1),
                      "hbm_bytes_per_launch": 2.0 * sf / max(nf, 1) + sw / max(nw, 1)}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from followyourclick_amd._build import source_digest
-    doc = {"lib_sha256": lib_digest(), "source_sha256": source_digest(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the DDIM steps of a `bench.py --ddim-steps 2` run at cfg2 (4 steps: 2 of the timed clip + 2 of the host-timing leg; per-launch averages do not depend on the count; weights packing and the "
+    from followyourclick_amd._build import family_digest, source_digest
+    doc = {"lib_sha256": lib_digest(), "source_sha256": source_digest(), "gemm_family_source_sha256": family_digest("gemm"), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the DDIM steps of a `bench.py --ddim-steps 2` run at cfg2 (4 steps: 2 of the timed clip + 2 of the host-timing leg; per-launch averages do not depend on the count; weights packing and the "
                      "one-off context projections included in 'other'/'gemm' launch counts); FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 "
                      "correction; WRITE_SIZE uncalibrated", "families": fams}
     with open(out_path, "w") as f:
