@@ -15,8 +15,9 @@ scaling : weak - every rank denoises its own clips; the only collective is the o
 
 Adds to the JSON line: "roofline" (dominant kernel = the MFMA GEMM/implicit-conv family, timed per launch
 with HIP events in an instrumented extra pass; on every configuration's line), with --vae "roofline_vae"
-(the same family inside the VAE decode), "cpu_baseline" (the CPU oracle: whole-clip DDIM steps at the same
-resolution, one untimed + --cpu-steps timed, threads bound to one NUMA node; rank 0, N=1 only) and "parity" (rel-L2 of THIS
+(the same family inside the VAE decode), "cpu_baseline" (whole-clip DDIM steps at the same resolution, one untimed +
+--cpu-steps timed, threads bound to one NUMA node; rank 0, N=1 only: kind "reference" = the unmodified reference's own CPU path from the
+byte copies under oracle/_ref/, in a subprocess; kind "port" = the CPU oracle, when the reference files are absent or its run fails) and "parity" (rel-L2 of THIS
 binary and dtype against the reference's own cfg2 trajectory, tests/golden/cfg2_trajectory.npz).
 `--gpus N` without a launcher re-executes itself under torch.distributed.run; a world size that differs from --gpus is an error.
 `metric` and `config.workload` are derived from the arguments: only the default arguments produce BASELINE.json's
@@ -87,6 +88,30 @@ def numa_node_cores(node: int = 0):
 
 CPU_THREADS_MAX = 32          # past ~32 threads the oracle's many small ops stop scaling (profiles/r04_cpu_baseline_thread_sweep.txt)
 REFERENCE_CPU_S_PER_FRAME = 6.5   # the reference's own CPU path, 8 cores, seconds per frame per DDIM step at 512^2
+
+
+def cpu_baseline_reference(frames, size, ddim_steps, timed_steps, timeout_s):
+    """kind "reference": the UNMODIFIED reference UNet3DConditionModel (byte copies under the git-ignored oracle/_ref/) on the host cores, in a
+    subprocess (`python -m oracle.gpu_reference --cpu-baseline`, test infrastructure), threads bound like the port's.  None when the reference
+    files are not staged or the subprocess fails / times out - the caller then falls back to the port."""
+    import subprocess
+    if not (os.path.exists(os.path.join(ROOT, "oracle", "_ref", "animatediff", "models", "unet.py")) or os.path.isdir("/root/reference/animatediff")):
+        return None, "reference model files not staged under oracle/_ref/"
+    cores, logical = numa_node_cores(0)
+    node_cores = len(cores)
+    cores = cores[:CPU_THREADS_MAX]
+    cmd = [sys.executable, "-m", "oracle.gpu_reference", "--cpu-baseline", "--frames", str(frames), "--size", str(size), "--ddim-steps", str(ddim_steps),
+           "--timed", str(max(1, timed_steps)), "--cores", ",".join(str(c) for c in cores)]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    except subprocess.TimeoutExpired:
+        return None, f"the reference's CPU run did not finish in {timeout_s}s"
+    for line in r.stdout.splitlines():
+        if line.startswith("CPU_REFERENCE "):
+            d = json.loads(line[len("CPU_REFERENCE "):])
+            d.update(cores_on_numa_node0=node_cores, logical_cpus_on_host=logical, reference_cpu_s_per_frame_per_ddim_step=REFERENCE_CPU_S_PER_FRAME)
+            return d, None
+    return None, (r.stderr or r.stdout)[-200:]
 
 
 def cpu_baseline(sd, frames, h, w, ddim_steps, timed_steps=1):
@@ -249,6 +274,8 @@ def main(argv=None, emulation=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed DDIM steps of the cpu_baseline leg (after one untimed step; BASELINE.md 3 asks for 2)")
+    ap.add_argument("--cpu-port", action="store_true", help="cpu_baseline from the oracle port (kind 'port') instead of the staged reference itself (kind 'reference')")
+    ap.add_argument("--cpu-timeout", type=int, default=600, help="seconds the reference's CPU run may take before the port is used instead")
     ap.add_argument("--no-parity", action="store_true", help="skip the `parity` field (one extra clip against tests/golden/cfg2_trajectory.npz)")
     ap.add_argument("--no-gpu-reference", action="store_true",
                     help="skip the `gpu_reference` leg (the UNMODIFIED reference UNet3D, eager PyTorch-ROCm under torch.autocast, from the byte copies under oracle/_ref/)")
@@ -490,10 +517,17 @@ def main(argv=None, emulation=None):
             result["gpu_reference"]["engine_over_reference"] = round(result["value"] / result["gpu_reference"]["value"], 2)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emulate and os.environ.get("FYC_BENCH_CPU", "1") != "0":
-        try:
-            result["cpu_baseline"] = cpu_baseline(sd, args.frames, h, w, args.ddim_steps, args.cpu_steps)
-        except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
-            result["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+        # the reference's OWN CPU path first (north_star: "the reference's own CPU path timed on the same box's host cores"); the oracle port
+        # when the reference files are not there or its run fails
+        ref, why = (None, "--cpu-port") if args.cpu_port else cpu_baseline_reference(args.frames, args.size, args.ddim_steps, args.cpu_steps, args.cpu_timeout)
+        if ref is not None:
+            result["cpu_baseline"] = ref
+        else:
+            try:
+                result["cpu_baseline"] = cpu_baseline(sd, args.frames, h, w, args.ddim_steps, args.cpu_steps)
+                result["cpu_baseline"]["reference_run"] = f"not used: {why}"
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
+                result["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
 
     if rank == 0:
         print(json.dumps(result))

@@ -167,6 +167,41 @@ def time_reference(frames=16, size=512, ddim_steps=25, dtype="bf16", attention="
                        f"the guidance / scheduler arithmetic between forwards (< 0.1 % of a step) is not included")
 
 
+def time_reference_cpu(frames=16, size=512, ddim_steps=25, timed=1, cores=None):
+    """bench.py's `cpu_baseline` leg with kind "reference": the UNMODIFIED reference UNet3DConditionModel on the HOST cores, fp32, as its CPU
+    path runs it (no xformers: baddbmm + softmax; the 16 spatial attn1 take the reference's own sliced-attention valve, `_slice_size = 8`, which
+    is bit-identical math and bounds the score tensor - the same setting the goldens were generated with, oracle/make_golden_full.py).  Threads
+    are bound to `cores` (bench.py passes the physical cores of NUMA node 0).  One untimed CFG-pair forward at the shape, then `timed` timed ones."""
+    import os
+    if cores:
+        os.sched_setaffinity(0, set(cores))
+        torch.set_num_threads(len(cores))
+    t0 = time.time()
+    cfg, unet = build_reference_unet("cpu", max_len=max(24, frames), attention="eager")
+    for m in unet.modules():
+        if m.__class__.__name__ == "BasicTransformerBlock" and hasattr(m, "attn1"):
+            m.attn1._slice_size = 8
+    t_build = time.time() - t0
+    h = w = size // 8
+    g = torch.Generator().manual_seed(1)
+    text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+    fps, flow = torch.tensor([2, 2]), torch.tensor([4, 4])
+    times = []
+    for i in range(1 + timed):
+        x9 = torch.randn(2, cfg.conv_in_channels, frames, h, w, generator=g)
+        t0 = time.time()
+        out = forward(unet, x9, 961 - 40 * i, text, fps, flow, None)
+        times.append(time.time() - t0)
+        assert torch.isfinite(out).all()
+    dt = sum(times[1:]) / timed
+    n = torch.get_num_threads()
+    return dict(value=frames / (ddim_steps * dt), unit="frames/s", cores=n, kind="reference", s_per_frame_per_ddim_step=round(dt / frames, 2),
+                build_s=round(t_build, 1), first_step_s=round(times[0], 1),
+                sample=f"the unmodified reference UNet3DConditionModel (oracle/_ref byte copies) on the host cores, fp32, its CPU attention path: {timed} timed "
+                       f"DDIM step(s) (CFG-pair forward at {size}x{size}) on ALL {frames} frames of the clip, {dt:.1f}s per step = {dt / frames:.2f} s/frame, after one "
+                       f"untimed step at the same shape ({times[0]:.1f}s); {n} threads bound to physical cores of NUMA node 0; frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
+
+
 def dump(what, out):
     """tests/test_reference_gpu.py runs the reference in a SUBPROCESS (`python -m oracle.gpu_reference --dump <what> --out file.pt`):
     the reference's `animatediff` / `diffusers` packages and the product's drop-in packages of the same names cannot live in one
@@ -225,7 +260,13 @@ if __name__ == "__main__":
     ap.add_argument("--attention", default="sdpa", choices=["sdpa", "eager"])
     ap.add_argument("--timed", type=int, default=2)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true", help="time the reference on the HOST cores instead (bench.py's cpu_baseline leg, kind 'reference')")
+    ap.add_argument("--cores", default="", help="comma-separated logical cpu ids to bind to")
     a = ap.parse_args()
+    if a.cpu_baseline:
+        r = time_reference_cpu(a.frames, a.size, a.ddim_steps, a.timed, [int(c) for c in a.cores.split(",") if c] or None)
+        print("CPU_REFERENCE " + json.dumps(r))
+        sys.exit(0)
     if a.dump:
         dump(a.dump, a.out)
         sys.exit(0)
