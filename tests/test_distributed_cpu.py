@@ -197,3 +197,21 @@ def test_bench_labels_follow_the_arguments():
     assert bench.workload_label(ns(frames=16, size=512, ddim_steps=2, ip_tokens=0)).startswith("custom")
     cores, logical = bench.numa_node_cores(0)
     assert 1 <= len(cores) <= logical
+
+
+def test_bench_helper_legs_fail_soft_and_traffic_matches_by_family():
+    """the extra legs of the bench line never cost the line: a reference CPU run that does not finish in time hands over to the port
+    (None + a reason), a missing staged tree likewise; and `roofline.traffic` is matched per kernel family - the committed PMC profile of the
+    GEMM family stays valid when another family's source changed afterwards (followyourclick_amd/_build.py::family_digest)"""
+    import glob
+    import json
+    import bench
+    from followyourclick_amd import _build
+    d, why = bench.cpu_baseline_reference(2, 64, 2, 1, timeout_s=1)
+    assert d is None and ("did not finish" in why or "not staged" in why)
+    fam = _build.family_digest("gemm")
+    assert fam == _build.family_digest("gemm") and len(fam) == 64
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True)[0]
+    doc = json.load(open(newest))
+    assert doc.get("gemm_family_source_sha256") == fam, "the GEMM-family sources changed after the newest PMC traffic profile was taken: re-run tools/collect_profiles.sh"
+    assert doc["families"]["gemm"]["hbm_bytes_per_launch"] > 1e8
