@@ -269,11 +269,13 @@ def main(argv=None, emulation=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
                     help="storage / MFMA operand type: bf16 (BASELINE configs[1], the default), f16 (the reference's deployed autocast precision), f32 (parity mode)")
     ap.add_argument("--ip-tokens", type=int, default=0, help="configs[4]: IP-Adapter decoupled cross-attention with this many image tokens")
-    ap.add_argument("--vae", action="store_true", help="also time the VAE decode of the final latents (outside the metric)")
+    ap.add_argument("--vae", dest="vae", action="store_true", default=True,
+                    help="time the VAE decode of the final latents (outside the metric: vae_decode_ms, roofline_vae, end_to_end_frames_per_sec); ON by default since round 6 (SURVEY 8d)")
+    ap.add_argument("--no-vae", dest="vae", action="store_false")
     ap.add_argument("--graph", action="store_true", help="replay DDIM steps 1..n-1 from one captured hipGraph (A/B vs eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=1, help="timed DDIM steps of the cpu_baseline leg (after one untimed step; BASELINE.md 3 asks for 2)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed DDIM steps of the cpu_baseline leg (after one untimed step; BASELINE.md 3 asks for 2)")
     ap.add_argument("--cpu-port", action="store_true", help="cpu_baseline from the oracle port (kind 'port') instead of the staged reference itself (kind 'reference')")
     ap.add_argument("--cpu-timeout", type=int, default=600, help="seconds the reference's CPU run may take before the port is used instead")
     ap.add_argument("--no-parity", action="store_true", help="skip the `parity` field (one extra clip against tests/golden/cfg2_trajectory.npz)")
@@ -471,7 +473,7 @@ def main(argv=None, emulation=None):
                                              "frac": round(at / PEAK_BF16_TFLOPS, 4), "launches_per_ddim_step": a["launches"] // n_inst,
                                              "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2)}
 
-    if rank == 0 and args.vae:
+    if rank == 0 and args.vae and not emulate:
         from followyourclick_amd.engine import VAEDecoderConfig
         from followyourclick_amd.engine.schema import vae_decoder_schema
         from followyourclick_amd.engine.vae import VAEDecoderEngine

@@ -89,13 +89,15 @@ class DDIMSampler:
         x = u.new(dupn * B * F * H * W, cp)
         if "temb_first" in st:
             latents[:, :, 0] = first_image_latents.reshape(B, CL, H, W)
-        if u.cfg.use_first_frame_mask_condition_concat:
-            o.unet_input(latents, mask, first_image_latents, x, B=B, F=F, HW=H * W, c_latent=CL, c_pad=cp, cfg_dup=dupn,
-                         mask_frames=1)
-        elif u.cfg.use_first_frame_condition_concat:
+        # (same precedence as UNet3DConfig.conv_in_channels / pack_unet and the reference's constructor, unet.py:114-126: the 8-channel
+        # concat wins when both flags are set - the mask flag defaults to True)
+        if u.cfg.use_first_frame_condition_concat:
             # the reference's UNet concatenates `reference_images_latent` (the clean first-frame latents) beside EVERY frame's latents
             # (unet.py:580-586; pipeline_animation.py:705-706 passes the plain latents); conv_in's `/ 2` lives in its packed weights
             o.unet_input(latents, None, first_image_latents, x, B=B, F=F, HW=H * W, c_latent=CL, c_pad=cp, cfg_dup=dupn, mode=1)
+        elif u.cfg.use_first_frame_mask_condition_concat:
+            o.unet_input(latents, mask, first_image_latents, x, B=B, F=F, HW=H * W, c_latent=CL, c_pad=cp, cfg_dup=dupn,
+                         mask_frames=1)
         else:
             # plain latents (the 2-D Stable Diffusion first-image path, reference pipeline_stable_diffusion.py:527-528)
             n = B * F * H * W
@@ -154,7 +156,7 @@ class DDIMSampler:
             return latents
         # Step 0 runs eagerly (it is also the warm-up: lazily set kernel attributes, allocator pools); step 1 is captured
         # reading its time-embedding row and DDIM coefficients from two fixed buffers, which are refreshed before every replay.
-        self.step(st, 0, latents, first, mask)
+        self.step(st, 0, latents, first, mask, use_clipped_model_output=use_clipped_model_output)
         if callback is not None:
             callback(0, ts[0], latents)
         temb_cur, coef_cur = torch.empty_like(st["temb"][0]), torch.empty_like(st["coef"][0])
@@ -163,7 +165,7 @@ class DDIMSampler:
         side = torch.cuda.Stream(device=u.device)
         side.wait_stream(torch.cuda.current_stream(u.device))
         with torch.cuda.graph(graph, stream=side):
-            self.step(gst, 0, latents, first, mask)
+            self.step(gst, 0, latents, first, mask, use_clipped_model_output=use_clipped_model_output)
         for i in range(1, num_steps):
             temb_cur.copy_(st["temb"][i])
             coef_cur.copy_(st["coef"][i])

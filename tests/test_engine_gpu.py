@@ -149,6 +149,20 @@ def test_sampling_loop_graph_replay_equals_eager(golden_dir, dtype):
     assert torch.equal(graph, eager), rel(graph, eager)
 
 
+def test_graph_replay_honours_use_clipped_model_output(golden_dir):
+    """round-5 advisor: the hipGraph path of DDIMSampler.sample dropped `use_clipped_model_output`.  With clip_sample on, the option
+    changes the update (scheduling_ddim.py:336-340): eager and replayed runs must agree WITH it and differ from the run without it"""
+    g = _load(golden_dir, "pipeline_tiny.npz")
+    sd = W.make_weights(W.unet_state_shapes(Fn.tiny_unet_config()), int(g["unet_weight_seed"]))
+    smp = DDIMSampler(UNet3DEngine(pack_unet(sd, tiny_cfg(), torch.float32, DEV)), DDIMConfig(clip_sample=True))
+    args = (g["latents"] * 2.0, g["text_embeddings"], 4, 8.0, g["first_image_latents"], g["first_images_mask"])
+    eager = smp.sample(*args, fps=[2], flow=[4], use_graph=False, use_clipped_model_output=True).cpu()
+    graph = smp.sample(*args, fps=[2], flow=[4], use_graph=True, use_clipped_model_output=True).cpu()
+    plain = smp.sample(*args, fps=[2], flow=[4], use_graph=True, use_clipped_model_output=False).cpu()
+    assert torch.equal(graph, eager), rel(graph, eager)
+    assert not torch.equal(plain, eager)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 6e-2)])
 def test_vae_decode_vs_reference_golden(golden_dir, dtype, tol):
     g = _load(golden_dir, "vae_tiny.npz")

@@ -163,6 +163,25 @@ def test_engine_first_frame_condition_concat(g, dtype, tol):
     assert rel(lat, ref) < (5e-4 if dtype == torch.float32 else 1e-1)
 
 
+def test_concat_flag_wins_over_the_default_mask_flag():
+    """both concat flags set (the mask flag DEFAULTS to True): the 8-channel concat wins everywhere - UNet3DConfig.conv_in_channels,
+    pack_unet (conv_in / 2) and the sampler's input layout - as in the reference's constructor (unet.py:114-126).  Round-5 advisor:
+    the sampler used to test the mask flag first and fed the halved 8-channel conv_in the 9-channel layout."""
+    kcfg = Fn.tiny_unet_config(use_first_frame_condition_concat=True, use_first_frame_mask_condition_concat=False)
+    sd = W.make_weights(W.unet_state_shapes(kcfg), 0)
+    inp = W.seeded_inputs(kcfg, 1, 2, 8, 8, seed=5)
+    lats = []
+    for mask_flag in (False, True):
+        ecfg = UNet3DConfig(use_first_frame_condition_concat=True, use_first_frame_mask_condition_concat=mask_flag, **TINY)
+        assert ecfg.conv_in_channels == 8
+        eng = UNet3DEngine(pack_unet(sd, ecfg, torch.float32, "cpu"), ops=EmuOps())
+        lats.append(DDIMSampler(eng, DDIMConfig()).sample(inp["latents"], inp["text"], 2, 8.0, inp["first_image_latents"], None, fps=[2], flow=[4]))
+    assert torch.equal(lats[0], lats[1])
+    with torch.no_grad():
+        ref = Fn.denoise(sd, kcfg, Fn.DDIMConfig(), inp["latents"].clone(), inp["text"], 2, 8.0, inp["first_image_latents"], None, torch.tensor([2]), torch.tensor([4]))
+    assert rel(lats[1], ref) < 5e-4
+
+
 # ---- the HIP kernels behind the two ops that changed ---------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
