@@ -202,32 +202,50 @@ def time_reference_cpu(frames=16, size=512, ddim_steps=25, timed=1, cores=None):
                        f"untimed step at the same shape ({times[0]:.1f}s); {n} threads bound to physical cores of NUMA node 0; frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
 
 
-def dump(what, out):
-    """tests/test_reference_gpu.py runs the reference in a SUBPROCESS (`python -m oracle.gpu_reference --dump <what> --out file.pt`):
-    the reference's `animatediff` / `diffusers` packages and the product's drop-in packages of the same names cannot live in one
-    interpreter.  Inputs are re-derived from the goldens' seeds on both sides; only the reference's outputs cross the file."""
+def dump(what, out=None, out_dir=None):
+    """tests/test_reference_gpu.py runs the reference in a SUBPROCESS (`python -m oracle.gpu_reference --dump a,b --out-dir D`, one per
+    test session, started by tests/conftest.py while the kernel tests run): the reference's `animatediff` / `diffusers` packages and the
+    product's drop-in packages of the same names cannot live in one interpreter.  Inputs are re-derived from the goldens' seeds on both
+    sides; only the reference's outputs cross the files (`D/<what>.pt`, written under a temporary name and renamed when complete).
+    One model is built per distinct configuration: `small` runs on the max_len-32 model of `cfg3` when both are asked for (the
+    positional table is sliced to the clip length, motion_module.py:303 - the first 24 rows are the same numbers)."""
     import os
     import numpy as np
     from . import functional as Fn
     from . import weights as W
     dev = torch.device("cuda", 0)
     golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-    t0 = time.time()
-    if what == "small":          # the unet_full_small_fwd inputs in f32 and under the real bf16 / f16 autocast
-        g = np.load(os.path.join(golden, "unet_full_small_fwd.npz"))
-        cfg, unet = build_reference_unet(dev, attention="sdpa")
-        inp = W.seeded_inputs(Fn.UNetConfig(), 1, int(g["frames"]), int(g["h"]), int(g["w"]), seed=int(g["input_seed"]))
-        x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
-        res = {name: forward(unet, x9, int(g["timestep"]), inp["text"], torch.from_numpy(g["fps"]), torch.from_numpy(g["flow"]), ac).cpu()
-               for name, ac in (("f32", None), ("bf16", torch.bfloat16), ("f16", torch.float16))}
-    else:
-        frames, lat, num_steps, run_steps, seed, ocfg, mask, use_ip = TRAJECTORIES[what]()
-        _, unet = build_reference_unet(dev, attention="sdpa", ocfg=ocfg)
-        inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
-        res = {name: reference_trajectory(unet, inp, num_steps, run_steps, ac, mask=mask, ip_tokens=inp["ip_tokens"] if use_ip else None)
-               for name, ac in (("f32", None), ("bf16", torch.bfloat16))}
-    res["seconds"] = time.time() - t0
-    torch.save(res, out)
+    whats = what.split(",")
+    models = {}
+
+    def model(ocfg):
+        key = repr(ocfg)
+        if key not in models:
+            models.clear()                       # one reference model on the device at a time
+            torch.cuda.empty_cache()
+            models[key] = build_reference_unet(dev, attention="sdpa", ocfg=ocfg)[1]
+        return models[key]
+
+    for w in whats:
+        t0 = time.time()
+        if w == "small":          # the unet_full_small_fwd inputs in f32 and under the real bf16 / f16 autocast
+            g = np.load(os.path.join(golden, "unet_full_small_fwd.npz"))
+            unet = model(TRAJECTORIES["cfg3"]()[5] if "cfg3" in whats else Fn.UNetConfig())
+            inp = W.seeded_inputs(Fn.UNetConfig(), 1, int(g["frames"]), int(g["h"]), int(g["w"]), seed=int(g["input_seed"]))
+            x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+            res = {name: forward(unet, x9, int(g["timestep"]), inp["text"], torch.from_numpy(g["fps"]), torch.from_numpy(g["flow"]), ac).cpu()
+                   for name, ac in (("f32", None), ("bf16", torch.bfloat16), ("f16", torch.float16))}
+        else:
+            frames, lat, num_steps, run_steps, seed, ocfg, mask, use_ip = TRAJECTORIES[w]()
+            unet = model(ocfg)
+            inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
+            res = {name: reference_trajectory(unet, inp, num_steps, run_steps, ac, mask=mask, ip_tokens=inp["ip_tokens"] if use_ip else None)
+                   for name, ac in (("f32", None), ("bf16", torch.bfloat16))}
+        res["seconds"] = time.time() - t0
+        path = out if (out and len(whats) == 1) else os.path.join(out_dir, w + ".pt")
+        torch.save(res, path + ".tmp")
+        os.replace(path + ".tmp", path)
+        print(f"[gpu_reference] {w}: {res['seconds']:.1f} s", flush=True)
 
 
 def rectangle_mask(lat):
@@ -251,8 +269,9 @@ TRAJECTORIES = {"cfg3": _traj_cfg3, "cfg4ip": _traj_cfg4ip}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dump", default=None, choices=["small", "cfg3", "cfg4ip"])
+    ap.add_argument("--dump", default=None, help="comma-separated subset of small, cfg3, cfg4ip")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--out-dir", default=None)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=25)
@@ -268,7 +287,7 @@ if __name__ == "__main__":
         print("CPU_REFERENCE " + json.dumps(r))
         sys.exit(0)
     if a.dump:
-        dump(a.dump, a.out)
+        dump(a.dump, a.out, a.out_dir)
         sys.exit(0)
     r = time_reference(a.frames, a.size, a.ddim_steps, a.dtype, a.attention, a.timed)
     print("GPU_REFERENCE " + json.dumps(r) if a.json else r)

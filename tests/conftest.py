@@ -27,3 +27,107 @@ def _fresh_library():
     if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
         _build.build(verbose=False)
     yield
+
+
+# ---- session-wide caches for the full-width GPU tests (round 6: the suite built the same 1.28 B-parameter seeded state dict 8 times
+# - 22 s each - and packed the same engines up to 5 times) -------------------------------------------------------------------------------
+class _FullWidthCache:
+    """seeded oracle-side state dicts and the engines packed from them, keyed by configuration: test infrastructure"""
+
+    def __init__(self):
+        self.sd, self.eng = {}, {}
+
+    def weights(self, ocfg, seed=0):
+        from oracle import weights as W
+        key = (repr(ocfg), int(seed))
+        if key not in self.sd:
+            self.sd[key] = W.make_weights(W.unet_state_shapes(ocfg), int(seed))
+        return self.sd[key]
+
+    def engine(self, ocfg, ecfg, dtype, seed=0, dev="cuda:0"):
+        """UNet3DEngine over make_weights(unet_state_shapes(ocfg), seed) packed for ecfg in dtype.  Engines are shared between tests:
+        every test calls prepare_context / the sampler's prepare before it runs a forward, nothing else of an engine is test state."""
+        from followyourclick_amd.engine.unet3d import UNet3DEngine
+        from followyourclick_amd.engine.weights import pack_unet
+        key = (repr(ecfg), int(seed), str(dtype), dev)
+        if key not in self.eng:
+            self.eng[key] = UNet3DEngine(pack_unet(self.weights(ocfg, seed), ecfg, dtype, dev))
+        return self.eng[key]
+
+
+@pytest.fixture(scope="session")
+def fullwidth():
+    cache = _FullWidthCache()
+    yield cache
+    cache.eng.clear()
+    cache.sd.clear()
+
+
+# ---- the same-device reference (tests/test_reference_gpu.py): ONE background subprocess per session ---------------------------------------
+# The reference's `animatediff` / `diffusers` packages and the drop-in packages of the same names cannot share an interpreter, so the
+# reference side runs as `python -m oracle.gpu_reference --dump a,b,c --out-dir D`.  Round 5 started one such process per test and
+# waited for it (270 s of the 744-s suite: three model builds, f32 forwards at 32f@768^2).  Now the process starts when the collection
+# is done and computes while the kernel tests run; the tests that need a dump wait for its `<what>.pt`.
+_REF_PROC = {}
+_REF_WHAT = (("small", ("small_case", "test_device_reference", "test_real_autocast", "test_engine_vs_same_device")),
+             ("cfg4ip", ("test_cfg4_full_shape_ip_trajectory",)), ("cfg3", ("test_cfg3_full_shape_trajectory",)))
+
+
+def pytest_collection_finish(session):
+    items = [it for it in session.items if "test_reference_gpu" in it.nodeid]
+    if not items or session.config.option.collectonly:
+        return
+    staged = os.path.join(ROOT, "oracle", "_ref", "animatediff", "models", "unet.py")
+    if not (os.path.exists(staged) or os.path.isdir("/root/reference/animatediff")):
+        return
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+    except Exception:
+        return
+    import subprocess
+    import tempfile
+    what = [w for w, keys in _REF_WHAT if any(any(k in it.nodeid for k in keys) for it in items)]
+    if not what:
+        return
+    out_dir = tempfile.mkdtemp(prefix="fyc_ref_")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    log = open(os.path.join(out_dir, "log.txt"), "w")
+    proc = subprocess.Popen([sys.executable, "-m", "oracle.gpu_reference", "--dump", ",".join(what), "--out-dir", out_dir], cwd=ROOT, env=env,
+                            stdout=log, stderr=subprocess.STDOUT)
+    _REF_PROC.update(proc=proc, dir=out_dir, what=what, log=log)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    proc = _REF_PROC.get("proc")
+    if proc is not None:
+        if proc.poll() is None:
+            proc.kill()            # the exact PID this session started
+            proc.wait()
+        _REF_PROC["log"].close()
+        import shutil
+        shutil.rmtree(_REF_PROC["dir"], ignore_errors=True)
+        _REF_PROC.clear()
+
+
+@pytest.fixture(scope="session")
+def device_reference():
+    """device_reference(what) -> the dict `oracle.gpu_reference --dump what` stored, from the session's background process"""
+    import time
+
+    def get(what, timeout=1500):
+        if "proc" not in _REF_PROC:
+            pytest.skip("reference model files not staged (python -m oracle.stage_ref_scripts, container only)")
+        import torch
+        proc, path = _REF_PROC["proc"], os.path.join(_REF_PROC["dir"], what + ".pt")
+        assert what in _REF_PROC["what"], (what, _REF_PROC["what"])
+        t0 = time.time()
+        while not os.path.exists(path):
+            if proc.poll() is not None and not os.path.exists(path):
+                _REF_PROC["log"].flush()
+                raise AssertionError("the reference subprocess ended without " + what + ".pt:\n" + open(os.path.join(_REF_PROC["dir"], "log.txt")).read()[-3000:])
+            assert time.time() - t0 < timeout, f"no {what}.pt after {timeout} s"
+            time.sleep(1.0)
+        return torch.load(path)
+    return get

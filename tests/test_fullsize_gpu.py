@@ -22,8 +22,18 @@ F, H, W = 16, 64, 64
 
 @pytest.fixture(scope="module")
 def weights():
+    """(cfg, engine(dtype)): the product-side random state dict, each precision packed once for the module"""
     cfg = UNet3DConfig()
-    return cfg, random_state_dict(unet_schema(cfg), seed=0)
+    sd = random_state_dict(unet_schema(cfg), seed=0)
+    cache = {}
+
+    def engine(dtype):
+        if dtype not in cache:
+            cache[dtype] = UNet3DEngine(pack_unet(sd, cfg, dtype, DEV))
+        return cache[dtype]
+    yield cfg, engine
+    cache.clear()
+    torch.cuda.empty_cache()
 
 
 def _inputs(B, seed):
@@ -47,11 +57,10 @@ def rel(a, b):
 
 
 def test_bf16_matches_f32_parity_mode_at_full_size(weights):
-    cfg, sd = weights
+    cfg, engine = weights
     x, text = _inputs(2, 1)
-    ref = _forward(UNet3DEngine(pack_unet(sd, cfg, torch.float32, DEV)), x, text, 2)
-    torch.cuda.empty_cache()
-    out = _forward(UNet3DEngine(pack_unet(sd, cfg, torch.bfloat16, DEV)), x, text, 2)
+    ref = _forward(engine(torch.float32), x, text, 2)
+    out = _forward(engine(torch.bfloat16), x, text, 2)
     assert torch.isfinite(out).all()
     r = rel(out, ref)
     print(f"full-size bf16 vs f32 parity mode: rel-L2 {r:.3e}")
@@ -59,8 +68,8 @@ def test_bf16_matches_f32_parity_mode_at_full_size(weights):
 
 
 def test_clips_are_independent_at_full_size(weights):
-    cfg, sd = weights
-    eng = UNet3DEngine(pack_unet(sd, cfg, torch.bfloat16, DEV))
+    cfg, engine = weights
+    eng = engine(torch.bfloat16)
     x, text = _inputs(2, 2)
     both = _forward(eng, x, text, 2)
     n = F * H * W

@@ -16,8 +16,6 @@ import pytest
 import torch
 
 from followyourclick_amd.engine import UNet3DConfig
-from followyourclick_amd.engine.unet3d import UNet3DEngine
-from followyourclick_amd.engine.weights import pack_unet
 from oracle import functional as Fn
 from oracle import weights as W
 
@@ -26,7 +24,6 @@ from test_engine_gpu import _load, _nhwc, rel, report
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGED = os.path.join(ROOT, "oracle", "_ref", "animatediff", "models", "unet.py")
 # engine 16-bit mode vs the device's f32 reference run <= SAME_DEVICE_FACTOR x (the reference's own autocast run vs its f32 run, same
 # device).  The CPU-emulated rule is 1.1 x (tests/test_fullwidth_gpu.py, measured 0.88-0.95 x); the real autocast also keeps softmax /
 # norms in f32 but runs its GEMMs through other kernels (hipBLASLt / MIOpen, other accumulation orders), so the ratio is measured here
@@ -39,29 +36,14 @@ SAME_DEVICE_FACTOR = 1.15
 EMUL_BAND = (0.6, 1.7)
 
 
-def _reference(what, tmp_path_factory):
-    """the reference side, computed by `python -m oracle.gpu_reference --dump <what>` in its own interpreter: the reference's
-    `animatediff` / `diffusers` packages and the drop-in packages of the same names (other test modules of this session) cannot share
-    one `sys.modules`"""
-    import subprocess
-    import sys
-    if not (os.path.exists(STAGED) or os.path.isdir("/root/reference/animatediff")):
-        pytest.skip("reference model files not staged (python -m oracle.stage_ref_scripts, container only)")
-    out = str(tmp_path_factory.mktemp("ref") / f"{what}.pt")
-    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
-    r = subprocess.run([sys.executable, "-m", "oracle.gpu_reference", "--dump", what, "--out", out], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return torch.load(out)
-
-
 @pytest.fixture(scope="module")
-def small_case(golden_dir, tmp_path_factory):
+def small_case(golden_dir, device_reference):
     """the unet_full_small_fwd inputs, and the reference's three runs of them on the device"""
     g = _load(golden_dir, "unet_full_small_fwd.npz")
     F, H, Wd = int(g["frames"]), int(g["h"]), int(g["w"])
     inp = W.seeded_inputs(Fn.UNetConfig(), 1, F, H, Wd, seed=int(g["input_seed"]))
     x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
-    runs = _reference("small", tmp_path_factory)
+    runs = device_reference("small")
     for name in ("f32", "bf16", "f16"):
         assert torch.isfinite(runs[name]).all(), name
     return g, inp, x9, runs
@@ -91,15 +73,13 @@ def test_real_autocast_validates_the_cpu_emulation(golden_dir, small_case):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-def test_engine_vs_same_device_reference(small_case, mode):
+def test_engine_vs_same_device_reference(small_case, fullwidth, mode):
     """the engine's 16-bit modes against the reference's runs ON THE SAME CHIP: no further from the f32 run than the reference's own
     autocast run of that precision (x SAME_DEVICE_FACTOR); the distance between the two 16-bit runs is reported"""
     g, inp, x9, runs = small_case
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
     F, H, Wd = int(g["frames"]), int(g["h"]), int(g["w"])
-    sd = W.make_weights(W.unet_state_shapes(Fn.UNetConfig()), seed=int(g["weight_seed"]))
-    eng = UNet3DEngine(pack_unet(sd, UNet3DConfig(), dtype, DEV))
-    del sd
+    eng = fullwidth.engine(Fn.UNetConfig(), UNet3DConfig(), dtype, seed=int(g["weight_seed"]))
     eng.prepare_context(inp["text"])
     _, temb = eng.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), 2)
     out = eng.forward(_nhwc(x9, dtype), temb, 2, F, H, Wd).float().cpu().reshape(2, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
@@ -109,8 +89,6 @@ def test_engine_vs_same_device_reference(small_case, mode):
     report(f"engine {mode} vs same-device reference (F=4, 16x16): vs ref-f32-on-cuda {r32:.3e} = {r32 / drift:.2f} x the reference's own "
            f"{mode}-autocast drift on this chip ({drift:.3e}); vs ref-{mode}-autocast-on-cuda {r16:.3e}")
     assert r32 < SAME_DEVICE_FACTOR * drift, (r32, drift)
-    del eng
-    torch.cuda.empty_cache()
 
 
 # ---- BASELINE configs[3] / configs[4] as multi-step trajectories at FULL shape (round-4 review, item 10) -------------------------------
@@ -141,18 +119,14 @@ def _engine_trajectory(eng, inp, num_steps, run_steps, mask=None, ip=None):
     return got
 
 
-def _hold_to_device_reference(tag, what, ecfg, tmp_path_factory):
+def _hold_to_device_reference(tag, what, ecfg, device_reference, fullwidth):
     from oracle import gpu_reference as G          # (module import only: the reference packages are imported in the subprocess)
     frames, lat, num_steps, run_steps, seed, ocfg, mask, use_ip = G.TRAJECTORIES[what]()
-    ref = _reference(what, tmp_path_factory)
+    ref = device_reference(what)
     inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
     ip = inp["ip_tokens"] if use_ip else None
-    sd = W.make_weights(W.unet_state_shapes(ocfg), seed=0)
     for dtype, mode in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
-        eng = UNet3DEngine(pack_unet(sd, ecfg, dtype, DEV))
-        got = _engine_trajectory(eng, inp, num_steps, run_steps, mask=mask, ip=ip)
-        del eng
-        torch.cuda.empty_cache()
+        got = _engine_trajectory(fullwidth.engine(ocfg, ecfg, dtype, seed=0), inp, num_steps, run_steps, mask=mask, ip=ip)
         for i in range(run_steps):
             assert torch.isfinite(got[i]).all(), (tag, mode, i)
             r32 = rel(got[i], ref["f32"][i])
@@ -166,18 +140,17 @@ def _hold_to_device_reference(tag, what, ecfg, tmp_path_factory):
                 assert r32 < SAME_DEVICE_FACTOR * drift, (tag, i, r32, drift)
 
 
-@pytest.mark.skipif(os.environ.get("FYC_SLOW_TESTS") != "1", reason="~4 minutes (the reference's f32 forwards at 32f@768^2 take ~50 s each on the chip): "
-                    "FYC_SLOW_TESTS=1; run once per round, numbers in profiles/r05_parity_report.txt")
-def test_cfg3_full_shape_trajectory_vs_device_reference(tmp_path_factory):
-    """BASELINE configs[3]: 32 frames at 768x768 (96x96 latent, 9 216-token spatial attention, 32x32 temporal scores, 32-row positional
+def test_cfg3_full_shape_trajectory_vs_device_reference(device_reference, fullwidth):
+    """(in the default `-m gpu` run since round 6: the reference side comes from the session's background process, tests/conftest.py)
+    BASELINE configs[3]: 32 frames at 768x768 (96x96 latent, 9 216-token spatial attention, 32x32 temporal scores, 32-row positional
     table), the first 2 steps of the 50-step schedule (motion_module.py:286-304, 371-464; diffusers/models/attention.py:649-678)"""
-    _hold_to_device_reference("cfg3 full shape (32f@768^2)", "cfg3", UNet3DConfig(temporal_position_encoding_max_len=32), tmp_path_factory)
+    _hold_to_device_reference("cfg3 full shape (32f@768^2)", "cfg3", UNet3DConfig(temporal_position_encoding_max_len=32), device_reference, fullwidth)
 
 
-def test_cfg4_full_shape_ip_trajectory_vs_device_reference(tmp_path_factory):
+def test_cfg4_full_shape_ip_trajectory_vs_device_reference(device_reference, fullwidth):
     """BASELINE configs[4]: 16 frames at 512x512 with 16 IP-Adapter image tokens (scale 0.7), the rectangle region mask and the first-frame
     concat, the first 2 steps of the 25-step schedule.  On the chip the reference takes its DEPLOYED attention branch (the memory-efficient
     one, animatediff/models/attention.py:92-93, 109-110), which does not carry the CPU path's attn2-temperature quirk: the engine is compared
     with the real reference directly here, not through the no-quirk oracle."""
     _hold_to_device_reference("cfg4 full shape (16f@512^2 + 16 IP tokens + region mask)", "cfg4ip",
-                              UNet3DConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7), tmp_path_factory)
+                              UNet3DConfig(use_ip_cross_attention=True, ip_num_tokens=16, ip_scale=0.7), device_reference, fullwidth)

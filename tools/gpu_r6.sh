@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round-6 GPU calls, one parametrised script:  gpurun -- 'bash tools/gpu_r6.sh <section> [<section> ...]'
+# Everything is written under gpurun_out/r6/; the summaries worth keeping are copied to profiles/ by hand afterwards.
+set -u
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+OUT=gpurun_out/r6
+mkdir -p $OUT
+BASE=${BASE_LIB:-tools/exp/libfyc_base.so}
+benchline() {   # one line per bench JSON: value, gemm roofline, the first kernel families
+  python - "$@" <<'PY'
+import json,sys
+for f in sys.argv[1:]:
+    try:
+        d=json.loads([l for l in open(f) if l.startswith("{")][-1])
+        fam={k:v["ms_per_ddim_step"] for k,v in list(d.get("kernel_families",{}).items())[:9]}
+        print(f, d["value"], "frames/s  ms/ddim-step", round(d["ms_per_step"]/25,2), " gemm", d.get("roofline",{}).get("achieved"), fam)
+    except Exception as e: print(f, "FAILED", e)
+PY
+}
+for sec in "$@"; do
+  echo "=== $sec ($(date +%T)) ==="
+  case $sec in
+    tests)        # the whole -m gpu suite with durations
+      timeout 1500 python -m pytest tests -x -q -m gpu --durations=30 2>&1 | tail -60 | tee $OUT/gpu_tests_durations.txt
+      cp gpurun_out/parity_report.txt $OUT/parity_report.txt 2>/dev/null ;;
+    tests_new)    # only the tests this round added / moved
+      timeout 900 python -m pytest tests -x -q -m gpu -k "split_k or non_finite or clipped_model_output or reference_gpu" --durations=10 2>&1 | tail -30 | tee $OUT/tests_new.txt ;;
+    bench)        # the driver's command
+      timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -3 $OUT/bench_default.err; benchline $OUT/bench_default.json ;;
+    bench_quick)
+      timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_quick.json 2> $OUT/bench_quick.err; benchline $OUT/bench_quick.json ;;
+    bench_ab)     # whole loop: base library vs the in-tree one, alternating
+      for i in 1 2; do
+        FYC_LIB_PATH=$BASE timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_ab_base_$i.json 2> $OUT/bench_ab_base_$i.err
+        timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_ab_new_$i.json 2> $OUT/bench_ab_new_$i.err
+      done
+      benchline $OUT/bench_ab_*.json | tee $OUT/bench_ab.txt ;;
+    probe)        # cold-operand per-shape times of the engine's GEMM calls: PROBE_* environment as tools/gemm_probe.py documents
+      timeout 900 python tools/gemm_probe.py 2>&1 | tee $OUT/probe_${PROBE_TAG:-default}.txt | cut -c1-150 ;;
+    *) echo "unknown section $sec" ;;
+  esac
+done
