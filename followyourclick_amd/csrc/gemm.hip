@@ -62,6 +62,67 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* __restr
   }
 }
 
+// The same finish with the OUTPUT STATISTICS of the LINEAR epilogue (fyc_gemm chan_parts; round 6: the split-K convolutions of the
+// 8x8 level used to send their consumers to the separate fyc_gn_stats pass - 40 launches per forward).  One block = 128 rows (the
+// row tile both split tile configs use: fyc_gemm_stat_layout) x 64 columns: the values go out as above, their rounded copies are
+// parked in LDS and thread (slot, column) adds the rows of its sample slot IN ROW ORDER - no atomics, bitwise repeatable - and writes
+// chan_parts[tile][slot][n] = {sum, sum of squares} of the values as stored.
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_finish_stats_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                                  const float* __restrict__ rowbias, int rows_per_batch, int ldrb,
+                                                                  const T* __restrict__ residual, int ldr, T* __restrict__ out, int ldo,
+                                                                  int M, int N, float out_scale, float* __restrict__ chan_parts, int cs_rows, int cs_slots) {
+  __shared__ float tile[128][64];
+  const int tile_m = blockIdx.x, n0 = blockIdx.y * 64;
+  const int cch = threadIdx.x & 7, rsub = threadIdx.x >> 3;
+  const int n = n0 + cch * 8;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int lr = pass * 32 + rsub, m = tile_m * 128 + lr;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (m < M && n < N) {
+      for (int s = 0; s < S; ++s) {
+        const float* src = ws + ((long long)s * M + m) * N + n;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+      }
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
+      }
+      if (rowbias) {
+        const float* rb = rowbias + (long long)(m / rows_per_batch) * ldrb + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rb[e];
+      }
+      if (residual) {
+        float r[8];
+        load8<T>(residual + (long long)m * ldr + n, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = round_through<T>(v[e] * out_scale);     // the value as stored
+      store8<T>(out + (long long)m * ldo + n, v);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[lr][cch * 8 + e] = v[e];                     // rows / columns outside the problem: 0
+  }
+  __syncthreads();
+  const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;                       // one wave per sample slot (cs_slots <= 4)
+  if (slot < cs_slots && n0 + col < N) {
+    const int first = (tile_m * 128) / cs_rows;
+    const long long lo = (long long)(first + slot) * cs_rows - (long long)tile_m * 128, hi = lo + cs_rows;
+    const int r0 = lo < 0 ? 0 : (int)lo, r1 = hi > 128 ? 128 : (int)hi;
+    float sx = 0.f, sq = 0.f;
+    for (int r = r0; r < r1; ++r) { const float x = tile[r][col]; sx += x; sq = __builtin_fmaf(x, x, sq); }
+    *reinterpret_cast<float2*>(chan_parts + (((long long)tile_m * cs_slots + slot) * N + n0 + col) * 2) = make_float2(sx, sq);
+  }
+}
+
 // Tile / ring-depth choice.  g_fyc_tuning[1] / [2] force a config / depth (bench sweeps, tests).
 void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tile_sweep.txt): the DMA fill rate of the
@@ -93,7 +154,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
   if (g_fyc_tuning[2] > 0) ns = g_fyc_tuning[2];
   // GEGLU pairs 16-column value / gate blocks inside a wave: config 6 gives a wave 5 column blocks (128x320 over 2x4 waves) and
   // used to leave the output unwritten (found by tools/gemm_diag.py at M = 4096 / 8192, N = 2560 - shapes the UNet never issued)
-  if (cfg == 6 && p.epilogue == FYC_EPI_GEGLU) cfg = 5;
+  if ((cfg == 6 || cfg == 11) && p.epilogue == FYC_EPI_GEGLU) cfg = 5;
   if (cfg == 22 && p.epilogue == FYC_EPI_GEGLU) cfg = 21;
   // ping-pong main loop (gemm_pp_kernel.h) for the 8-wave tiles: fyc_set_tuning key 9 = 1 keeps the one-phase loop, 2 forces the
   // ping-pong one wherever it is built; fyc_gemm() falls back to the one-phase twin when the problem does not qualify
@@ -113,7 +174,7 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
 int pp_twin(int cfg) { return cfg == 21 ? 5 : cfg == 22 ? 6 : cfg == 23 ? 7 : cfg == 31 ? 6 : cfg; }
 // column-tile width / row-tile height of a tile config (gemm_kernel.h::dispatch_cfg)
 int tile_bn(int cfg) {
-  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: case 21: case 22: case 31: return 320; case 7: case 23: return 256; default: return 128; }
+  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: case 21: case 22: case 31: return 320; case 7: case 23: return 256; case 11: return 160; default: return 128; }
 }
 int tile_bm(int cfg) {
   switch (cfg) { case 3: case 4: case 5: case 7: case 21: case 23: return 256; default: return 128; }
@@ -139,15 +200,18 @@ void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
 // K slices per output tile (1 = no split) and the tile config a split problem uses
 int split_of(const fyc_gemm_args* a, int& cfg) {
   if (!is16(a->dtype) || a->epilogue != FYC_EPI_LINEAR || a->act != FYC_ACT_NONE || a->batch > 1 || a->tile != 0 || g_fyc_tuning[1] > 0 || g_fyc_tuning[0] == 1) return 1;
-  if (a->ln_stats != nullptr || a->chan_parts != nullptr || a->row_parts != nullptr) return 1;
-  if (a->M > 4096 || a->K < 2048 || a->N % 8 != 0 || a->N < 256) return 1;
+  if (a->ln_stats != nullptr || a->row_parts != nullptr) return 1;      // (chan_parts: the finish kernel writes them, round 6)
+  // fyc_set_tuning key 10 = v > 0 (A/B): at least v K tiles per slice instead of 16, and K >= 128 v instead of 2048 - the K = 1280 linears
+  // of the 8x8 latent level (profiles/r06_gemm_small_m_split_k.txt)
+  const int min_kt = g_fyc_tuning[10] > 0 ? g_fyc_tuning[10] : 16;
+  if (a->M > 4096 || a->K < (g_fyc_tuning[10] > 0 ? 128 * min_kt : 2048) || a->N % 8 != 0 || a->N < 256) return 1;
   const int c = (a->N % 320 == 0) ? 6 : 1;                     // 128x320 or 128x128 tiles
   const int bn = (c == 6) ? 320 : 128;
   const long long tiles = (long long)((a->M + 127) / 128) * ((a->N + bn - 1) / bn);
   const int kt = (a->K + 63) / 64;
   int s = (int)(256 / tiles);
   if (s > 8) s = 8;
-  while (s > 1 && kt / s < 16) --s;                            // keep >= 16 K tiles per slice
+  while (s > 1 && kt / s < min_kt) --s;                        // keep >= 16 K tiles per slice
   if (s < 2) return 1;
   cfg = c;
   return s;
@@ -173,7 +237,10 @@ extern "C" int fyc_gemm_stat_layout(const fyc_gemm_args* a, int32_t* tile_rows, 
   if (a == nullptr || a->M <= 0 || a->cs_rows <= 0) return 0;
   int cfg = 1, ns = 2;
   pick(a, cfg, ns, true);
-  const int bm = tile_bm(cfg);
+  int scfg = 0;
+  fyc_gemm_args q = *a;                     // (the query carries no pointers: split_of() must see the call as the engine will make it)
+  q.chan_parts = nullptr; q.row_parts = nullptr; q.ln_stats = nullptr; q.act = FYC_ACT_NONE; q.epilogue = FYC_EPI_LINEAR;
+  const int bm = split_of(&q, scfg) > 1 ? 128 : tile_bm(cfg);      // split-K problems: the finish kernel's 128-row blocks
   if (tile_rows) *tile_rows = bm;
   if (slots) *slots = stat_slots(bm, a->cs_rows);
   return (a->M + bm - 1) / bm;
@@ -323,10 +390,12 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
                        (a->rowbias == nullptr || p.rows_per_batch % bm == 0 || fycg::rowbias_slots(bm, p.rows_per_batch) > 0) && split_of(a, scfg0) <= 1;
     if (!ov_ok) cfg = pp_twin(cfg);
   }
-  if (cfg == 6 && a->epilogue == FYC_EPI_GEGLU) cfg = 5;      // (a fallback above may land on the one tile GEGLU is not built for)
+  if ((cfg == 6 || cfg == 11) && a->epilogue == FYC_EPI_GEGLU) cfg = 5;      // (a fallback above may land on the one tile GEGLU is not built for)
   {
     int scfg = 0;
     const int sk = split_of(a, scfg);
+    FYC_REQUIRE(!(sk > 1 && a->chan_parts != nullptr) || (p.wide && a->workspace != nullptr && a->workspace_bytes >= (int64_t)sk * a->M * a->N * 4 && ((uintptr_t)a->workspace % 16) == 0),
+                "fyc_gemm: chan_parts of a split-K problem (fyc_gemm_workspace_bytes() > 0) are laid out for its finish kernel: pass the workspace (and 16-byte aligned operands)");
     if (sk > 1 && p.wide && a->workspace != nullptr && a->workspace_bytes >= (int64_t)sk * a->M * a->N * 4 && ((uintptr_t)a->workspace % 16) == 0) {
       GemmP q = p;
       q.splitk = sk; q.ws = (float*)a->workspace;
@@ -337,6 +406,17 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
                      : f16 ? ((a->mode == FYC_GEMM_PLAIN) ? fycg::run_f16_plain(q, batch, scfg, 2, st) : fycg::run_f16_conv(q, batch, scfg, 2, st))
                      : (a->mode == FYC_GEMM_PLAIN) ? fycg::run_bf16_plain(q, batch, scfg, 2, st) : fycg::run_bf16_conv(q, batch, scfg, 2, st);
       if (rc != 0) return rc;
+      if (a->chan_parts != nullptr) {
+        const dim3 grid((a->M + 127) / 128, (a->N + 63) / 64);
+        if (f16)
+          hipLaunchKernelGGL(splitk_finish_stats_kernel<f16_t>, grid, dim3(256), 0, st, (const float*)a->workspace, sk, a->bias, a->rowbias, p.rows_per_batch, p.ldrb,
+                             (const f16_t*)a->residual, a->ldr, (f16_t*)a->out, a->ldo, a->M, a->N, a->out_scale, a->chan_parts, a->cs_rows, p.cs_slots);
+        else
+          hipLaunchKernelGGL(splitk_finish_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const float*)a->workspace, sk, a->bias, a->rowbias, p.rows_per_batch, p.ldrb,
+                             (const bf16_t*)a->residual, a->ldr, (bf16_t*)a->out, a->ldo, a->M, a->N, a->out_scale, a->chan_parts, a->cs_rows, p.cs_slots);
+        FYC_CHECK_LAUNCH("fyc_gemm split-K finish + statistics");
+        return 0;
+      }
       const long long items = (long long)a->M * (a->N / 8);
       const int blocks = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
       if (f16)

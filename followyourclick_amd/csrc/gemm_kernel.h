@@ -986,6 +986,11 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     char* sA = smem + stage * STAGE;
     char* sB = sA + A_BYTES;
     const int k0 = kt * BK;
+#ifdef FYC_ABLATE_CONV_A
+    // TIMING BUILD (wrong results): the A gather of a 3x3 convolution is issued for `FYC_ABLATE_CONV_A` of the 9 taps of a slab only -
+    // the upper bound of what a halo tile of the input in LDS (each pixel fetched once per slab, read by all nine taps) could save
+    if (MODE == FYC_GEMM_PLAIN || tap < FYC_ABLATE_CONV_A)
+#endif
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) glds16(src_a(it, k0), sA + (it * NT + wave * 64) * 16);
 #pragma unroll
@@ -1166,6 +1171,11 @@ int dispatch_cfg(int cfg, int ns, const GemmP& p, int batch, hipStream_t st) {
       // 64-byte K tiles: half the LDS per stage -> two independent 4-wave blocks per CU with 64x160 wave tiles (8)
       case 8: return launch<T, 128, 320, 2, 2, MODE, EPI, 2, 64, true>(p, batch, st);
       case 10: return launch<T, 128, 128, 2, 2, MODE, EPI, 2, 64, true>(p, batch, st);
+      // round 6: 128x160 over 2x2 waves (64x80 per wave, the wave tile of config 6) with 72 KB of ring: TWO independent workgroups per CU,
+      // so one's epilogue / first fill runs under the other's K loop - for the short-K problems whose 128x320 tiles spend as long in the
+      // epilogue as in the K loop (profiles/r06_gemm_two_workgroups_ab.txt)
+      case 11: if constexpr (EPI == FYC_EPI_GEGLU) FYC_FAIL(-2, "fyc_gemm: tile config 11 gives a wave an odd number of column blocks: not built for GEGLU");
+               else return launch<T, 128, 160, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
     }
     FYC_FAIL(-2, "fyc_gemm: tile config %d not built", cfg);
   }

@@ -45,13 +45,14 @@ int fyc_init(const void* zero_page);
 /* fills caps[0..7]: CU count, LDS bytes/CU, wave size, gfx arch number (950), clock kHz, L2 bytes, 0, 0 */
 int fyc_device_caps(int64_t* caps);
 /* tuning knobs for A/B measurements (0 = automatic): key 0 = 1 disables split-K, key 1 = GEMM tile config (1: 128x128/4 waves, 2: 128x64/4,
- * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
+ * 3: 256x128/8, 4: 256x64/4, 5: 256x320/8, 6: 128x320/8, 7: 256x256/8, 8/10: 128x320 / 128x128 with 64-byte K tiles, 11: 128x160/4 waves, two workgroups per CU), key 2 = GEMM LDS ring depth (2..4), key 3 = attention kernel variant,
  * key 4 = column-strip width of the GEMM tile order (-1: row-major), key 5 = 1 disables the wave-role stagger of the 8-wave GEMM tiles, key 6 = 1 disables the LDS-staged wide epilogues, key 7 = 1 only the wide head-split one,
  * keys 8 / 9 only act in a library built with FYC_GEMM_VARIANTS=1 (tools/exp/gemm_variants/: the round-4 main-loop experiments, measured slower,
  * not part of the product library): key 8 = 1: no s_setprio around the MFMA phases of the ping-pong loop; key 9 = 2: the ping-pong loop (tile
  * configs 21 / 22 / 23) wherever it is built, 3: the overlapped-epilogue kernel (config 31).  In the product library key 9 is ignored and a
  * request for one of those tile configs runs its one-phase twin (5 / 6 / 7 / 6): the one-phase loop always;
- * keys 10..15 reserved */
+ * key 10 = v > 0: split-K for M <= 4096 keeps at least v K tiles per slice (default 16) and starts at K >= 128 v (default 2048);
+ * keys 11..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------

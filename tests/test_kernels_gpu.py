@@ -46,8 +46,8 @@ def close(hip_t, emu_t, tag, rtol):
 
 
 # ---------------------------------------------------------------------------------------------
-PLAIN_TILES = [(0, 0), (1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)]
-CONV_TILES = [(0, 0), (1, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2)]
+PLAIN_TILES = [(0, 0), (1, 2), (1, 3), (2, 2), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (11, 2)]
+CONV_TILES = [(0, 0), (1, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (10, 2), (11, 2)]
 
 
 def _dt_tiles(tiles):
@@ -173,6 +173,31 @@ def test_gemm_heads(hip, emu, dt, tokens, heads, d):
         close(oh[i], oe[i], f"heads {dt} seg {n}", RTOL[dt])
 
 
+@pytest.mark.parametrize("tile", [1, 5, 6, 11])
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_gemm_heads_every_wide_tile(hip, emu, dt, tile):
+    """the wide head-split epilogue (q / k as 16-byte runs along the head dim, V^T along the token axis) at the SD-1.5 level-0 width
+    (N = 3 x 320, d = 40) with a folded LayerNorm, on every tile config the engine may give it - incl. 128x160 (round 6)"""
+    T = DT[dt]
+    Bn, heads, d, tokens, K = 5, 8, 40, 64, 320
+    C, M = heads * d, Bn * tokens
+    a, w, bias = rnd((M, K), T, 1), rnd((3 * C, K), T, 2, 1 / math.sqrt(K)), rnd((3 * C,), torch.float32, 3)
+    st = torch.stack([0.1 * rnd((M,), torch.float32, 4), 1 + 0.1 * rnd((M,), torch.float32, 5).abs()], dim=1).contiguous()
+    cs = rnd((3 * C,), torch.float32, 6)
+
+    def outs(dev):
+        return [torch.zeros(Bn, heads, tokens, d, dtype=T, device=dev), torch.zeros(Bn, heads, tokens, d, dtype=T, device=dev),
+                torch.zeros(Bn, heads, d, tokens, dtype=T, device=dev)]
+    oh, oe = outs("cuda"), outs("cpu")
+    kw = dict(M=M, N=3 * C, K=K, lda=K, ldw=K, epilogue=2)
+    hip.gemm(a.cuda(), w.cuda(), None, bias=bias.cuda(), ln_stats=st.cuda(), ln_colsum=cs.cuda(), tile=tile,
+             heads=dict(seg_cols=C, heads=heads, tokens=tokens, outs=oh, transposed=[0, 0, 1], ld=[0, 0, tokens]), **kw)
+    torch.cuda.synchronize()
+    emu.gemm(a, w, None, bias=bias, ln_stats=st, ln_colsum=cs, heads=dict(seg_cols=C, heads=heads, tokens=tokens, outs=oe, transposed=[0, 0, 1], ld=[0, 0, tokens]), **kw)
+    for i, n in enumerate("qkv"):
+        close(oh[i], oe[i], f"heads {dt} tile {tile} seg {n}", RTOL[dt])
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32", "f16"])
 @pytest.mark.parametrize("M,C", [(300, 64), (1000, 320)])
 def test_gemm_dual_source_k(hip, emu, dt, M, C):
@@ -264,7 +289,7 @@ def test_attention_peaked_softmax(hip, emu):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("d,n", [(40, 320), (80, 200), (160, 150)])
+@pytest.mark.parametrize("d,n", [(40, 320), (80, 200), (160, 152)])
 def test_attention_propagates_non_finite_inputs(hip, dt, d, n):
     """round-5 advisor: the attention sources are built with -fno-honor-nans (no sNaN-quieting maxima in the softmax).  A NaN or an
     overflowed (Inf) query / key from an upstream layer must still come out NON-FINITE - bench.py's isfinite() assert and the parity
@@ -949,7 +974,7 @@ def test_ddim_three_way_guidance(hip, emu, dt):
 
 
 # ---- statistics fused into the producing epilogue (fyc_gemm chan_stats / row_parts, fyc_gn_apply_cs) --------------------------
-STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7]
+STAT_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 11]
 
 
 @pytest.mark.parametrize("dt,tile", [("bf16", t) for t in STAT_TILES] + [("f32", 0)] + [("f16", t) for t in (0, 5, 6)])
@@ -1105,3 +1130,42 @@ def test_gemm_split_k(hip, emu, kind, M, N, K, res):
     finally:
         hip.set_tuning(0, 0)
     close(o_p, o_e, f"unsplit {kind} {M}x{N}x{K}", RTOL["bf16"])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("kind,M,N,K,cs_rows,res", [("conv", 2048, 1280, 11520, 64, True), ("conv", 2048, 1280, 23040, 64, False), ("gemm", 2048, 1280, 6400, 64, True),
+                                                    ("gemm", 1008, 640, 2560, 48, False), ("conv", 512, 320, 5760, 64, False)])
+def test_gemm_split_k_output_statistics(hip, emu, dt, kind, M, N, K, cs_rows, res):
+    """round 6: the split-K finish kernel writes the per-(128-row tile, sample slot, channel) sums of the values it stores - the 8x8-level
+    convolutions no longer send their consumers to the separate statistics pass - in the layout fyc_gemm_stat_layout announces; bitwise
+    repeatable (ordered adds, no atomics), incl. samples that straddle tiles (48-row samples) and a ragged last tile"""
+    T = DT[dt]
+    w, bias = rnd((N, K), T, 2, 1 / math.sqrt(K)), rnd((N,), torch.float32, 3)
+    r = rnd((M, N), T, 4) if res else None
+    if kind == "conv":
+        Cin, side = K // 9, 8
+        a = rnd((M, Cin), T, 1)
+        kw = dict(M=M, N=N, K=K, lda=Cin, ldw=K, ldo=N, ldr=N, mode=1, conv=dict(Hout=side, Wout=side, Hin=side, Win=side, Cin=Cin, stride=1))
+    else:
+        a = rnd((M, K), T, 1)
+        kw = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, ldr=N)
+    assert hip.gemm_split_bytes(T, M=M, N=N, K=K, mode=kw.get("mode", 0)) > 0, "this shape is expected to take the split-K path"
+    nt, tile_rows, slots = hip.gemm_stat_layout(T, M=M, N=N, K=K, cs_rows=cs_rows, mode=kw.get("mode", 0))
+    assert tile_rows == 128 and nt == (M + 127) // 128 and 1 <= slots <= 4, (nt, tile_rows, slots)
+    outs, parts_all = [], []
+    for it in range(3):
+        parts = torch.full((nt * slots * N * 2,), float("nan"), device="cuda")
+        o_h = torch.full((M, N), float("nan"), dtype=T, device="cuda")
+        hip.gemm(a.cuda(), w.cuda(), o_h, bias=bias.cuda(), residual=None if r is None else r.cuda(), chan_parts=parts, cs_rows=cs_rows, **kw)
+        torch.cuda.synchronize()
+        outs.append(o_h.cpu())
+        parts_all.append(parts.cpu())
+    assert torch.equal(parts_all[0], parts_all[1]) and torch.equal(parts_all[0], parts_all[2]), "column sums differ between launches"
+    o_e = torch.zeros(M, N, dtype=T)
+    emu.gemm(a, w, o_e, bias=bias, residual=r, **kw)
+    close(outs[0], o_e, f"split-K + stats {dt} {kind} {M}x{N}x{K}", RTOL[dt] if dt == "bf16" else 6e-4)
+    cs = torch.zeros(M // cs_rows, N, 2, dtype=torch.float64, device="cuda")
+    hip.chan_stats_reduce(parts_all[0].cuda(), cs, rows=M, N=N, cs_rows=cs_rows, tile_rows=tile_rows, slots=slots)
+    torch.cuda.synchronize()
+    v = outs[0].double().reshape(M // cs_rows, cs_rows, N)
+    close(cs, torch.stack([v.sum(dim=1), (v * v).sum(dim=1)], dim=-1), f"split-K chan stats {dt} {kind} ({slots} slots)", 2e-6)

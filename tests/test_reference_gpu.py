@@ -125,17 +125,27 @@ def _hold_to_device_reference(tag, what, ecfg, device_reference, fullwidth):
     ref = device_reference(what)
     inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
     ip = inp["ip_tokens"] if use_ip else None
+    eng_f32 = {}
     for dtype, mode in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
         got = _engine_trajectory(fullwidth.engine(ocfg, ecfg, dtype, seed=0), inp, num_steps, run_steps, mask=mask, ip=ip)
+        if mode == "f32":
+            eng_f32 = got
         for i in range(run_steps):
             assert torch.isfinite(got[i]).all(), (tag, mode, i)
-            r32 = rel(got[i], ref["f32"][i])
-            drift = rel(ref["bf16"][i], ref["f32"][i])
+            # the f32 side of step i: the reference's own f32 run where it was computed (oracle.gpu_reference.F32_STEPS: configs[3] runs ONE
+            # f32 step of the reference, ~50 s of eager kernels at 32f@768^2); beyond that the engine's f32 run, which the steps before
+            # have just held to the reference's to ~1e-7 and which tests/test_fullwidth_gpu.py pins at this shape against a stored golden
+            have_ref32 = i in ref["f32"] if isinstance(ref["f32"], dict) else i < len(ref["f32"])
+            f32_side = ref["f32"][i] if have_ref32 else eng_f32[i]
+            side = "the reference's f32 run on this chip" if have_ref32 else "the engine's f32 run (held to the reference's at the steps before)"
+            r32 = rel(got[i], f32_side)
+            drift = rel(ref["bf16"][i], f32_side)
             if mode == "f32":
-                report(f"{tag} step {i} engine f32 vs the reference's f32 run on this chip: {r32:.3e}")
-                assert r32 < 1e-3, (tag, i, r32)
+                if have_ref32:
+                    report(f"{tag} step {i} engine f32 vs {side}: {r32:.3e}")
+                    assert r32 < 1e-3, (tag, i, r32)
             else:
-                report(f"{tag} step {i} engine bf16 vs ref-f32-on-cuda {r32:.3e} = {r32 / drift:.2f} x the reference's own bf16-autocast drift ({drift:.3e}); "
+                report(f"{tag} step {i} engine bf16 vs {side} {r32:.3e} = {r32 / drift:.2f} x the reference's own bf16-autocast drift ({drift:.3e}); "
                        f"vs ref-bf16-autocast-on-cuda {rel(got[i], ref['bf16'][i]):.3e}")
                 assert r32 < SAME_DEVICE_FACTOR * drift, (tag, i, r32, drift)
 

@@ -12,7 +12,7 @@ T = torch.bfloat16
 DEV = torch.device("cuda:0")
 
 
-def run(h, M, N, K, *, epi=0, res=False, ln=False, rowbias=False, stats=False, nb=1, tile=0, reps=6, conv=None, k2=0):
+def run(h, M, N, K, *, epi=0, res=False, ln=False, rowbias=False, stats=False, nb=1, tile=0, reps=6, conv=None, k2=0, segs=0):
     ocols = N // 2 if epi == 1 else N
     sets = []
     for _ in range(nb):
@@ -38,6 +38,13 @@ def run(h, M, N, K, *, epi=0, res=False, ln=False, rowbias=False, stats=False, n
     if rowbias:
         kw["rowbias"] = torch.randn(32, N, device=DEV)
         kw["rows_per_batch"] = M // 32
+    if epi == 2:      # head-split epilogue: `segs` segments of C = N / segs columns (q | k | V^T, or q alone), 8 heads, 32 frames of M / 32 tokens
+        Cc, tok = N // segs, M // 32
+        d = Cc // 8
+        outs = [torch.empty(32, 8, tok, d, dtype=T, device=DEV) for _ in range(min(segs, 2))] + ([torch.empty(32, 8, d, tok, dtype=T, device=DEV)] if segs == 3 else [])
+        kw.update(heads=dict(seg_cols=Cc, heads=8, tokens=tok, outs=outs, transposed=[0, 0, 1][:segs], ld=[0, 0, tok][:segs]))
+        for i in range(len(sets)):
+            sets[i] = (sets[i][0], None, None)
     if stats:
         n, tr, sl = h.gemm_stat_layout(T, M=M, N=N, K=K, cs_rows=M // 32, mode=1 if conv else 0, tile=tile)
         kw["chan_parts"] = torch.empty(n * sl * N * 2, device=DEV)
@@ -64,6 +71,10 @@ def sweep(h):
         ("FF1 GEGLU L2 ln", 8192, 10240, 1280, dict(epi=1, ln=True)),
         ("tQKV L0 ln rb", 131072, 960, 320, dict(ln=True, rowbias=True)), ("tQKV L1 ln rb", 32768, 1920, 640, dict(ln=True, rowbias=True)),
         ("tQKV L2 ln rb", 8192, 3840, 1280, dict(ln=True, rowbias=True)),
+        ("sQKV L0 heads ln", 131072, 960, 320, dict(epi=2, ln=True, segs=3)), ("sQKV L1 heads ln", 32768, 1920, 640, dict(epi=2, ln=True, segs=3)),
+        ("sQKV L2 heads ln", 8192, 3840, 1280, dict(epi=2, ln=True, segs=3)),
+        ("q2 L0 heads ln", 131072, 320, 320, dict(epi=2, ln=True, segs=1)), ("q2 L1 heads ln", 32768, 640, 640, dict(epi=2, ln=True, segs=1)),
+        ("q2 L2 heads ln", 8192, 1280, 1280, dict(epi=2, ln=True, segs=1)),
         ("to_out L0 res", 131072, 320, 320, dict(res=True)), ("to_out L1 res", 32768, 640, 640, dict(res=True)),
         ("to_out L2 res", 8192, 1280, 1280, dict(res=True)), ("to_out L3 res", 2048, 1280, 1280, dict(res=True)),
         ("proj_in L0", 131072, 320, 320, dict()), ("proj_in L1", 32768, 640, 640, dict()),

@@ -38,6 +38,16 @@ for sec in "$@"; do
       benchline $OUT/bench_ab_*.json | tee $OUT/bench_ab.txt ;;
     probe)        # cold-operand per-shape times of the engine's GEMM calls: PROBE_* environment as tools/gemm_probe.py documents
       timeout 900 python tools/gemm_probe.py 2>&1 | tee $OUT/probe_${PROBE_TAG:-default}.txt | cut -c1-150 ;;
+    gemm_parity)  # what changed in the GEMM family this round (tile config 11, split-K statistics)
+      timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_kernels_f16_gpu.py -x -q -k "test_gemm_plain or test_gemm_conv or output_statistics or heads or split_k or geglu" 2>&1 | tail -6 | tee $OUT/gemm_parity.txt ;;
+    gemm_ab)      # cold-operand per-shape sweep over the tile configs incl. 128x160 x 2 workgroups (11); small-M split-K policies; A-gather ablation
+      PROBE_SWEEP=1 PROBE_CFGS=0,5,6,11,1 timeout 900 python tools/gemm_probe.py > $OUT/probe_tiles.txt 2>&1; cut -c1-120 $OUT/probe_tiles.txt
+      PROBE_SWEEP=1 PROBE_SMALL=1 PROBE_CFGS=0,2,1,6,11 timeout 600 python tools/gemm_probe.py > $OUT/probe_small_tiles.txt 2>&1; cut -c1-120 $OUT/probe_small_tiles.txt
+      for v in 4 5 7 10; do
+        PROBE_TUNING=10=$v PROBE_SWEEP=1 PROBE_SMALL=1 PROBE_CFGS=0 timeout 600 python tools/gemm_probe.py > $OUT/probe_small_splitk$v.txt 2>&1; echo "-- split-K min K tiles $v"; cut -c1-120 $OUT/probe_small_splitk$v.txt
+      done
+      echo "-- A gather of 1 tap in 9 only (timing build, upper bound of a halo tile)"
+      FYC_LIB_PATH=tools/exp/libfyc_ablate_a1.so PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep -i "conv\|case" | tee $OUT/probe_conv_ablate_a1.txt | cut -c1-120 ;;
     *) echo "unknown section $sec" ;;
   esac
 done
