@@ -58,6 +58,7 @@ struct GemmP {
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
   int res_acc;   // bf16 LINEAR wide epilogue: the residual tile is loaded INTO the accumulators before the K loop (see epilogue_linear_packed)
+  int phase_delay;   // round 6 (A/B, fyc_set_tuning key 11): every other block of an XCD starts this many x 1024 cycles late, see fyc_gemm_kernel
   unsigned long long* trace;   // timing builds (-DFYC_TRACE, tools/gemm_phase_probe.py): per-block s_memtime stamps; nullptr otherwise
 };
 
@@ -1005,6 +1006,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     }
   };
 
+  // Phase shift (round 6).  Every block of a launch runs identical tiles, so all 256 CUs reach their epilogue TOGETHER: ~42 MB of stores
+  // leave in one burst at ~2.2 TB/s while the K-loop phases in between leave the HBM write path idle (profiles/r04_gemm_phase_trace.txt),
+  // and - loads and stores retire in order on one counter - a wave cannot start the next tile's K loop before its stores are acknowledged.
+  // Starting every other block of an XCD half a tile period late puts one half of the chip's epilogues beside the other half's K loops.
+  if (p.phase_delay > 0 && ((blockIdx.x >> 3) & 1)) {
+    for (int i = 0; i < p.phase_delay; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   // ---- main loop: NS-deep ring over the continuous K-tile stream, counted waits -------------------
   const int nwork = ntiles * S;
   int i_tile = blockIdx.x, i_kt = 0, i_kt_end = 0;   // issue side of the stream (i_tile: work item being issued)
@@ -1121,6 +1129,7 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
   q.rb_slots = (WIDE && EPI == FYC_EPI_LINEAR && p.rowbias != nullptr && !q.rb_tile) ? rowbias_slots(BM, p.rows_per_batch) : 0;
   q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
+  q.phase_delay = g_fyc_tuning[11] > 0 ? g_fyc_tuning[11] : 0;
   q.res_acc = (WIDE && EPI == FYC_EPI_LINEAR && p.residual != nullptr && p.ln_stats == nullptr && !(q.splitk > 1)) ? 1 : 0;
 #ifdef FYC_TRACE
   q.trace = g_fyc_trace;

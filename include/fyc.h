@@ -52,7 +52,8 @@ int fyc_device_caps(int64_t* caps);
  * configs 21 / 22 / 23) wherever it is built, 3: the overlapped-epilogue kernel (config 31).  In the product library key 9 is ignored and a
  * request for one of those tile configs runs its one-phase twin (5 / 6 / 7 / 6): the one-phase loop always;
  * key 10 = v > 0: split-K for M <= 4096 keeps at least v K tiles per slice (default 16) and starts at K >= 128 v (default 2048);
- * keys 11..15 reserved */
+ * key 11 = v > 0: every other GEMM block of an XCD starts v x 1024 cycles late (phase shift between the CUs' epilogues, A/B);
+ * keys 12..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------

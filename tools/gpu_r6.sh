@@ -48,6 +48,11 @@ for sec in "$@"; do
       done
       echo "-- A gather of 1 tap in 9 only (timing build, upper bound of a halo tile)"
       FYC_LIB_PATH=tools/exp/libfyc_ablate_a1.so PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep -i "conv\|case" | tee $OUT/probe_conv_ablate_a1.txt | cut -c1-120 ;;
+    phase_ab)     # every other block of an XCD starts v x 1024 cycles late: per-shape sweep
+      for v in 0 8 16 24 32 48 64; do
+        echo "-- phase delay $v x 1024 cycles"
+        PROBE_TUNING=11=$v PROBE_SWEEP=1 PROBE_CFGS=${PHASE_CFGS:-0,5,6,11} timeout 600 python tools/gemm_probe.py > $OUT/probe_phase$v.txt 2>&1; grep -v amdgpu.ids $OUT/probe_phase$v.txt | cut -c1-110
+      done ;;
     *) echo "unknown section $sec" ;;
   esac
 done
