@@ -58,6 +58,7 @@ struct GemmP {
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
   int res_acc;   // bf16 LINEAR wide epilogue: the residual tile is loaded INTO the accumulators before the K loop (see epilogue_linear_packed)
+  int pre;     // round 6: the epilogue's per-row / per-column inputs are already in LDS (issue_consts in fyc_gemm_kernel), see pre_bytes()
   int phase_delay;   // round 6 (A/B, fyc_set_tuning key 11): every other block of an XCD starts this many x 1024 cycles late, see fyc_gemm_kernel
   unsigned long long* trace;   // timing builds (-DFYC_TRACE, tools/gemm_phase_probe.py): per-block s_memtime stamps; nullptr otherwise
 };
@@ -247,6 +248,21 @@ __device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc,
   __builtin_amdgcn_s_barrier();
 }
 
+// ---- epilogue inputs pre-staged by DMA (round 6) -------------------------------------------------------------------------------------------
+// profiles/r06_gemm_epilogue_ablation.txt: of the 103 us the epilogues of the 131072x960x320 projection cost (178 us per launch), 54 are
+// "pass 1" - and that is not its arithmetic but two exposed round trips: the column constants (stage_col_constants) and the LayerNorm row
+// statistics (ln_row) are global loads, loads retire in order, and the next tile's first K-tile DMA is in flight in front of them - every
+// tile of every launch paid the DMA's HBM latency plus its own.  The wide epilogues of the 2-deep-ring kernels now find their inputs in LDS:
+// behind the FIRST barrier of a tile's K loop (every wave has left the previous tile's epilogue) the waves fetch, by global_load_lds,
+//   [BM] {mean, rstd} | [BN] bias | [BN] LayerNorm column sums | [<= RB_SLOTS][BN] row-bias rows
+// into a region behind the ring; the K loop's own vmcnt(0) + barrier of the next iteration retires them (host: GemmP::pre needs >= 2 K tiles
+// per tile).  No global load and no vmcnt wait is left in those epilogues.
+template <int BM, int BN> constexpr int pre_bytes() { return BM * 8 + (2 + RB_SLOTS) * BN * 4; }
+template <int BM> __device__ __forceinline__ void pre_ln_row(const char* pre, int row_in_tile, float& mu, float& rs) {
+  const float2 ms = *reinterpret_cast<const float2*>(pre + row_in_tile * 8);
+  mu = ms.x; rs = ms.y;
+}
+
 // ---- bf16 LINEAR epilogue, "pack first" (round 4) ---------------------------------------------------------------------------------
 // s_memtime stamps (profiles/r04_gemm_phase_trace.txt) showed the epilogue of a 256x320 tile with residual + output statistics at
 // 125 000 cycles against 175 000 for its whole 45-K-tile loop: 160 live accumulators + two sets of prefetched residual rows + the
@@ -264,9 +280,16 @@ __device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc,
 //     256x320 tile instead of 8 half-width f32 ones) and stores / accumulates the statistics from 16-byte row segments as before.
 template <typename T, int BM, int BN, int WGM, int WGN, int STG_BYTES, int MODE>
 __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
-                                                       long long bz, char* stg_stage, int wave, int lane) {
+                                                       long long bz, char* stg_stage, int wave, int lane, const char* pre) {
   static_assert(sizeof(T) == 2, "16-bit outputs only (bf16 / f16)");
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+#if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 3      // TIMING BUILDS (wrong results), tools/gpu_r6.sh epi_ablation: 3 = no epilogue at all
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+  return;
+#endif
   constexpr bool LN = (MODE == FYC_GEMM_PLAIN);
   constexpr int PITCH = WTN * 32 + 16;               // bytes per staged row: the wave's WTN * 16 bf16 columns + 16 (keeps the 16-byte reads aligned)
   constexpr int CPR = WTN * 2;                       // 16-byte chunks per staged row
@@ -281,6 +304,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;   // batched problems (materialised attention of the VAE): one output per batch element
   __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
   char* stg = stg_stage + wave * SLICE;
+  const bool use_pre = pre != nullptr;                 // (wave-uniform, the same for every tile of a launch)
   float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * SLICE);   // [2][BN], see stage_col_constants
   float* cacc = colc + 2 * BN;
   float* racc = cacc + stat_arrays<WGM>() * BN * 2;
@@ -289,7 +313,13 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   constexpr bool RB_FIT = WGM * WGN * SLICE + 2 * BN * 4 + stat_bytes<BM, BN, WGM>() + RB_SLOTS * BN * 4 <= STG_BYTES;
   float* rbc = (RB_FIT && p.rb_slots > 0) ? racc + BM * 2 : nullptr;
   if (do_cs || do_rp) stats_zero<BM, BN, WGM, WGM * WGN * 64>(cacc, wave * 64 + lane);
-  stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane, rbc);
+  if (use_pre) {                                       // inputs already in LDS: [bias | colsum | row-bias rows] behind the row statistics
+    colc = reinterpret_cast<float*>(const_cast<char*>(pre) + BM * 8);
+    rbc = p.rowbias != nullptr ? colc + 2 * BN : nullptr;
+    if (do_cs || do_rp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // the zeroed accumulators
+  } else {
+    stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane, rbc);
+  }
   const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
   const int nl_w0 = wn * WTN * 16;                   // ... inside the tile
   // ---- pass 1: final values, packed in place --------------------------------------------------------------------------------------
@@ -302,7 +332,10 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   for (int i = 0; i < WTM; ++i) {
     const int m0 = tile_m * BM + (wm * WTM + i) * 16;
     mu[i] = 0.f; rs[i] = 1.f;
-    if (LN && p.ln_stats && m0 + r16 < p.M) ln_row(p, m0 + r16, mu[i], rs[i]);
+    if (LN && p.ln_stats) {
+      if (use_pre) pre_ln_row<BM>(pre, (wm * WTM + i) * 16 + r16, mu[i], rs[i]);      // (rows beyond M: {0, 0} from the zero page, never stored)
+      else if (m0 + r16 < p.M) ln_row(p, m0 + r16, mu[i], rs[i]);
+    }
     rbo[i] = rbc != nullptr ? (m0 / p.rows_per_batch - (tile_m * BM) / p.rows_per_batch) * BN : 0;
   }
   // (scheduling fences: left alone, hipcc hoists the constant reads of ALL column blocks to the top - 80 registers - and sinks the
@@ -339,6 +372,13 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 2      // 2 = pass 1 only (final values packed in registers, nothing staged or stored)
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(pk[i][j][0]), "v"(pk[i][j][1]));
+  return;
+#endif
   // ---- pass 2: 16 rows x (WTN * 16) columns per step through the wave's staging slice ---------------------------------------------
   const int lrow = lane / CPR, lch = lane - lrow * CPR;
   const bool lact = lrow < RPP;
@@ -394,7 +434,11 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
       const bool live = lact && row < 16 && m < p.M && n_lane < p.N;
       if (live) {
         const u32x4 v4 = *reinterpret_cast<const u32x4*>(stg + row * PITCH + lch * 16);
+#if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 1      // 1 = everything but the global stores
+        asm volatile("" :: "v"(v4[0]), "v"(v4[1]), "v"(v4[2]), "v"(v4[3]));
+#else
         *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n_lane) = v4;   // (nt stores: same GEMM time, consumers +10 %: profiles/r04_epilogue_nontemporal_ab.txt)
+#endif
         if (do_cs || do_rp) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -458,7 +502,7 @@ __device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[B
 // in one kernel the narrow loops no longer unrolled and the whole accumulator array lived in scratch).
 template <typename T, int BM, int BN, int WGM, int WGN, int EPI, int STG_BYTES, int MODE, bool WIDE>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
-                                              long long bz, char* stg_stage, int wave, int lane) {
+                                              long long bz, char* stg_stage, int wave, int lane, const char* pre) {
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
   constexpr bool LN = (MODE == FYC_GEMM_PLAIN);   // the folded LayerNorm only exists for plain GEMMs: keep it out of the conv kernels
   const int wm = wave / WGN, wn = wave % WGN;
@@ -478,13 +522,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     __builtin_amdgcn_s_barrier();
     char* stg = stg_stage + wave * (16 * PITCH);
     float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * 16 * PITCH);
-    stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+    if (pre != nullptr) colc = reinterpret_cast<float*>(const_cast<char*>(pre) + BM * 8);      // pre-staged inputs (issue_consts)
+    else stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
     const int n_w0 = tile_n * BN + wn * WTN * 16, nl_w0 = wn * WTN * 16;
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int m0 = tile_m * BM + (wm * WTM + i) * 16;            // first of the 16 token rows of this block (same batch element)
       float ln_mu = 0.f, ln_rs = 1.f;
-      if (LN && p.ln_stats && m0 + r16 < p.M) ln_row(p, m0 + r16, ln_mu, ln_rs);
+      if (LN && p.ln_stats) {
+        if (pre != nullptr) pre_ln_row<BM>(pre, (wm * WTM + i) * 16 + r16, ln_mu, ln_rs);
+        else if (m0 + r16 < p.M) ln_row(p, m0 + r16, ln_mu, ln_rs);
+      }
       const int b = m0 / p.tokens, tok0 = m0 - b * p.tokens;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -541,7 +589,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     return;
   }
   if constexpr (WIDE && EPI == FYC_EPI_LINEAR) {
-    epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, bz, stg_stage, wave, lane);
+    epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, bz, stg_stage, wave, lane, pre);
     return;
   }
   if constexpr (WIDE && EPI != FYC_EPI_HEADS && EPI != FYC_EPI_LINEAR) {
@@ -562,13 +610,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     const int n_out = GLU ? (p.N >> 1) : p.N;
     float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * 16 * PITCH);   // [2][BN], see stage_col_constants
     // (no output statistics here: fyc_gemm() only takes chan_parts / row_parts with the plain LINEAR epilogue)
-    stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+    if (pre != nullptr) colc = reinterpret_cast<float*>(const_cast<char*>(pre) + BM * 8);      // pre-staged inputs (issue_consts)
+    else stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
     float ln_mu[WTM], ln_rs[WTM];
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
       const int m_lane = tile_m * BM + (wm * WTM + i) * 16 + r16;
       ln_mu[i] = 0.f; ln_rs[i] = 1.f;
-      if (LN && p.ln_stats && m_lane < p.M) ln_row(p, m_lane, ln_mu[i], ln_rs[i]);
+      if (LN && p.ln_stats) {
+        if (pre != nullptr) pre_ln_row<BM>(pre, (wm * WTM + i) * 16 + r16, ln_mu[i], ln_rs[i]);
+        else if (m_lane < p.M) ln_row(p, m_lane, ln_mu[i], ln_rs[i]);
+      }
     }
     const int nl_w0 = wn * WTN * 16;                   // this wave's first column inside the tile
 #pragma unroll
@@ -1013,6 +1065,34 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   if (p.phase_delay > 0 && ((blockIdx.x >> 3) & 1)) {
     for (int i = 0; i < p.phase_delay; ++i) __builtin_amdgcn_s_sleep(16);
   }
+  // ---- epilogue inputs by DMA into the region behind the ring (see pre_bytes) ---------------------------------------------------------
+  constexpr bool PRE_BUILT = WIDE && NS == 2;
+  char* const pre_lds = smem + NS * STAGE;
+  auto issue_consts = [&](int c_tm, int c_tn) {
+    constexpr int SP = (BM * 8 + 1023) / 1024, CP = (BN * 4 + 1023) / 1024;       // 1-KiB DMA pieces of the row statistics / of one column array
+    const int nrb = p.rowbias != nullptr ? (p.rb_tile ? 1 : p.rb_slots) : 0;
+    const int npieces = SP + CP * (2 + nrb);
+    const int b0 = (c_tm * BM) / p.rows_per_batch, nb = (p.M + p.rows_per_batch - 1) / p.rows_per_batch;
+    for (int q = wave; q < npieces; q += WGM * WGN) {                             // wave-uniform
+      const char* src = p.zero;
+      int dst, bytes;
+      if (q < SP) {                                                                // {mean, rstd} of two rows per lane (host: M even)
+        bytes = BM * 8 - q * 1024;
+        dst = q * 1024;
+        const int row = c_tm * BM + (q * 1024 + lane * 16) / 8;
+        if (p.ln_stats != nullptr && row < p.M) src = reinterpret_cast<const char*>(p.ln_stats + 2ll * row);
+      } else {
+        const int a = (q - SP) / CP, piece = (q - SP) - a * CP;                   // array: 0 bias, 1 column sums, 2 + slot: row-bias rows
+        bytes = BN * 4 - piece * 1024;
+        dst = BM * 8 + a * (BN * 4) + piece * 1024;
+        const int n = c_tn * BN + (piece * 1024 + lane * 16) / 4;
+        const float* base = a == 0 ? p.bias : a == 1 ? (p.ln_stats != nullptr ? p.ln_colsum : nullptr)
+                                   : (b0 + a - 2 < nb ? p.rowbias + (long long)(b0 + a - 2) * p.ldrb : nullptr);
+        if (base != nullptr && n < p.N) src = reinterpret_cast<const char*>(base + n);
+      }
+      if (lane * 16 < bytes) glds16(src, pre_lds + dst);
+    }
+  };
   // ---- main loop: NS-deep ring over the continuous K-tile stream, counted waits -------------------
   const int nwork = ntiles * S;
   int i_tile = blockIdx.x, i_kt = 0, i_kt_end = 0;   // issue side of the stream (i_tile: work item being issued)
@@ -1061,6 +1141,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       // issue block sits beside its partner's MFMAs.  (Safe with the 2-deep ring: the stage being refilled was consumed by
       // every wave before this barrier, and the late DMAs still have a k-step of both waves to land.)
       // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
+      if constexpr (PRE_BUILT) {
+        if (p.pre && kt == kt_begin(tile)) {             // behind the tile's first barrier: nobody reads the previous tile's inputs any more
+          int c_tm, c_tn;
+          tile_coords(p, remap(tile / S), c_tm, c_tn);
+          issue_consts(c_tm, c_tn);
+        }
+      }
       const bool late = STAGGER && p.stagger && wave >= (WGM * WGN) / 2;
       if (!late && i_tile < nwork) issue_next();
       compute(st_c, 0, 1);
@@ -1087,7 +1174,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       continue;
     }
 
-    gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE, WIDE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane);
+    gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE, WIDE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane,
+                                                               (PRE_BUILT && p.pre) ? pre_lds : nullptr);
     FYC_STAMP(p, wave, lane);
   }  // tile stream
 }
@@ -1101,7 +1189,8 @@ inline int rowbias_slots(int bm, int rpb) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false>
 int launch(const GemmP& p, int batch, hipStream_t st) {
-  constexpr int smem = NS * (BM + BN) * RB;
+  constexpr bool PRE_BUILT = WIDE && NS == 2;
+  constexpr int smem = NS * (BM + BN) * RB + (PRE_BUILT ? pre_bytes<BM, BN>() : 0);
   static_assert(smem <= 160 * 1024, "LDS budget");
   auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS, RB, WIDE>;
   int dev = 0;
@@ -1128,6 +1217,16 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
   q.tiles_n = (p.N + BN - 1) / BN;
   q.rb_tile = (p.colc && p.rowbias != nullptr && p.rows_per_batch % BM == 0) ? 1 : 0;
   q.rb_slots = (WIDE && EPI == FYC_EPI_LINEAR && p.rowbias != nullptr && !q.rb_tile) ? rowbias_slots(BM, p.rows_per_batch) : 0;
+  // epilogue inputs by DMA under the K loop: 2-deep-ring wide epilogues with at least two K tiles per output tile; the row statistics as
+  // stored {mean, rstd} pairs, two rows per 16-byte lane (M even, 16-byte aligned); row-bias rows only where the packed LINEAR epilogue
+  // stages them (fyc_set_tuning key 12 = 1 restores the loads in the epilogue: A/B)
+  {
+    constexpr int BK = (RB / 16) * (16 / (int)sizeof(T));
+    const int kt = (p.K + BK - 1) / BK;
+    const bool rb_ok = p.rowbias == nullptr || (EPI == FYC_EPI_LINEAR && (q.rb_tile || q.rb_slots > 0));
+    q.pre = (PRE_BUILT && g_fyc_tuning[12] != 1 && kt >= 2 && !(q.splitk > 1) && p.ln_nparts == 0 && rb_ok && p.wide &&
+             (p.ln_stats == nullptr || (p.M % 2 == 0 && ((uintptr_t)p.ln_stats % 16) == 0))) ? 1 : 0;
+  }
   q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
   q.phase_delay = g_fyc_tuning[11] > 0 ? g_fyc_tuning[11] : 0;
   q.res_acc = (WIDE && EPI == FYC_EPI_LINEAR && p.residual != nullptr && p.ln_stats == nullptr && !(q.splitk > 1)) ? 1 : 0;

@@ -53,7 +53,8 @@ int fyc_device_caps(int64_t* caps);
  * request for one of those tile configs runs its one-phase twin (5 / 6 / 7 / 6): the one-phase loop always;
  * key 10 = v > 0: split-K for M <= 4096 keeps at least v K tiles per slice (default 16) and starts at K >= 128 v (default 2048);
  * key 11 = v > 0: every other GEMM block of an XCD starts v x 1024 cycles late (phase shift between the CUs' epilogues, A/B);
- * keys 12..15 reserved */
+ * key 12 = 1: the GEMM epilogues load their per-row / per-column inputs themselves instead of finding them pre-staged in LDS (A/B);
+ * keys 13..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------

@@ -53,6 +53,17 @@ for sec in "$@"; do
         echo "-- phase delay $v x 1024 cycles"
         PROBE_TUNING=11=$v PROBE_SWEEP=1 PROBE_CFGS=${PHASE_CFGS:-0,5,6,11} timeout 600 python tools/gemm_probe.py > $OUT/probe_phase$v.txt 2>&1; grep -v amdgpu.ids $OUT/probe_phase$v.txt | cut -c1-110
       done ;;
+    epi_ablation) # where does the packed LINEAR epilogue's time go?  timing builds -DFYC_ABL_EPI=1 (no global stores) / 2 (pass 1 only) / 3 (no epilogue)
+      for v in 0 1 2 3; do
+        echo "-- FYC_ABL_EPI=$v"
+        lib=tools/exp/libfyc_abl_epi$v.so; [ $v = 0 ] && lib=followyourclick_amd/libfyc_hip.so
+        FYC_LIB_PATH=$lib PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep -v "amdgpu.ids\|GEGLU\|heads" | tee $OUT/probe_abl_epi$v.txt | cut -c1-100
+      done ;;
+    pre_ab)       # epilogue inputs pre-staged by DMA (default) vs loaded in the epilogue (tuning key 12 = 1)
+      for v in 0 1 0 1; do
+        echo "-- key 12 = $v"
+        PROBE_TUNING=12=$v PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/probe_pre_key12_$v.txt | cut -c1-100
+      done ;;
     *) echo "unknown section $sec" ;;
   esac
 done
