@@ -25,6 +25,7 @@
 // f32 parity mode uses the same kernel with v_mfma_f32_16x16x4_f32 (exact f32, 1/16 rate).
 #pragma once
 #include <mutex>
+#include <type_traits>
 
 #include "fyc_common.h"
 
@@ -58,6 +59,7 @@ struct GemmP {
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
   int res_acc;   // bf16 LINEAR wide epilogue: the residual tile is loaded INTO the accumulators before the K loop (see epilogue_linear_packed)
+  int fast1;   // packed LINEAR epilogue: specialised pass 1 (fyc_set_tuning key 13 = 1: the generic one, A/B)
   int pre;     // round 6: the epilogue's per-row / per-column inputs are already in LDS (issue_consts in fyc_gemm_kernel), see pre_bytes()
   int phase_delay;   // round 6 (A/B, fyc_set_tuning key 11): every other block of an XCD starts this many x 1024 cycles late, see fyc_gemm_kernel
   unsigned long long* trace;   // timing builds (-DFYC_TRACE, tools/gemm_phase_probe.py): per-block s_memtime stamps; nullptr otherwise
@@ -341,6 +343,58 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   // (scheduling fences: left alone, hipcc hoists the constant reads of ALL column blocks to the top - 80 registers - and sinks the
   // packing into pass 2, i.e. keeps all 160 accumulators alive to the end: the spills this function exists to remove.  The constants
   // of block j + 1 are read while block j is packed.)
+  //
+  // Round 6 (profiles/r06_gemm_epilogue_ablation.txt): this pass was 54 of the 178 us of the 131072x960x320 projection - not its loads but
+  // its instruction stream: per 4 values two wave-uniform branches (LayerNorm? row bias?), an LDS read with its own lgkmcnt(0), 10 VALU
+  // for the LayerNorm fold, 4 adds, 2 scale multiplies.  The common combinations now run specialised copies chosen ONCE per tile: unit
+  // out_scale, the row-bias row the same for all row blocks of the wave (one read per column block, folded into the bias), the LayerNorm
+  // fold as two packed FMAs per value pair: out = fma(acc, rstd, fma(-rstd * mean, colsum, bias')).  4-6 VALU per 4 values instead of ~20.
+  bool rb_same = true;
+#pragma unroll
+  for (int i = 1; i < WTM; ++i) rb_same = rb_same && rbo[i] == rbo[0];
+  const bool has_ln = LN && p.ln_stats != nullptr;
+  auto pass1_fast = [&](auto ln_c, auto rb_c) __attribute__((always_inline)) {
+    constexpr bool HAS_LN = decltype(ln_c)::value, HAS_RB = decltype(rb_c)::value;
+    f32x2 rs2[WTM], nm2[WTM];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) { rs2[i] = (f32x2){rs[i], rs[i]}; nm2[i] = (f32x2){-rs[i] * mu[i], -rs[i] * mu[i]}; }
+    const float* rb0 = HAS_RB ? rbc + rbo[0] : colc;
+    f32x4 b4n = *reinterpret_cast<const f32x4*>(colc + nl_w0 + g * 4), s4n = (f32x4){0.f, 0.f, 0.f, 0.f}, r4n = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (HAS_LN) s4n = *reinterpret_cast<const f32x4*>(colc + BN + nl_w0 + g * 4);
+    if (HAS_RB) r4n = *reinterpret_cast<const f32x4*>(rb0 + nl_w0 + g * 4);
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int nl = nl_w0 + j * 16 + g * 4;
+      f32x4 b4 = b4n;
+      const f32x4 s4 = s4n;
+      if (HAS_RB) { b4[0] += r4n[0]; b4[1] += r4n[1]; b4[2] += r4n[2]; b4[3] += r4n[3]; }
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < WTN) {
+        b4n = *reinterpret_cast<const f32x4*>(colc + nl + 16);
+        if (HAS_LN) s4n = *reinterpret_cast<const f32x4*>(colc + BN + nl + 16);
+        if (HAS_RB) r4n = *reinterpret_cast<const f32x4*>(rb0 + nl + 16);
+      }
+      const f32x2 b01 = {b4[0], b4[1]}, b23 = {b4[2], b4[3]}, s01 = {s4[0], s4[1]}, s23 = {s4[2], s4[3]};
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        f32x2 v01 = {acc[i][j][0], acc[i][j][1]}, v23 = {acc[i][j][2], acc[i][j][3]};
+        if (HAS_LN) {
+          v01 = __builtin_elementwise_fma(v01, rs2[i], __builtin_elementwise_fma(nm2[i], s01, b01));
+          v23 = __builtin_elementwise_fma(v23, rs2[i], __builtin_elementwise_fma(nm2[i], s23, b23));
+        } else {
+          v01 = v01 + b01; v23 = v23 + b23;
+        }
+        unsigned lo = Pair16<T>::pack(v01[0], v01[1]), hi = Pair16<T>::pack(v23[0], v23[1]);
+        asm volatile("" : "+v"(lo), "+v"(hi));       // pin the conversion HERE (see below)
+        pk[i][j] = (u32x2){lo, hi};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (p.out_scale == 1.0f && (rbc == nullptr || rb_same) && p.fast1) {
+    if (has_ln) { if (rbc != nullptr) pass1_fast(std::true_type{}, std::true_type{}); else pass1_fast(std::true_type{}, std::false_type{}); }
+    else { if (rbc != nullptr) pass1_fast(std::false_type{}, std::true_type{}); else pass1_fast(std::false_type{}, std::false_type{}); }
+  } else {
   f32x4 b4n = *reinterpret_cast<const f32x4*>(colc + nl_w0 + g * 4), s4n = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (LN && p.ln_stats) s4n = *reinterpret_cast<const f32x4*>(colc + BN + nl_w0 + g * 4);
 #pragma unroll
@@ -371,6 +425,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
       pk[i][j] = (u32x2){lo, hi};
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
   }
 #if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 2      // 2 = pass 1 only (final values packed in registers, nothing staged or stored)
 #pragma unroll
@@ -426,6 +481,15 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
 #pragma unroll
     for (int j = 0; j < WTN; ++j) *reinterpret_cast<u32x2*>(stg + r16 * PITCH + j * 32 + g * 8) = pk[i][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // round 6: ALL reads of the block first, by every lane (rows clamped into the staged block), ONE wait, then the predicated stores -
+    // inside the `if (live)` each of the NQ reads was followed by its own lgkmcnt(0): 24 exposed LDS round trips per 256x320 tile and wave
+    u32x4 v4q[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int rowc = (q * RPP + lrow) < 15 ? (q * RPP + lrow) : 15;
+      v4q[q] = *reinterpret_cast<const u32x4*>(stg + rowc * PITCH + lch * 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int row = q * RPP + lrow;
@@ -433,7 +497,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
       float rsum = 0.f, rsq = 0.f;
       const bool live = lact && row < 16 && m < p.M && n_lane < p.N;
       if (live) {
-        const u32x4 v4 = *reinterpret_cast<const u32x4*>(stg + row * PITCH + lch * 16);
+        const u32x4 v4 = v4q[q];
 #if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 1      // 1 = everything but the global stores
         asm volatile("" :: "v"(v4[0]), "v"(v4[1]), "v"(v4[2]), "v"(v4[3]));
 #else
@@ -1227,6 +1291,7 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
     q.pre = (PRE_BUILT && g_fyc_tuning[12] != 1 && kt >= 2 && !(q.splitk > 1) && p.ln_nparts == 0 && rb_ok && p.wide &&
              (p.ln_stats == nullptr || (p.M % 2 == 0 && ((uintptr_t)p.ln_stats % 16) == 0))) ? 1 : 0;
   }
+  q.fast1 = g_fyc_tuning[13] == 1 ? 0 : 1;
   q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
   q.phase_delay = g_fyc_tuning[11] > 0 ? g_fyc_tuning[11] : 0;
   q.res_acc = (WIDE && EPI == FYC_EPI_LINEAR && p.residual != nullptr && p.ln_stats == nullptr && !(q.splitk > 1)) ? 1 : 0;

@@ -54,7 +54,8 @@ int fyc_device_caps(int64_t* caps);
  * key 10 = v > 0: split-K for M <= 4096 keeps at least v K tiles per slice (default 16) and starts at K >= 128 v (default 2048);
  * key 11 = v > 0: every other GEMM block of an XCD starts v x 1024 cycles late (phase shift between the CUs' epilogues, A/B);
  * key 12 = 1: the GEMM epilogues load their per-row / per-column inputs themselves instead of finding them pre-staged in LDS (A/B);
- * keys 13..15 reserved */
+ * key 13 = 1: the generic pass 1 of the packed LINEAR epilogue instead of its specialised copies (A/B);
+ * keys 14..15 reserved */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------

@@ -64,6 +64,11 @@ for sec in "$@"; do
         echo "-- key 12 = $v"
         PROBE_TUNING=12=$v PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/probe_pre_key12_$v.txt | cut -c1-100
       done ;;
+    fast1_ab)     # specialised pass 1 of the packed LINEAR epilogue (default) vs the generic one (tuning key 13 = 1)
+      for v in 0 1 0 1; do
+        echo "-- key 13 = $v"
+        PROBE_TUNING=13=$v PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep -v "amdgpu.ids\|GEGLU\|heads" | tee $OUT/probe_fast1_key13_$v.txt | cut -c1-100
+      done ;;
     *) echo "unknown section $sec" ;;
   esac
 done
