@@ -161,7 +161,7 @@ MISC = ["fyc_version", "fyc_last_error", "fyc_init", "fyc_device_caps", "fyc_set
         "fyc_ff_block_supported", "fyc_ff_block_wstream_bytes", "fyc_panel_linear_supported", "fyc_panel_linear_wstream_bytes"]
 
 _lib = None
-FYC_VERSION = 300        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
+FYC_VERSION = 301        # the ABI version this binding's ctypes structs mirror (include/fyc.h::FYC_VERSION)
 
 
 class FycError(RuntimeError):

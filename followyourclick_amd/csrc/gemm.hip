@@ -134,7 +134,10 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
     // operands coming from HBM and the epilogue features the UNet uses (tools/gemm_probe.py, profiles/r02_gemm_probe_cold_sweep.txt):
     // 95 (config 6) vs 111 (8) / 122 (5) us at M = 131072, N = K = 320 + residual, 67 vs 75 (5) at M = 32768, N = K = 640; the
     // Infinity-Cache-hot sweep had ranked 8 first.  (Shape-only rule: fyc_gemm_stat_layout must predict the tile from M, N, K.)
-    const bool short_k = p.mode == FYC_GEMM_PLAIN && (p.N == 320 || p.N == 640) && p.K <= p.N;
+    // Round 6 (profiles/r06_gemm_tile_sweep.txt, after the packed epilogue of round 4 and this round's epilogue work): with a residual the
+    // two tiles are level (84 / 58 us either way), WITHOUT one the 256-row tile is 10-18 % faster (q2 head projection 131072x320x320: 72 vs
+    // 88 us, 32768x640x640: 51 vs 61; proj_in 32768x640x640: 44 vs 49) - the short-K rule now only holds for problems with a residual.
+    const bool short_k = p.mode == FYC_GEMM_PLAIN && (p.N == 320 || p.N == 640) && p.K <= p.N && p.residual != nullptr;
     if (p.M >= 16384) cfg = short_k ? 6 : 5;
     else if (p.M >= 4096) cfg = (p.N >= 5120) ? 5 : 6;
     // M < 4096 (the 8x8 latent level): the widest tile that still gives the chip ~200+ work items.  Cold-operand probe at
@@ -193,6 +196,9 @@ void pick(const fyc_gemm_args* a, int& cfg, int& ns, bool stats) {
   GemmP q;
   memset(&q, 0, sizeof(q));
   q.M = a->M; q.N = a->N; q.K = a->K; q.mode = a->mode; q.epilogue = a->epilogue;
+  // (the tile of a problem with output statistics must follow from its shape alone - fyc_gemm_stat_layout has no pointers: such problems keep
+  // the residual-independent short-K rule)
+  q.residual = stats ? (const char*)a : (const char*)a->residual;
   choose(q, a->batch > 0 ? a->batch : 1, a->tile, cfg, ns);
   if (stats && cfg == 8) cfg = 6;
   if (stats && cfg == 10) cfg = 1;
@@ -203,7 +209,7 @@ int split_of(const fyc_gemm_args* a, int& cfg) {
   if (a->ln_stats != nullptr || a->row_parts != nullptr) return 1;      // (chan_parts: the finish kernel writes them, round 6)
   // fyc_set_tuning key 10 = v > 0 (A/B): at least v K tiles per slice instead of 16, and K >= 128 v instead of 2048 - the K = 1280 linears
   // of the 8x8 latent level (profiles/r06_gemm_small_m_split_k.txt)
-  const int min_kt = g_fyc_tuning[10] > 0 ? g_fyc_tuning[10] : 16;
+  const int min_kt = g_fyc_tuning[10] > 0 ? g_fyc_tuning[10] : 10;     // (16 until round 6: the K = 2560 shortcut of the 8x8 level now splits 4 ways, 39 -> 33 us)
   if (a->M > 4096 || a->K < (g_fyc_tuning[10] > 0 ? 128 * min_kt : 2048) || a->N % 8 != 0 || a->N < 256) return 1;
   const int c = (a->N % 320 == 0) ? 6 : 1;                     // 128x320 or 128x128 tiles
   const int bn = (c == 6) ? 320 : 128;
@@ -211,7 +217,7 @@ int split_of(const fyc_gemm_args* a, int& cfg) {
   const int kt = (a->K + 63) / 64;
   int s = (int)(256 / tiles);
   if (s > 8) s = 8;
-  while (s > 1 && kt / s < min_kt) --s;                        // keep >= 16 K tiles per slice
+  while (s > 1 && kt / s < min_kt) --s;                        // keep >= min_kt K tiles per slice
   if (s < 2) return 1;
   cfg = c;
   return s;

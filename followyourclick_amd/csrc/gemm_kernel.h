@@ -75,9 +75,17 @@ struct GemmP {
       (p).trace[((size_t)blockIdx.x * 2 + ((wave) >> 2)) * 128 + fyc_trace_n] = __builtin_amdgcn_s_memtime();            \
     ++fyc_trace_n;                                                                                                       \
   } while (0)
+// ... and inside the packed LINEAR epilogue (second half of the buffer, own counter): behind its first barrier, its inputs, pass 1, pass 2
+#define FYC_STAMP_E(p, wave, lane, cnt)                                                                                  \
+  do {                                                                                                                   \
+    if ((p).trace != nullptr && ((wave) & 3) == 0 && (lane) == 0 && (cnt) < 128)                                         \
+      (p).trace[65536 + ((size_t)blockIdx.x * 2 + ((wave) >> 2)) * 128 + (cnt)] = __builtin_amdgcn_s_memtime();          \
+    ++(cnt);                                                                                                             \
+  } while (0)
 #else
 #define FYC_STAMP_DECL
 #define FYC_STAMP(p, wave, lane) do { } while (0)
+#define FYC_STAMP_E(p, wave, lane, cnt) do { } while (0)
 #endif
 
 // Linear tile index (after the XCD remap) -> tile coordinates.  The 32 CUs of an XCD work on ~32 consecutive indices at
@@ -282,7 +290,7 @@ template <int BM> __device__ __forceinline__ void pre_ln_row(const char* pre, in
 //     256x320 tile instead of 8 half-width f32 ones) and stores / accumulates the statistics from 16-byte row segments as before.
 template <typename T, int BM, int BN, int WGM, int WGN, int STG_BYTES, int MODE>
 __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
-                                                       long long bz, char* stg_stage, int wave, int lane, const char* pre) {
+                                                       long long bz, char* stg_stage, int wave, int lane, const char* pre, int& ecnt) {
   static_assert(sizeof(T) == 2, "16-bit outputs only (bf16 / f16)");
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
 #if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 3      // TIMING BUILDS (wrong results), tools/gpu_r6.sh epi_ablation: 3 = no epilogue at all
@@ -349,6 +357,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   // for the LayerNorm fold, 4 adds, 2 scale multiplies.  The common combinations now run specialised copies chosen ONCE per tile: unit
   // out_scale, the row-bias row the same for all row blocks of the wave (one read per column block, folded into the bias), the LayerNorm
   // fold as two packed FMAs per value pair: out = fma(acc, rstd, fma(-rstd * mean, colsum, bias')).  4-6 VALU per 4 values instead of ~20.
+  FYC_STAMP_E(p, wave, lane, ecnt);
   bool rb_same = true;
 #pragma unroll
   for (int i = 1; i < WTM; ++i) rb_same = rb_same && rbo[i] == rbo[0];
@@ -434,6 +443,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
     for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(pk[i][j][0]), "v"(pk[i][j][1]));
   return;
 #endif
+  FYC_STAMP_E(p, wave, lane, ecnt);
   // ---- pass 2: 16 rows x (WTN * 16) columns per step through the wave's staging slice ---------------------------------------------
   const int lrow = lane / CPR, lch = lane - lrow * CPR;
   const bool lact = lrow < RPP;
@@ -522,6 +532,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  FYC_STAMP_E(p, wave, lane, ecnt);
   if (do_cs) flush_tree(cur_slot);
   if (do_cs || do_rp) stats_flush<BM, BN, WGM, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
 }
@@ -566,7 +577,7 @@ __device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[B
 // in one kernel the narrow loops no longer unrolled and the whole accumulator array lived in scratch).
 template <typename T, int BM, int BN, int WGM, int WGN, int EPI, int STG_BYTES, int MODE, bool WIDE>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
-                                              long long bz, char* stg_stage, int wave, int lane, const char* pre) {
+                                              long long bz, char* stg_stage, int wave, int lane, const char* pre, int& ecnt) {
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
   constexpr bool LN = (MODE == FYC_GEMM_PLAIN);   // the folded LayerNorm only exists for plain GEMMs: keep it out of the conv kernels
   const int wm = wave / WGN, wn = wave % WGN;
@@ -653,7 +664,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     return;
   }
   if constexpr (WIDE && EPI == FYC_EPI_LINEAR) {
-    epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, bz, stg_stage, wave, lane, pre);
+    epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, bz, stg_stage, wave, lane, pre, ecnt);
     return;
   }
   if constexpr (WIDE && EPI != FYC_EPI_HEADS && EPI != FYC_EPI_LINEAR) {
@@ -1072,6 +1083,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 
   f32x4 acc[WTM][WTN];
   FYC_STAMP_DECL;
+  int fyc_trace_e = 0;      // (timing builds: stamps inside the packed epilogue)
 
   const int g = lane >> 4, r16 = lane & 15;
   const int sw = swz_key<RB>(r16);   // all fragment rows are r16 + multiples of 16: same key
@@ -1239,7 +1251,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     }
 
     gemm_epilogue<T, BM, BN, WGM, WGN, EPI, STAGE, MODE, WIDE>(p, acc, tile_m, tile_n, bz, smem + ((st_c == 0) ? NS - 1 : st_c - 1) * STAGE, wave, lane,
-                                                               (PRE_BUILT && p.pre) ? pre_lds : nullptr);
+                                                               (PRE_BUILT && p.pre) ? pre_lds : nullptr, fyc_trace_e);
     FYC_STAMP(p, wave, lane);
   }  // tile stream
 }

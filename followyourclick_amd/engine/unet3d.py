@@ -197,8 +197,10 @@ class UNet3DEngine(EngineBase):
         (rows per frame not a multiple of 16, or a row tile would touch more than 4 frames)"""
         if not self.fuse_stats or rows_per_sample % 16 or rows % rows_per_sample:
             return None
-        # (small M, long K - the 8x8 latents - run split-K: since round 6 its finish kernel writes the same partial sums,
-        # fyc_gemm_stat_layout answers for it)
+        # small M, long K - the 8x8 latents - run split-K: since round 6 (ABI 301) its finish kernel writes the same partial sums and
+        # fyc_gemm_stat_layout answers for it; an older A/B library (FYC_LIB_PATH) keeps the separate statistics pass
+        if getattr(self.ops, "abi_version", 301) < 301 and self.ops.gemm_split_bytes(self.dtype, M=rows, N=N, K=K, mode=mode) > 0:
+            return None
         nt, tile_rows, slots = self.ops.gemm_stat_layout(self.dtype, M=rows, N=N, K=K, cs_rows=rows_per_sample, mode=mode)
         if not 1 <= slots <= 4:
             return None

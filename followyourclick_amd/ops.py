@@ -82,6 +82,7 @@ class HipOps:
             raise L.FycError(f"followyourclick_amd is bound to cuda:{self._inited_dev}; use one process per GPU (asked for cuda:{idx})")
         self._zero = torch.zeros(4096, dtype=torch.uint8, device=torch.device("cuda", idx))
         L.check(self.lib.fyc_init(self._zero.data_ptr()), "fyc_init")
+        self.abi_version = int(self.lib.fyc_version())        # (differs from _lib.FYC_VERSION only for an A/B library, FYC_LIB_PATH)
         self._inited_dev = idx
         for kv in filter(None, os.environ.get("FYC_TUNING", "").split(",")):   # A/B runs: FYC_TUNING="5=1,4=8" (fyc_set_tuning keys)
             k, v = kv.split("=")

@@ -29,8 +29,8 @@ extern "C" {
 /* ABI version = major * 100 + minor.  A host compiled against this header MUST compare fyc_version() with FYC_VERSION before its first
  * call and refuse a library whose MAJOR differs: argument structs grow at the end between majors (round 3 appended `wstream` to
  * fyc_temporal_block_args and widened the tuning table to 16 keys without bumping the number: a round-2 host would have passed a short
- * struct whose missing tail the library reads as a pointer).  History: 100 = rounds 1-3 (see above), 200 = round 4, 201 = FYC_F16, 300 = round 5: fields were APPENDED to two argument structs - variance_noise / sigma / clipped_model_output behind the DDIM step's arguments, mode behind the UNet input's - a struct change, hence a new major: a 2xx host passes shorter structs whose missing tail this library would read. */
-#define FYC_VERSION 300
+ * struct whose missing tail the library reads as a pointer).  History: 100 = rounds 1-3 (see above), 200 = round 4, 201 = FYC_F16, 300 = round 5: fields were APPENDED to two argument structs - variance_noise / sigma / clipped_model_output behind the DDIM step's arguments, mode behind the UNet input's - a struct change, hence a new major: a 2xx host passes shorter structs whose missing tail this library would read; 301 = round 6, no struct change: fyc_gemm accepts chan_parts for problems it runs split-K (fyc_gemm_workspace_bytes() > 0; the finish kernel writes them in 128-row tiles, fyc_gemm_stat_layout answers for it), tile config 11, tuning keys 10-13. */
+#define FYC_VERSION 301
 
 /* FYC_F16 (minor version 1): IEEE half storage with f32 accumulation - every op that takes FYC_BF16 takes it, same layouts, same
  * packed weight streams (16-bit elements), v_mfma_*_f16 instead of v_mfma_*_bf16; the packers cast to the `dtype` they are given */

@@ -69,6 +69,10 @@ for sec in "$@"; do
         echo "-- key 13 = $v"
         PROBE_TUNING=13=$v PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep -v "amdgpu.ids\|GEGLU\|heads" | tee $OUT/probe_fast1_key13_$v.txt | cut -c1-100
       done ;;
+    epi_trace)    # s_memtime stamps inside the packed LINEAR epilogue (timing build tools/exp/libfyc_trace.so)
+      FYC_LIB_PATH=tools/exp/libfyc_trace.so timeout 600 python tools/gemm_epilogue_trace.py 2>&1 | grep -v amdgpu.ids | tee $OUT/epilogue_trace.txt
+      echo "-- generic pass 1 (key 13 = 1), inputs loaded in the epilogue (key 12 = 1)"
+      FYC_LIB_PATH=tools/exp/libfyc_trace.so PROBE_TUNING=13=1,12=1 timeout 600 python tools/gemm_epilogue_trace.py 2>&1 | grep -v amdgpu.ids | tee $OUT/epilogue_trace_old.txt ;;
     *) echo "unknown section $sec" ;;
   esac
 done
