@@ -340,6 +340,8 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
     FYC_REQUIRE(a->M % a->tokens == 0, "fyc_gemm HEADS: M not a multiple of tokens");
     FYC_REQUIRE(a->residual == nullptr && batch == 1, "fyc_gemm HEADS: residual/batch unsupported");
     p.seg_cols = a->seg_cols; p.heads = a->heads; p.tokens = a->tokens; p.head_dim = a->seg_cols / a->heads;
+    p.inv_seg_cols = 1.0f / (float)p.seg_cols; p.inv_head_dim = 1.0f / (float)p.head_dim;      // (fdiv_small: N < 2^16, divisors <= 2^12)
+    FYC_REQUIRE(a->N < 65536 && p.seg_cols <= 4096, "fyc_gemm HEADS: N=%d / seg_cols=%d beyond the epilogue's index arithmetic", a->N, p.seg_cols);
     for (int s = 0; s < a->N / a->seg_cols; ++s) {
       FYC_REQUIRE(a->seg_out[s] != nullptr, "fyc_gemm HEADS: seg_out[%d] null", s);
       p.seg_out[s] = (char*)a->seg_out[s];

@@ -59,6 +59,7 @@ struct GemmP {
   int wide;   // bf16 linear epilogue may use 16-B row accesses (N, ldo, ldr multiples of 8; bias/rowbias 16-B aligned)
   const char* zero;
   int res_acc;   // bf16 LINEAR wide epilogue: the residual tile is loaded INTO the accumulators before the K loop (see epilogue_linear_packed)
+  float inv_seg_cols, inv_head_dim;   // HEADS epilogue: reciprocals for fdiv_small (host: fyc_gemm)
   int fast1;   // packed LINEAR epilogue: specialised pass 1 (fyc_set_tuning key 13 = 1: the generic one, A/B)
   int pre;     // round 6: the epilogue's per-row / per-column inputs are already in LDS (issue_consts in fyc_gemm_kernel), see pre_bytes()
   int phase_delay;   // round 6 (A/B, fyc_set_tuning key 11): every other block of an XCD starts this many x 1024 cycles late, see fyc_gemm_kernel
@@ -140,6 +141,11 @@ constexpr int EPI_LINEAR_ACT = 3;
 __device__ __forceinline__ float activate(float x, int act) {
   return act == FYC_ACT_GELU ? gelu_erf_f(x) : x / (1.0f + __expf(-1.702f * x));
 }
+
+// floor(n / d) for 0 <= n < 2^16, 1 <= d <= 2^12 from inv = 1.0f / d: (n + 0.5) / d is at least 0.5 / d away from every integer, the f32
+// product is off by < 2^-7 of that.  3 VALU instructions where hipcc's 32-bit division by a run-time value is ~25: the head-split epilogue
+// decomposed EVERY 16-byte chunk it stored with two such divisions (round 6: ~3 000 VALU instructions per lane and 256x320 tile).
+__device__ __forceinline__ int fdiv_small(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -537,6 +543,103 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   if (do_cs || do_rp) stats_flush<BM, BN, WGM, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
 }
 
+// ---- GEGLU epilogue, "pack first" (round 6) ---------------------------------------------------------------------------------------------
+// The feed-forward projections of levels 1-3 (N = 5120 / 10240: 8 / 4 tile rounds per launch, 120 of the 533 tile rounds of a DDIM step) ran the
+// round-1 epilogue: every 16-row block was gated in f32, staged as f32 in two half-width passes, read back and packed, each step behind its own
+// lgkmcnt(0).  Same scheme as epilogue_linear_packed: pass 1 gates ALL blocks (value block 2 jo, gate block 2 jo + 1 of the wave: LayerNorm fold
+// as packed FMAs, the packed polynomial gate of fyc_common.h::geglu_pair) and packs them to 16-bit pairs in place - WTN / 2 x WTM x 2 registers;
+// pass 2 stages 16 rows x the wave's WTN * 8 output columns as 16-bit words, reads the block back in one go and stores 16-byte row segments.
+template <typename T, int BM, int BN, int WGM, int WGN, int STG_BYTES, int MODE>
+__device__ __forceinline__ void epilogue_geglu_packed(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
+                                                      long long bz, char* stg_stage, int wave, int lane, const char* pre) {
+  static_assert(sizeof(T) == 2, "16-bit outputs only (bf16 / f16)");
+  constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16, OT = WTN / 2;
+  constexpr bool LN = (MODE == FYC_GEMM_PLAIN);
+  constexpr int PITCH = OT * 32 + 16;                // bytes per staged row: OT * 16 output columns of 2 bytes + 16
+  constexpr int CPR = OT * 2;                        // 16-byte chunks per staged row
+  constexpr int RPP = 64 / CPR;                      // rows per store instruction
+  constexpr int NQ = (16 + RPP - 1) / RPP;
+  constexpr int SLICE = 16 * PITCH;
+  static_assert(WGM * WGN * SLICE + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int g = lane >> 4, r16 = lane & 15;
+  T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
+  __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
+  char* stg = stg_stage + wave * SLICE;
+  float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * SLICE);
+  if (pre != nullptr) colc = reinterpret_cast<float*>(const_cast<char*>(pre) + BM * 8);      // pre-staged inputs (issue_consts)
+  else stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+  const bool has_ln = LN && p.ln_stats != nullptr;
+  f32x2 rs2[WTM], nm2[WTM];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    float mu = 0.f, rs = 1.f;
+    if (has_ln) {
+      if (pre != nullptr) pre_ln_row<BM>(pre, (wm * WTM + i) * 16 + r16, mu, rs);
+      else if (tile_m * BM + (wm * WTM + i) * 16 + r16 < p.M) ln_row(p, tile_m * BM + (wm * WTM + i) * 16 + r16, mu, rs);
+    }
+    rs2[i] = (f32x2){rs, rs}; nm2[i] = (f32x2){-rs * mu, -rs * mu};
+  }
+  const int nl_w0 = wn * WTN * 16;                   // this wave's first packed column inside the tile
+  // ---- pass 1: gate and pack -------------------------------------------------------------------------------------------------------
+  u32x2 pk[WTM][OT];
+  auto pass1 = [&](auto ln_c) __attribute__((always_inline)) {
+    constexpr bool HAS_LN = decltype(ln_c)::value;
+#pragma unroll
+    for (int jo = 0; jo < OT; ++jo) {
+      const int nl = nl_w0 + (2 * jo) * 16 + g * 4;  // packed value column inside the tile; its gate is 16 further
+      const f32x4 bh = *reinterpret_cast<const f32x4*>(colc + nl), bg = *reinterpret_cast<const f32x4*>(colc + nl + 16);
+      f32x4 sh = (f32x4){0.f, 0.f, 0.f, 0.f}, sg = sh;
+      if (HAS_LN) { sh = *reinterpret_cast<const f32x4*>(colc + BN + nl); sg = *reinterpret_cast<const f32x4*>(colc + BN + nl + 16); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        f32x2 h01 = {acc[i][2 * jo][0], acc[i][2 * jo][1]}, h23 = {acc[i][2 * jo][2], acc[i][2 * jo][3]};
+        f32x2 g01 = {acc[i][2 * jo + 1][0], acc[i][2 * jo + 1][1]}, g23 = {acc[i][2 * jo + 1][2], acc[i][2 * jo + 1][3]};
+        if (HAS_LN) {
+          h01 = __builtin_elementwise_fma(h01, rs2[i], __builtin_elementwise_fma(nm2[i], (f32x2){sh[0], sh[1]}, (f32x2){bh[0], bh[1]}));
+          h23 = __builtin_elementwise_fma(h23, rs2[i], __builtin_elementwise_fma(nm2[i], (f32x2){sh[2], sh[3]}, (f32x2){bh[2], bh[3]}));
+          g01 = __builtin_elementwise_fma(g01, rs2[i], __builtin_elementwise_fma(nm2[i], (f32x2){sg[0], sg[1]}, (f32x2){bg[0], bg[1]}));
+          g23 = __builtin_elementwise_fma(g23, rs2[i], __builtin_elementwise_fma(nm2[i], (f32x2){sg[2], sg[3]}, (f32x2){bg[2], bg[3]}));
+        } else {
+          h01 = h01 + (f32x2){bh[0], bh[1]}; h23 = h23 + (f32x2){bh[2], bh[3]};
+          g01 = g01 + (f32x2){bg[0], bg[1]}; g23 = g23 + (f32x2){bg[2], bg[3]};
+        }
+        const f32x2 lo2 = geglu_pair(h01, g01), hi2 = geglu_pair(h23, g23);
+        unsigned lo = Pair16<T>::pack(lo2.x, lo2.y), hi = Pair16<T>::pack(hi2.x, hi2.y);
+        asm volatile("" : "+v"(lo), "+v"(hi));       // pin the conversion here (see epilogue_linear_packed)
+        pk[i][jo] = (u32x2){lo, hi};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (has_ln) pass1(std::true_type{}); else pass1(std::false_type{});
+  // ---- pass 2: 16 rows x (OT * 16) output columns per step through the wave's staging slice -----------------------------------------------
+  const int lrow = lane / CPR, lch = lane - lrow * CPR;
+  const bool lact = lrow < RPP;
+  const int n_out = p.N >> 1;
+  const int n_lane = ((tile_n * BN + nl_w0) >> 1) + lch * 8;      // this lane's 8 output columns
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+    for (int jo = 0; jo < OT; ++jo) *reinterpret_cast<u32x2*>(stg + r16 * PITCH + jo * 32 + g * 8) = pk[i][jo];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    u32x4 v4q[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int rowc = (q * RPP + lrow) < 15 ? (q * RPP + lrow) : 15;
+      v4q[q] = *reinterpret_cast<const u32x4*>(stg + rowc * PITCH + lch * 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int row = q * RPP + lrow;
+      const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
+      if (lact && row < 16 && m < p.M && n_lane < n_out) *reinterpret_cast<u32x4*>(O + (long long)m * p.ldo + n_lane) = v4q[q];
+    }
+  }
+}
+
 // the residual tile into the accumulators (MFMA layout: a lane holds 4 consecutive channels of a row), before the K loop
 template <typename T, int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n, int wave, int lane) {
@@ -594,6 +697,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     constexpr int JG = (WTN + 1) / 2;
     constexpr int PITCH = JG * 64 + 16;
     static_assert(WGM * WGN * 16 * PITCH + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
+#if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 3      // timing build: no epilogue (the accumulators stay alive)
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+    return;
+#endif
     __builtin_amdgcn_s_barrier();
     char* stg = stg_stage + wave * (16 * PITCH);
     float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * 16 * PITCH);
@@ -634,9 +744,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
             const int row = c / cpr, ch = c - row * cpr;
             const int n = n0 + ch * 8;
             if (n >= p.N) continue;
-            const int seg = n / p.seg_cols, cs = n - seg * p.seg_cols;
+            const int seg = fdiv_small(n, p.inv_seg_cols), cs = n - seg * p.seg_cols;
             if (p.seg_transposed[seg]) continue;
-            const int hh = cs / p.head_dim, di = cs - hh * p.head_dim;
+            const int hh = fdiv_small(cs, p.inv_head_dim), di = cs - hh * p.head_dim;
             float v8[8];
             *reinterpret_cast<f32x4*>(v8) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32);
             *reinterpret_cast<f32x4*>(v8 + 4) = *reinterpret_cast<const f32x4*>(stg + row * PITCH + ch * 32 + 16);
@@ -648,9 +758,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
             const int col = u >> 1, half = u & 1;
             const int n = n0 + col;
             if (n >= p.N) continue;
-            const int seg = n / p.seg_cols, cs = n - seg * p.seg_cols;
+            const int seg = fdiv_small(n, p.inv_seg_cols), cs = n - seg * p.seg_cols;
             if (!p.seg_transposed[seg]) continue;
-            const int hh = cs / p.head_dim, di = cs - hh * p.head_dim;
+            const int hh = fdiv_small(cs, p.inv_head_dim), di = cs - hh * p.head_dim;
             float v8[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) v8[r] = *reinterpret_cast<const float*>(stg + (half * 8 + r) * PITCH + col * 4);
@@ -667,6 +777,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     epilogue_linear_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, bz, stg_stage, wave, lane, pre, ecnt);
     return;
   }
+  if constexpr (WIDE && EPI == FYC_EPI_GEGLU && sizeof(T) == 2) {
+    if (p.fast1) {
+#if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 3      // timing build: no epilogue (the accumulators stay alive)
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+      return;
+#endif
+      epilogue_geglu_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, bz, stg_stage, wave, lane, pre);
+      return;
+    }
+  }
   if constexpr (WIDE && EPI != FYC_EPI_HEADS && EPI != FYC_EPI_LINEAR) {
     // Wide epilogue (bf16 GEGLU, and LINEAR with an activation: the conditioning encoders): the MFMA layout gives a lane only 4 consecutive channels (8 B), i.e.
     // 32-B row segments per store/residual-load instruction - measured as half the time of the K<=640 layers
@@ -678,6 +801,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
     constexpr int JG = (OT + 1) / 2;                   // output tiles per pass
     constexpr int PITCH = JG * 64 + 16;                // bytes per staged row (f32), +16 keeps ds_write_b128 conflict-free
     static_assert(WGM * WGN * 16 * PITCH + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
+#if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 3      // timing build: no epilogue (the accumulators stay alive)
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+    return;
+#endif
     __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
     char* stg = stg_stage + wave * (16 * PITCH);
     const int n_w0 = tile_n * BN + wn * WTN * 16;      // first GEMM column of this wave
@@ -1202,8 +1332,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       }
     }
     FYC_STAMP(p, wave, lane);
-    const int kt_hi = kt_end(tile);
-    for (int kt = kt_begin(tile); kt < kt_hi; ++kt) {
+    const int kt_hi = kt_end(tile), kt_lo = kt_begin(tile);
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
       // the oldest in-flight element must have landed; up to NS-2 younger ones may stay in flight
       const int ahead = min(NS - 2, n_ahead - 1);
       if (NS >= 4 && ahead == 2) wait_vmcnt<2 * LOADS>();
@@ -1218,7 +1348,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       // every wave before this barrier, and the late DMAs still have a k-step of both waves to land.)
       // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
       if constexpr (PRE_BUILT) {
-        if (p.pre && kt == kt_begin(tile)) {             // behind the tile's first barrier: nobody reads the previous tile's inputs any more
+        if (p.pre && kt == kt_lo) {                      // behind the tile's first barrier: nobody reads the previous tile's inputs any more
           int c_tm, c_tn;
           tile_coords(p, remap(tile / S), c_tm, c_tn);
           issue_consts(c_tm, c_tn);

@@ -142,3 +142,16 @@ def test_attention_issue_statement_restores_m0_and_exec(tmp_path):
         assert not [c for c in canon if c[1] == c[2]], f"{name}: sNaN-quieting v_max_f32 x, x, x is back (is -fno-honor-nans still on the attention sources?)"
         assert "s_setprio" not in body, f"{name}: s_setprio in an issue-bound loop (-DFYC_ATTN_SETPRIO builds it)"
     assert checked >= len(kernels), (checked, len(kernels))      # at least one such statement per kernel (prologue + loop)
+
+
+def test_reciprocal_division_of_the_head_split_epilogue_is_exact():
+    """csrc/gemm_kernel.h::fdiv_small (round 6): floor(n / d) as (int)((n + 0.5f) * (1.0f / d)) replaces the run-time integer divisions of the
+    head-split epilogue's index arithmetic.  Exhaustive over the range fyc_gemm admits (N < 2^16 columns, segment width / head dim <= 2^12):
+    the f32 formula, evaluated with numpy's IEEE single arithmetic as the GPU evaluates it (no contraction: -ffp-contract=off), never differs
+    from the integer quotient."""
+    import numpy as np
+    n = np.arange(65536, dtype=np.int64)
+    nf = n.astype(np.float32) + np.float32(0.5)
+    for d in range(1, 4097):
+        q = (nf * (np.float32(1.0) / np.float32(d))).astype(np.int64)
+        assert np.array_equal(q, n // d), d

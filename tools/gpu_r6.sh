@@ -73,6 +73,13 @@ for sec in "$@"; do
       FYC_LIB_PATH=tools/exp/libfyc_trace.so timeout 600 python tools/gemm_epilogue_trace.py 2>&1 | grep -v amdgpu.ids | tee $OUT/epilogue_trace.txt
       echo "-- generic pass 1 (key 13 = 1), inputs loaded in the epilogue (key 12 = 1)"
       FYC_LIB_PATH=tools/exp/libfyc_trace.so PROBE_TUNING=13=1,12=1 timeout 600 python tools/gemm_epilogue_trace.py 2>&1 | grep -v amdgpu.ids | tee $OUT/epilogue_trace_old.txt ;;
+    epi2_ab)      # GEGLU / head-split epilogues: packed GEGLU + fast pass 1 (default) vs key 13 = 1 (round-5 code), and no epilogue at all (timing build)
+      for v in 0 1 0 1; do
+        echo "-- key 13 = $v"
+        PROBE_TUNING=13=$v PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep "GEGLU\|heads\|tQKV\|case" | tee $OUT/probe_epi2_key13_$v.txt | cut -c1-100
+      done
+      echo "-- FYC_ABL_EPI=3 (no epilogue)"
+      FYC_LIB_PATH=tools/exp/libfyc_abl_epi3.so PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep "GEGLU\|heads\|tQKV\|case" | tee $OUT/probe_epi2_abl3.txt | cut -c1-100 ;;
     *) echo "unknown section $sec" ;;
   esac
 done
