@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(256) splitk_finish_stats_kernel(const float* _
   const int tile_m = blockIdx.x, n0 = blockIdx.y * 64;
   const int cch = threadIdx.x & 7, rsub = threadIdx.x >> 3;
   const int n = n0 + cch * 8;
-#pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {      // (unrolled: the partial-sum loads of the four passes are independent)
     const int lr = pass * 32 + rsub, m = tile_m * 128 + lr;
     float v[8];
 #pragma unroll

@@ -499,21 +499,28 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // round 6: ALL reads of the block first, by every lane (rows clamped into the staged block), ONE wait, then the predicated stores -
     // inside the `if (live)` each of the NQ reads was followed by its own lgkmcnt(0): 24 exposed LDS round trips per 256x320 tile and wave
-    u32x4 v4q[NQ];
+    // (in groups of at most QG reads: all six of the 256x320 tile at once cost its kernels 60 more bytes of scratch and the convolutions 1.5 %)
+    constexpr int QG = NQ <= 3 ? NQ : 3;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q0 = 0; q0 < NQ; q0 += QG) {
+    u32x4 v4q[QG];
+#pragma unroll
+    for (int qq = 0; qq < QG; ++qq) {
+      const int q = q0 + qq;
       const int rowc = (q * RPP + lrow) < 15 ? (q * RPP + lrow) : 15;
-      v4q[q] = *reinterpret_cast<const u32x4*>(stg + rowc * PITCH + lch * 16);
+      if (q < NQ) v4q[qq] = *reinterpret_cast<const u32x4*>(stg + rowc * PITCH + lch * 16);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int qq = 0; qq < QG; ++qq) {
+      const int q = q0 + qq;
+      if (q >= NQ) continue;
       const int row = q * RPP + lrow;
       const int m = tile_m * BM + (wm * WTM + i) * 16 + row;
       float rsum = 0.f, rsq = 0.f;
       const bool live = lact && row < 16 && m < p.M && n_lane < p.N;
       if (live) {
-        const u32x4 v4 = v4q[q];
+        const u32x4 v4 = v4q[qq];
 #if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 1      // 1 = everything but the global stores
         asm volatile("" :: "v"(v4[0]), "v"(v4[1]), "v"(v4[2]), "v"(v4[3]));
 #else
@@ -535,6 +542,7 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
         float* dst = racc + ((wm * WTM + i) * 16 + row) * 2;
         lds_add(dst, rsum); lds_add(dst + 1, rsq);
       }
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }

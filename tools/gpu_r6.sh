@@ -32,10 +32,36 @@ for sec in "$@"; do
       timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_quick.json 2> $OUT/bench_quick.err; benchline $OUT/bench_quick.json ;;
     bench_ab)     # whole loop: base library vs the in-tree one, alternating
       for i in 1 2; do
-        FYC_LIB_PATH=$BASE timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_ab_base_$i.json 2> $OUT/bench_ab_base_$i.err
-        timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_ab_new_$i.json 2> $OUT/bench_ab_new_$i.err
+        FYC_BENCH_SHAPES=$OUT/shapes_base_$i.txt FYC_LIB_PATH=$BASE timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_ab_base_$i.json 2> $OUT/bench_ab_base_$i.err
+        FYC_BENCH_SHAPES=$OUT/shapes_new_$i.txt timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_ab_new_$i.json 2> $OUT/bench_ab_new_$i.err
       done
-      benchline $OUT/bench_ab_*.json | tee $OUT/bench_ab.txt ;;
+      benchline $OUT/bench_ab_*.json | tee $OUT/bench_ab.txt
+      python - $OUT <<'PY' | tee $OUT/shapes_ab.txt
+import sys, re, collections
+out = sys.argv[1]
+def load(tag):
+    d = collections.defaultdict(list)
+    for i in (1, 2):
+        try:
+            for l in open(f"{out}/shapes_{tag}_{i}.txt"):
+                f = l.split()
+                d[" ".join(f[6:])].append((float(f[0]), int(f[2].replace("n=", "")) if f[2].startswith("n=") and len(f[2]) > 2 else int(f[3])))
+        except OSError:
+            pass
+    return d
+b, n = load("base"), load("new")
+rows = []
+for k in set(b) | set(n):
+    mb = sum(v[0] for v in b.get(k, [])) / max(len(b.get(k, [])), 1)
+    mn = sum(v[0] for v in n.get(k, [])) / max(len(n.get(k, [])), 1)
+    rows.append((mn - mb, mb, mn, k))
+print("per DDIM step, in the pipeline: base ms -> new ms (delta), sorted by delta")
+for d, mb, mn, k in sorted(rows):
+    if abs(d) >= 0.01:
+        print(f"{mb:8.3f} -> {mn:8.3f}  ({d:+.3f})  {k}")
+print(f"sum of deltas {sum(r[0] for r in rows):+.3f} ms")
+PY
+      ;;
     probe)        # cold-operand per-shape times of the engine's GEMM calls: PROBE_* environment as tools/gemm_probe.py documents
       timeout 900 python tools/gemm_probe.py 2>&1 | tee $OUT/probe_${PROBE_TAG:-default}.txt | cut -c1-150 ;;
     gemm_parity)  # what changed in the GEMM family this round (tile config 11, split-K statistics)
@@ -80,6 +106,26 @@ for sec in "$@"; do
       done
       echo "-- FYC_ABL_EPI=3 (no epilogue)"
       FYC_LIB_PATH=tools/exp/libfyc_abl_epi3.so PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep "GEGLU\|heads\|tQKV\|case" | tee $OUT/probe_epi2_abl3.txt | cut -c1-100 ;;
+    keys_ab)      # in-pipeline per-shape times of the in-tree library under tuning keys (KEYS="12=1 13=1 12=1,13=1")
+      for k in "" ${KEYS:-12=1 13=1}; do
+        tag=$(echo "x$k" | tr '=,' '__')
+        FYC_TUNING=$k FYC_BENCH_SHAPES=$OUT/shapes_keys_$tag.txt timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_keys_$tag.json 2> $OUT/bench_keys_$tag.err
+      done
+      benchline $OUT/bench_keys_*.json
+      python - $OUT <<'PY' | tee $OUT/shapes_keys.txt
+import sys, glob, os
+out = sys.argv[1]
+tabs = {}
+for f in sorted(glob.glob(f"{out}/shapes_keys_*.txt")):
+    tag = os.path.basename(f)[len("shapes_keys_"):-4]
+    tabs[tag] = {" ".join(l.split()[6:]): float(l.split()[0]) for l in open(f)}
+tags = sorted(tabs)
+keys = sorted(tabs[tags[0]], key=lambda k: -tabs[tags[0]][k])
+print("ms per DDIM step in the pipeline |", " | ".join(tags))
+for k in keys[:45]:
+    print(" ".join(f"{tabs[t].get(k, 0):8.3f}" for t in tags), " ", k)
+PY
+      ;;
     *) echo "unknown section $sec" ;;
   esac
 done
