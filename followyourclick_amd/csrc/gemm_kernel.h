@@ -269,10 +269,9 @@ __device__ __forceinline__ void stage_col_constants(const GemmP& p, float* colc,
 // "pass 1" - and that is not its arithmetic but two exposed round trips: the column constants (stage_col_constants) and the LayerNorm row
 // statistics (ln_row) are global loads, loads retire in order, and the next tile's first K-tile DMA is in flight in front of them - every
 // tile of every launch paid the DMA's HBM latency plus its own.  The wide epilogues of the 2-deep-ring kernels now find their inputs in LDS:
-// behind the FIRST barrier of a tile's K loop (every wave has left the previous tile's epilogue) the waves fetch, by global_load_lds,
+// in front of a tile's K loop, behind a barrier (every wave has left the previous tile's epilogue), the waves fetch, by global_load_lds,
 //   [BM] {mean, rstd} | [BN] bias | [BN] LayerNorm column sums | [<= RB_SLOTS][BN] row-bias rows
-// into a region behind the ring; the K loop's own vmcnt(0) + barrier of the next iteration retires them (host: GemmP::pre needs >= 2 K tiles
-// per tile).  No global load and no vmcnt wait is left in those epilogues.
+// into a region behind the ring; the vmcnt(0) + barrier of the tile's first K-loop iteration retires them.  No global load and no vmcnt wait is left in those epilogues.
 template <int BM, int BN> constexpr int pre_bytes() { return BM * 8 + (2 + RB_SLOTS) * BN * 4; }
 template <int BM> __device__ __forceinline__ void pre_ln_row(const char* pre, int row_in_tile, float& mu, float& rs) {
   const float2 ms = *reinterpret_cast<const float2*>(pre + row_in_tile * 8);
@@ -1332,6 +1331,17 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (PRE_BUILT) {
+      // the epilogue's inputs of THIS tile, by DMA, in front of its K loop (not inside it: 200 more instructions in the loop body cost the
+      // convolutions 2-4 %): behind a barrier - nobody reads the previous tile's inputs any more -, retired by the vmcnt(0) + barrier of the
+      // first K-loop iteration
+      if (p.pre) {
+        __builtin_amdgcn_s_barrier();
+        int c_tm, c_tn;
+        tile_coords(p, remap(tile / S), c_tm, c_tn);
+        issue_consts(c_tm, c_tn);
+      }
+    }
     if constexpr (WIDE && EPI == FYC_EPI_LINEAR) {
       if (p.res_acc) {                                 // the residual rides in the accumulators (epilogue_linear_packed)
         int rm, rn;
@@ -1355,13 +1365,6 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       // issue block sits beside its partner's MFMAs.  (Safe with the 2-deep ring: the stage being refilled was consumed by
       // every wave before this barrier, and the late DMAs still have a k-step of both waves to land.)
       // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
-      if constexpr (PRE_BUILT) {
-        if (p.pre && kt == kt_lo) {                      // behind the tile's first barrier: nobody reads the previous tile's inputs any more
-          int c_tm, c_tn;
-          tile_coords(p, remap(tile / S), c_tm, c_tn);
-          issue_consts(c_tm, c_tn);
-        }
-      }
       const bool late = STAGGER && p.stagger && wave >= (WGM * WGN) / 2;
       if (!late && i_tile < nwork) issue_next();
       compute(st_c, 0, 1);
