@@ -499,7 +499,14 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
     // round 6: ALL reads of the block first, by every lane (rows clamped into the staged block), ONE wait, then the predicated stores -
     // inside the `if (live)` each of the NQ reads was followed by its own lgkmcnt(0): 24 exposed LDS round trips per 256x320 tile and wave
     // (in groups of at most QG reads: all six of the 256x320 tile at once cost its kernels 60 more bytes of scratch and the convolutions 1.5 %)
-    constexpr int QG = NQ <= 3 ? NQ : 3;
+    // (QG = 1: read, wait, store - the round-5 order.  Batching the reads of a block - all NQ, or groups of 3 - measured 5-7 % faster on the
+    // short-K linears in the cold-operand probe and 0.1 ms per DDIM step SLOWER in the pipeline, where the convolutions' epilogues lost more than
+    // the linears' gained: profiles/r06_gemm_epilogue_ab.txt.  -DFYC_P2_QG=n rebuilds the batched form.)
+#ifdef FYC_P2_QG
+    constexpr int QG = FYC_P2_QG;
+#else
+    constexpr int QG = 1;
+#endif
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += QG) {
     u32x4 v4q[QG];
