@@ -109,7 +109,7 @@ PY
     keys_ab)      # in-pipeline per-shape times of the in-tree library under tuning keys (KEYS="12=1 13=1 12=1,13=1")
       for k in "" ${KEYS:-12=1 13=1}; do
         tag=$(echo "x$k" | tr '=,' '__')
-        FYC_TUNING=$k FYC_BENCH_SHAPES=$OUT/shapes_keys_$tag.txt timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_keys_$tag.json 2> $OUT/bench_keys_$tag.err
+        FYC_TUNING=$k FYC_BENCH_SHAPES=$OUT/shapes_keys_$tag.txt timeout 600 python bench.py --steps ${KEYS_STEPS:-2} --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_keys_$tag.json 2> $OUT/bench_keys_$tag.err
       done
       benchline $OUT/bench_keys_*.json
       python - $OUT <<'PY' | tee $OUT/shapes_keys.txt
