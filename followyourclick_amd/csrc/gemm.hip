@@ -177,11 +177,13 @@ void choose(const GemmP& p, int batch, int tile, int& cfg, int& ns) {
 int pp_twin(int cfg) { return cfg == 21 ? 5 : cfg == 22 ? 6 : cfg == 23 ? 7 : cfg == 31 ? 6 : cfg; }
 // column-tile width / row-tile height of a tile config (gemm_kernel.h::dispatch_cfg)
 int tile_bn(int cfg) {
-  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: case 21: case 22: case 31: return 320; case 7: case 23: return 256; case 11: return 160; default: return 128; }
+  switch (cfg) { case 2: case 4: return 64; case 5: case 6: case 8: case 12: case 21: case 22: case 31: return 320; case 7: case 13: case 23: return 256; case 11: return 160; default: return 128; }
 }
 int tile_bm(int cfg) {
-  switch (cfg) { case 3: case 4: case 5: case 7: case 21: case 23: return 256; default: return 128; }
+  switch (cfg) { case 3: case 4: case 5: case 7: case 12: case 13: case 14: case 21: case 23: return 256; default: return 128; }
 }
+// the 32x32x16-instruction twin of a tile config (same tile, same wave grid, same epilogues): 0 = none built
+int mi32_twin(int cfg) { return cfg == 5 ? 12 : cfg == 7 ? 13 : cfg == 3 ? 14 : 0; }
 // sample slots a row tile of bm rows can touch when a sample has cs_rows rows
 int stat_slots(int bm, int cs_rows) {
   if (cs_rows % bm == 0) return 1;
@@ -446,6 +448,8 @@ extern "C" int fyc_gemm(const fyc_gemm_args* a, void* stream) {
   }
   if (fycg::ov_cfg(cfg)) return fycg::run_ov(p, cfg, st);
   if (fycg::pp_cfg(cfg)) return a->mode == FYC_GEMM_PLAIN ? fycg::run_pp_plain(p, cfg, st) : fycg::run_pp_conv(p, cfg, st);
+  // 32x32x16 matrix instruction in the K loop of the tiles that have such a twin (fyc_set_tuning key 14: A/B switch)
+  if (p.wide && mi32_twin(cfg) != 0 && g_fyc_tuning[14] == 1) cfg = mi32_twin(cfg);
   if (f16) return a->mode == FYC_GEMM_PLAIN ? fycg::run_f16_plain(p, batch, cfg, ns, st) : fycg::run_f16_conv(p, batch, cfg, ns, st);
   if (a->mode == FYC_GEMM_PLAIN) return fycg::run_bf16_plain(p, batch, cfg, ns, st);
   return fycg::run_bf16_conv(p, batch, cfg, ns, st);

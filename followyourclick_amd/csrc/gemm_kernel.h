@@ -129,6 +129,62 @@ template <> struct Mma<float> {
   }
 };
 
+// ---- 32x32x16 main loop (round 6) ----------------------------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_{bf16,f16} is a 32-cycle instruction: half as many matrix instructions per K tile as the 16x16x32 form, and every one
+// covers twice as many issue cycles of the partner wave's DMA / LDS instructions (profiles/r03_mfma_fill_microbench.txt: a wave interleaving
+// LDS reads gets 26 cycles per 16 cycles of matrix work with it against 41 with the 16-cycle form).  Used as D^T = W x^T like the 16x16 form:
+// a lane of the 32x32 block holds output row m = lane % 32 and columns n = 8 q + 4 (lane / 32) + e for register 4 q + e.
+// The epilogues are written for the 16x16 layout (lane = 16 g + r: row r, columns 4 g + e of a 16x16 block); acc32_to_acc16 re-sorts a block in
+// registers with gfx950's v_permlane32_swap / v_permlane16_swap: (lane bit 5, lane bit 4, register bit q0) of the 32x32 layout are
+// (h, row bit 4, column bit 3); the 16x16 layout wants (column bit 3, h, -) in the lane and row bit 4 in the register index - a 3-cycle
+// of one register bit and two lane bits = the two swaps.  16 VALU instructions per 32x32 block, no LDS.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename T> struct Mma32;
+template <> struct Mma32<bf16_t> {
+  __device__ static __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32<f16_t> {
+  __device__ static __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32<float> {     // (never instantiated with MI = 32: the f32 parity mode keeps v_mfma_f32_16x16x4_f32)
+  __device__ static __forceinline__ f32x16 mma(f32x4, f32x4, f32x16 c) { return c; }
+};
+// X = {X.lo, Y.lo}, Y = {X.hi, Y.hi} (halves of 32 lanes) / X = {X.r0, Y.r0, X.r2, Y.r2}, Y = {X.r1, Y.r1, X.r3, Y.r3} (rows of 16 lanes)
+__device__ __forceinline__ void swap32(float& x, float& y) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& x, float& y) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+// one 32x32 block -> its four 16x16 blocks o[im][jn] (rows 16 im.., columns 16 jn..)
+__device__ __forceinline__ void acc32_to_acc16(const f32x16& c, f32x4& o00, f32x4& o01, f32x4& o10, f32x4& o11) {
+#pragma unroll
+  for (int q1 = 0; q1 < 2; ++q1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = c[8 * q1 + e], y = c[8 * q1 + 4 + e];      // q0 = 0 / 1
+      swap32(x, y);                                          // lane bit 5 <-> q0: registers now indexed by h
+      swap16(x, y);                                          // lane bit 4 <-> h:  registers now indexed by row bit 4
+      if (q1 == 0) { o00[e] = x; o10[e] = y; } else { o01[e] = x; o11[e] = y; }
+    }
+  }
+}
+// the inverse (residual tile loaded in the 16x16 layout -> 32x32 accumulators)
+__device__ __forceinline__ void acc16_to_acc32(f32x16& c, const f32x4& o00, const f32x4& o01, const f32x4& o10, const f32x4& o11) {
+#pragma unroll
+  for (int q1 = 0; q1 < 2; ++q1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = q1 == 0 ? o00[e] : o01[e], y = q1 == 0 ? o10[e] : o11[e];
+      swap16(x, y);
+      swap32(x, y);
+      c[8 * q1 + e] = x; c[8 * q1 + 4 + e] = y;
+    }
+  }
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -151,7 +207,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // swizzle key of an LDS row: 128-B rows (8 chunks) use row&7; 64-B rows (4 chunks) use a 4-entry table over (row>>2)&3 -
 // both make the ds_read_b128 of 16 consecutive rows x one chunk conflict-free under the real 16-lane service groups
-template <int RB> __device__ __forceinline__ int swz_key(int row) {
+template <int RB, int MI = 16> __device__ __forceinline__ int swz_key(int row) {
+  // 32x32x16 fragments: a 16-lane service group of ds_read_b128 holds 16 DIFFERENT rows (8 even, 8 odd) x ONE chunk - (row >> 1) & 7 gives the
+  // 8 rows of a parity 8 different chunk slots in every group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}); row & 7 would pair rows 0 | 24, 12 | 20, ...
+  if (MI == 32) return (row >> 1) & 7;
   if (RB == 128) return row & 7;
   return (0x78 >> (((row >> 2) & 3) * 2)) & 3;   // {0, 2, 3, 1}
 }
@@ -557,6 +616,139 @@ __device__ __forceinline__ void epilogue_linear_packed(const GemmP& p, f32x4 (&a
   if (do_cs || do_rp) stats_flush<BM, BN, WGM, WGM * WGN * 64>(p, cacc, tile_m, tile_n, wave * 64 + lane);
 }
 
+// ---- head-split epilogue, "pack first" (round 6) ---------------------------------------------------------------------------------------------
+// q | k | V^T of the spatial attentions and the q of the cross attentions: 55 tile rounds per DDIM step whose round-2 epilogue staged f32 in two
+// half-width passes and decomposed every chunk it stored (profiles/r06_gemm_epilogue_ablation.txt: 18-20 us per 256x320 tile round against 15
+// for LINEAR and 7 for GEGLU).  Same scheme as epilogue_linear_packed: pass 1 packs the final values (LayerNorm fold as packed FMAs, bias);
+// pass 2 stages 16 rows x the wave's columns as 16-bit words and
+//   * a lane keeps ONE 8-column chunk for the whole tile - its (segment, head, offset) is computed once, not per store - and writes its rows
+//     of the q / k style segments as 16-byte runs along the head dim;
+//   * the transposed segments (V^T [b*H][d][ld]) gather 8 consecutive tokens of one column from the staged rows (8 ds_read_u16) and leave as
+//     16-byte runs along the token axis.
+// Host guarantees (GemmP::wide with FYC_EPI_HEADS): head_dim % 8 == 0, tokens % 16 == 0, transposed pitches % 8 == 0, 16-byte aligned bases.
+template <typename T, int BM, int BN, int WGM, int WGN, int STG_BYTES, int MODE>
+__device__ __forceinline__ void epilogue_heads_packed(const GemmP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], int tile_m, int tile_n,
+                                                      char* stg_stage, int wave, int lane, const char* pre) {
+  static_assert(sizeof(T) == 2, "16-bit outputs only (bf16 / f16)");
+  constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
+  constexpr bool LN = (MODE == FYC_GEMM_PLAIN);
+  constexpr int PITCH = WTN * 32 + 16, CPR = WTN * 2, RPP = 64 / CPR, NQ = (16 + RPP - 1) / RPP;
+  constexpr int SLICE = 16 * PITCH;
+  static_assert(WGM * WGN * SLICE + 2 * BN * 4 <= STG_BYTES, "staging + column constants must fit in one ring stage");
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int g = lane >> 4, r16 = lane & 15;
+  __builtin_amdgcn_s_barrier();                      // every wave is done reading the stage we reuse
+  char* stg = stg_stage + wave * SLICE;
+  float* colc = reinterpret_cast<float*>(stg_stage + WGM * WGN * SLICE);
+  if (pre != nullptr) colc = reinterpret_cast<float*>(const_cast<char*>(pre) + BM * 8);
+  else stage_col_constants<BN, LN>(p, colc, tile_m * BM, tile_n, wave * 64 + lane);
+  const bool has_ln = LN && p.ln_stats != nullptr;
+  f32x2 rs2[WTM], nm2[WTM];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    float mu = 0.f, rs = 1.f;
+    if (has_ln) {
+      if (pre != nullptr) pre_ln_row<BM>(pre, (wm * WTM + i) * 16 + r16, mu, rs);
+      else if (tile_m * BM + (wm * WTM + i) * 16 + r16 < p.M) ln_row(p, tile_m * BM + (wm * WTM + i) * 16 + r16, mu, rs);
+    }
+    rs2[i] = (f32x2){rs * p.out_scale, rs * p.out_scale}; nm2[i] = (f32x2){-rs * mu, -rs * mu};      // out = fma(acc, rs * scale, scale * fma(-rs mu, colsum, bias))
+  }
+  const int nl_w0 = wn * WTN * 16, n_w0 = tile_n * BN + nl_w0;
+  const f32x2 sc2 = {p.out_scale, p.out_scale};
+  // ---- pass 1 ------------------------------------------------------------------------------------------------------------------------
+  u32x2 pk[WTM][WTN];
+  auto pass1 = [&](auto ln_c) __attribute__((always_inline)) {
+    constexpr bool HAS_LN = decltype(ln_c)::value;
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int nl = nl_w0 + j * 16 + g * 4;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(colc + nl);
+      f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (HAS_LN) s4 = *reinterpret_cast<const f32x4*>(colc + BN + nl);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x2 b01 = {b4[0], b4[1]}, b23 = {b4[2], b4[3]}, s01 = {s4[0], s4[1]}, s23 = {s4[2], s4[3]};
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        f32x2 v01 = {acc[i][j][0], acc[i][j][1]}, v23 = {acc[i][j][2], acc[i][j][3]};
+        if (HAS_LN) {
+          v01 = __builtin_elementwise_fma(v01, rs2[i], sc2 * __builtin_elementwise_fma(nm2[i], s01, b01));
+          v23 = __builtin_elementwise_fma(v23, rs2[i], sc2 * __builtin_elementwise_fma(nm2[i], s23, b23));
+        } else {
+          v01 = (v01 + b01) * sc2; v23 = (v23 + b23) * sc2;
+        }
+        unsigned lo = Pair16<T>::pack(v01[0], v01[1]), hi = Pair16<T>::pack(v23[0], v23[1]);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        pk[i][j] = (u32x2){lo, hi};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (has_ln) pass1(std::true_type{}); else pass1(std::false_type{});
+  // ---- pass 2 ------------------------------------------------------------------------------------------------------------------------
+  // (a) this lane's 8-column chunk of the row-major segments, decomposed once
+  const int lrow = lane / CPR, lch = lane - lrow * CPR;
+  const int n_a = n_w0 + lch * 8;
+  const int seg_a = fdiv_small(n_a < p.N ? n_a : 0, p.inv_seg_cols), cs_a = (n_a < p.N ? n_a : 0) - seg_a * p.seg_cols;
+  const int hh_a = fdiv_small(cs_a, p.inv_head_dim), di_a = cs_a - hh_a * p.head_dim;
+  const bool act_a = lrow < RPP && n_a < p.N && !p.seg_transposed[seg_a];
+  T* const S_a = reinterpret_cast<T*>(p.seg_out[seg_a]);
+  // (b) the (column, 8-token half) pairs of the transposed segments this lane gathers: u = lane + 64 k over the wave's WTN * 16 columns x 2.
+  // One word per pair: segment << 28 | head << 16 | offset in the head, -1 = nothing to do (registers: this epilogue runs beside 80 packed
+  // accumulators at the 256-register cap)
+  constexpr int NU = (WTN * 32 + 63) / 64;
+  int dec_b[NU];
+  bool any_b = false;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int u = lane + 64 * k;
+    const int n = n_w0 + (u >> 1);
+    const bool in = u < WTN * 32 && n < p.N;
+    const int seg = fdiv_small(in ? n : 0, p.inv_seg_cols), cs = (in ? n : 0) - seg * p.seg_cols;
+    const int hh = fdiv_small(cs, p.inv_head_dim), di = cs - hh * p.head_dim;
+    dec_b[k] = (in && p.seg_transposed[seg]) ? ((seg << 28) | (hh << 16) | di) : -1;
+    any_b = any_b || dec_b[k] != -1;
+  }
+  const bool wave_b = __builtin_amdgcn_ballot_w64(any_b) != 0;
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    const int m0 = tile_m * BM + (wm * WTM + i) * 16;            // first of the 16 token rows of this block (same batch element: tokens % 16 == 0)
+    const int b = m0 / p.tokens, tok0 = m0 - b * p.tokens;
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) *reinterpret_cast<u32x2*>(stg + r16 * PITCH + j * 32 + g * 8) = pk[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (m0 < p.M) {
+      if (act_a) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int row = q * RPP + lrow;
+          if (row < 16) {
+            const u32x4 v4 = *reinterpret_cast<const u32x4*>(stg + row * PITCH + lch * 16);
+            *reinterpret_cast<u32x4*>(S_a + ((long long)(b * p.heads + hh_a) * p.tokens + tok0 + row) * p.head_dim + di_a) = v4;
+          }
+        }
+      }
+      if (wave_b) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+          if (dec_b[k] != -1) {
+            const int half = lane & 1, seg = dec_b[k] >> 28, hh = (dec_b[k] >> 16) & 0xfff, di = dec_b[k] & 0xffff;
+            T* const Sb = reinterpret_cast<T*>(seg == 0 ? p.seg_out[0] : seg == 1 ? p.seg_out[1] : p.seg_out[2]);
+            const int ldb = seg == 0 ? p.seg_ld[0] : seg == 1 ? p.seg_ld[1] : p.seg_ld[2];
+            const char* src = stg + (half * 8) * PITCH + ((lane + 64 * k) >> 1) * 2;
+            unsigned short w[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w[r] = *reinterpret_cast<const unsigned short*>(src + r * PITCH);
+            const u32x4 v4 = {(unsigned)w[0] | ((unsigned)w[1] << 16), (unsigned)w[2] | ((unsigned)w[3] << 16), (unsigned)w[4] | ((unsigned)w[5] << 16),
+                              (unsigned)w[6] | ((unsigned)w[7] << 16)};
+            *reinterpret_cast<u32x4*>(Sb + ((long long)(b * p.heads + hh) * p.head_dim + di) * ldb + tok0 + half * 8) = v4;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // ---- GEGLU epilogue, "pack first" (round 6) ---------------------------------------------------------------------------------------------
 // The feed-forward projections of levels 1-3 (N = 5120 / 10240: 8 / 4 tile rounds per launch, 120 of the 533 tile rounds of a DDIM step) ran the
 // round-1 epilogue: every 16-row block was gated in f32, staged as f32 in two half-width passes, read back and packed, each step behind its own
@@ -702,6 +894,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
   // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j) ---------------------------------
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
   const T* R = reinterpret_cast<const T*>(p.residual);
+  if constexpr (WIDE && EPI == FYC_EPI_HEADS && sizeof(T) == 2) {
+    if (p.fast1) {
+#if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 3      // timing build: no epilogue (the accumulators stay alive)
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+      return;
+#endif
+      epilogue_heads_packed<T, BM, BN, WGM, WGN, STG_BYTES, MODE>(p, acc, tile_m, tile_n, stg_stage, wave, lane, pre);
+      return;
+    }
+  }
   if constexpr (WIDE && EPI == FYC_EPI_HEADS) {
     // Wide head-split epilogue.  The plain path stores what a lane holds - 4 consecutive channels (8 B) for q / k and four
     // single bf16 values a whole row pitch apart for the transposed V^T.  Here each wave stages its f32 tile through LDS
@@ -1096,7 +1301,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
   }  // !WIDE
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false, int MI = 16>
 __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) {
   typedef Mma<T> Tr;
   typedef typename Tr::Frag Frag;
@@ -1109,6 +1314,8 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   constexpr int LOADS = A_IT + B_IT;       // DMA instructions per thread per K tile
   constexpr int WTM = BM / WGM / 16, WTN = BN / WGN / 16;
   static_assert(EPI != FYC_EPI_GEGLU || WTN % 2 == 0, "GEGLU pairs value / gate column blocks inside a wave");
+  constexpr bool M32 = (MI == 32);       // 32x32x16 matrix instruction in the K loop (16-bit operands, 128-byte K tiles, even block counts)
+  static_assert(MI == 16 || (MI == 32 && sizeof(T) == 2 && RB == 128 && WTM % 2 == 0 && WTN % 2 == 0), "32x32x16 main loop: 16-bit operands, wave tile of whole 32x32 blocks");
   constexpr int A_BYTES = BM * RB, STAGE = (BM + BN) * RB;
   constexpr bool STAGGER = (WGM * WGN == 8) && KSTEPS >= 2 && NS == 2;
   static_assert(A_IT * NT == BM * CPR && B_IT * NT == BN * CPR, "tile/threads mismatch");
@@ -1142,7 +1349,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   // K offset is the same for every `it` and for both operands.  Addresses are rebuilt from (tile, it) at issue time (a few
   // VALU ops per 1 KiB DMA); only the conv gather keeps per-row state (pixel base and packed top-left tap position).
   const int lrow = tid / CPR;
-  const int koff = ((tid % CPR) ^ swz_key<RB>(lrow)) * CH;
+  const int koff = ((tid % CPR) ^ swz_key<RB, MI>(lrow)) * CH;
   constexpr int ROWS_IT = NT / CPR;
   static_assert(ROWS_IT % 16 == 0, "row stride per DMA instruction must keep the swizzle key");
   int i_tm = 0, i_tn = 0;                 // tile coordinates of the tile being issued (wave-uniform)
@@ -1226,6 +1433,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   };
 
   f32x4 acc[WTM][WTN];
+  f32x16 acc32[M32 ? WTM / 2 : 1][M32 ? WTN / 2 : 1];      // (M32: the K loop accumulates here; acc is filled from it behind the loop)
   FYC_STAMP_DECL;
   int fyc_trace_e = 0;      // (timing builds: stamps inside the packed epilogue)
 
@@ -1253,6 +1461,32 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 #pragma unroll
         for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bf[j], af[i], acc[i][j]);
       if (FRAG_ALL) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // 32x32x16 form: k32-step s = two k16-steps; lane (h = lane / 32, r32 = lane % 32) reads row r32 of a 32-row block, chunk 2 s' + h
+  const int r32 = lane & 31, h32 = lane >> 5;
+  const int sw32 = swz_key<RB, 32>(r32);
+  auto compute32 = [&](int stage, int s0, int s1) {
+    constexpr int BI = M32 ? WTM / 2 : 1, BJ = M32 ? WTN / 2 : 1;
+    const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r32) * RB;
+    const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r32) * RB;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {            // one k32 step = the fragments of its two k16 steps read together, then 2 x BI x BJ instructions
+      if (s < s0 || s >= s1) continue;
+      const int coff0 = ((4 * s + h32) ^ sw32) * 16, coff1 = ((4 * s + 2 + h32) ^ sw32) * 16;
+      Frag af[2][BI], bf[2][BJ];
+#pragma unroll
+      for (int i = 0; i < BI; ++i) { af[0][i] = *reinterpret_cast<const Frag*>(sA + i * 32 * RB + coff0); af[1][i] = *reinterpret_cast<const Frag*>(sA + i * 32 * RB + coff1); }
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) { bf[0][j] = *reinterpret_cast<const Frag*>(sB + j * 32 * RB + coff0); bf[1][j] = *reinterpret_cast<const Frag*>(sB + j * 32 * RB + coff1); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+#pragma unroll
+          for (int j = 0; j < BJ; ++j) acc32[i][j] = Mma32<T>::mma(bf[u][j], af[u][i], acc32[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto issue = [&](int kt, int stage) {
@@ -1338,6 +1572,14 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (M32) {
+#pragma unroll
+      for (int i = 0; i < WTM / 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN / 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    }
     if constexpr (PRE_BUILT) {
       // the epilogue's inputs of THIS tile, by DMA, in front of its K loop (not inside it: 200 more instructions in the loop body cost the
       // convolutions 2-4 %): behind a barrier - nobody reads the previous tile's inputs any more -, retired by the vmcnt(0) + barrier of the
@@ -1354,6 +1596,12 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
         int rm, rn;
         tile_coords(p, remap(tile / S), rm, rn);
         load_residual_acc<T, BM, BN, WGM, WGN>(p, acc, rm, rn, wave, lane);
+        if constexpr (M32) {
+#pragma unroll
+          for (int i = 0; i < WTM / 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN / 2; ++j) acc16_to_acc32(acc32[i][j], acc[2 * i][2 * j], acc[2 * i][2 * j + 1], acc[2 * i + 1][2 * j], acc[2 * i + 1][2 * j + 1]);
+        }
       }
     }
     FYC_STAMP(p, wave, lane);
@@ -1374,10 +1622,16 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
       const bool late = STAGGER && p.stagger && wave >= (WGM * WGN) / 2;
       if (!late && i_tile < nwork) issue_next();
-      compute(st_c, 0, 1);
+      if constexpr (M32) compute32(st_c, 0, 1); else compute(st_c, 0, 1);
       if (late && i_tile < nwork) issue_next();
-      compute(st_c, 1, KSTEPS);
+      if constexpr (M32) compute32(st_c, 1, KSTEPS); else compute(st_c, 1, KSTEPS);
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    }
+    if constexpr (M32) {      // 32x32 blocks -> the 16x16 layout every epilogue (and the split-K partial store) is written for
+#pragma unroll
+      for (int i = 0; i < WTM / 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN / 2; ++j) acc32_to_acc16(acc32[i][j], acc[2 * i][2 * j], acc[2 * i][2 * j + 1], acc[2 * i + 1][2 * j], acc[2 * i + 1][2 * j + 1]);
     }
     FYC_STAMP(p, wave, lane);
     const int t = remap(tile / S);
@@ -1411,12 +1665,12 @@ inline int rowbias_slots(int bm, int rpb) {
   return n <= RB_SLOTS ? n : 0;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, int EPI, int NS, int RB = 128, bool WIDE = false, int MI = 16>
 int launch(const GemmP& p, int batch, hipStream_t st) {
   constexpr bool PRE_BUILT = WIDE && NS == 2;
   constexpr int smem = NS * (BM + BN) * RB + (PRE_BUILT ? pre_bytes<BM, BN>() : 0);
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS, RB, WIDE>;
+  auto kern = fyc_gemm_kernel<T, BM, BN, WGM, WGN, MODE, EPI, NS, RB, WIDE, MI>;
   int dev = 0;
   (void)hipGetDevice(&dev);
   // per-device one-time setup (attribute + CU count), guarded: one process may drive several GPUs from several threads
@@ -1507,6 +1761,10 @@ int dispatch_cfg(int cfg, int ns, const GemmP& p, int batch, hipStream_t st) {
       // round 6: 128x160 over 2x2 waves (64x80 per wave, the wave tile of config 6) with 72 KB of ring: TWO independent workgroups per CU,
       // so one's epilogue / first fill runs under the other's K loop - for the short-K problems whose 128x320 tiles spend as long in the
       // epilogue as in the K loop (profiles/r06_gemm_two_workgroups_ab.txt)
+      // round 6: the 32x32x16 matrix instruction in the K loop (same tiles and wave grids as 5 / 7 / 3)
+      case 12: return launch<T, 256, 320, 4, 2, MODE, EPI, 2, 128, true, 32>(p, batch, st);
+      case 13: return launch<T, 256, 256, 2, 4, MODE, EPI, 2, 128, true, 32>(p, batch, st);
+      case 14: return launch<T, 256, 128, 4, 2, MODE, EPI, 2, 128, true, 32>(p, batch, st);
       case 11: if constexpr (EPI == FYC_EPI_GEGLU) FYC_FAIL(-2, "fyc_gemm: tile config 11 gives a wave an odd number of column blocks: not built for GEGLU");
                else return launch<T, 128, 160, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
     }

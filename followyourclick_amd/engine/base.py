@@ -7,13 +7,27 @@ from .. import _lib as L
 
 Tensor = torch.Tensor
 
+# Debug aid: ALLOC_FILL = a byte value makes every buffer the engines allocate start as that byte pattern instead of whatever the
+# caching allocator hands back (0xFF = NaN in bf16 / f16 / f32 / f64).  A kernel that reads memory nobody wrote - rows past M, partial-sum
+# slots the producer skipped - then shows up as a result that depends on the fill: tests/test_uninit_gpu.py runs the forward under two
+# fills and demands identical bits.  FYC_ALLOC_FILL=255 sets it from the environment.
+import os as _os
+ALLOC_FILL = int(_os.environ["FYC_ALLOC_FILL"]) if _os.environ.get("FYC_ALLOC_FILL") else None
+
+
+def empty(*shape, dtype, device) -> Tensor:
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if ALLOC_FILL is not None and t.numel():
+        t.view(torch.uint8).fill_(ALLOC_FILL)
+    return t
+
 
 class EngineBase:
     """Expects self.ops, self.dtype, self.device and self.groups (GroupNorm group count)."""
 
     # ---- buffers -----------------------------------------------------------------------------
     def new(self, *shape, dtype=None) -> Tensor:
-        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+        return empty(*shape, dtype=dtype or self.dtype, device=self.device)
 
     def zeros(self, *shape, dtype=None) -> Tensor:
         return torch.zeros(*shape, dtype=dtype or self.dtype, device=self.device)

@@ -187,7 +187,7 @@ class UNet3DEngine(EngineBase):
 
     def row_stats(self, x: Tensor, rows: int, C: int, eps: float = 1e-5) -> Tensor:
         """{mean, rstd} per token row: the statistics half of a LayerNorm whose affine half lives in the next GEMM"""
-        st = torch.empty(rows, 2, dtype=torch.float32, device=self.device)
+        st = self.new(rows, 2, dtype=torch.float32)
         self.ops.row_stats(x, st, rows=rows, C_=C, eps=eps)
         return st
 
@@ -204,13 +204,13 @@ class UNet3DEngine(EngineBase):
         nt, tile_rows, slots = self.ops.gemm_stat_layout(self.dtype, M=rows, N=N, K=K, cs_rows=rows_per_sample, mode=mode)
         if not 1 <= slots <= 4:
             return None
-        return torch.empty(nt * slots * N * 2, dtype=torch.float32, device=self.device), tile_rows, slots
+        return self.new(nt * slots * N * 2, dtype=torch.float32), tile_rows, slots
 
     def _cs_finish(self, plan, rows: int, rows_per_sample: int, N: int, out_rows: int) -> Tensor:
         """per-(GroupNorm sample, channel) f64 sums from the epilogue's row-tile partials; out_rows = rows of the consuming
         norm's sample (a frame, or the F frames of a clip)"""
         parts, tile_rows, slots = plan
-        cs = torch.empty(rows // out_rows, N, 2, dtype=torch.float64, device=self.device)
+        cs = self.new(rows // out_rows, N, 2, dtype=torch.float64)
         self.ops.chan_stats_reduce(parts, cs, rows=rows, N=N, cs_rows=rows_per_sample, tile_rows=tile_rows, slots=slots, out_rows=out_rows)
         return cs
 
@@ -246,7 +246,7 @@ class UNet3DEngine(EngineBase):
         rp, n = None, 0
         if self.fuse_rows:
             n = self.ops.gemm_row_parts(x.dtype, M=rows, N=N, K=K)
-            rp = torch.empty(rows, n, 2, dtype=torch.float32, device=self.device)
+            rp = self.new(rows, n, 2, dtype=torch.float32)
         self.ops.gemm(x, w, out, M=rows, N=N, K=K, lda=K, ldw=K, ldo=N, bias=bias, residual=residual, ldr=N, row_parts=rp, row_nparts=n)
         return Act(out, N, rp=rp, rp_n=n)
 
@@ -349,7 +349,7 @@ class UNet3DEngine(EngineBase):
             if "_wstream" not in ff:
                 ff["_wstream"] = pack_ff_block(ff)
             out = self.new(rows, C)
-            parts = torch.empty(rows // 128 * C * 2, dtype=torch.float32, device=self.device) if cs_rows else None
+            parts = self.new(rows // 128 * C * 2, dtype=torch.float32) if cs_rows else None
             self.ops.ff_block(tok.t, residual, out, wstream=ff["_wstream"], b_out=ff.po_b, rows=rows, C_=C, hidden=hidden,
                               chan_parts=parts, cs_rows=cs_rows)
             cs = self._cs_finish((parts, 128, 1), rows, nxt[0], C, nxt[1]) if cs_rows else None
@@ -368,7 +368,7 @@ class UNet3DEngine(EngineBase):
         rp, rp_n = None, 0
         if residual is None and self.fuse_rows:      # inner motion blocks: the output is the next block's token stream (LayerNorm input)
             rp_n = self.ops.gemm_row_parts(tok.t.dtype, M=rows, N=C, K=K)
-            rp = torch.empty(rows, rp_n, 2, dtype=torch.float32, device=self.device)
+            rp = self.new(rows, rp_n, 2, dtype=torch.float32)
         self.ops.gemm(tok.t, ff.po_w, out, M=rows, N=C, K=K, lda=C, ldw=K, ldo=C, bias=ff.po_b, residual=residual, ldr=C,
                       a2=hmid, k_split=C, lda2=K - C, chan_parts=None if plan is None else plan[0], cs_rows=nxt[0] if plan is not None else 0,
                       row_parts=rp, row_nparts=rp_n)

@@ -202,6 +202,46 @@ def time_reference_cpu(frames=16, size=512, ddim_steps=25, timed=1, cores=None):
                        f"untimed step at the same shape ({times[0]:.1f}s); {n} threads bound to physical cores of NUMA node 0; frames/s = {frames} / ({ddim_steps} x {dt:.1f}s)")
 
 
+class GpuTurn:
+    """The reference subprocess and the test session that started it take TURNS on the chip.  Round 6 first let the two run side by side:
+    the reference's eager f32 forwards at 32f@768^2 made every test that ran beside them 3-8x slower (the suite 1 163 s on one box against
+    the driver's 1 200-s limit).  Now only the HOST side of the reference (building the 1.28 B-parameter model, ~40 s per configuration)
+    overlaps the tests.  Protocol, files in the session's out-dir: the subprocess creates `ref_wants_gpu`, takes flock(`gpu.lock`) - the test
+    that is running finishes first -, computes, releases, removes the flag; tests/conftest.py holds the lock for the length of each GPU test
+    and does not start one while the flag exists.  Without an out-dir (single dumps, bench.py) the context does nothing."""
+
+    def __init__(self, out_dir):
+        import os
+        self.dir = out_dir if (out_dir and os.environ.get("FYC_REF_NO_TURNS") != "1") else None
+        self.fd = None
+
+    def __enter__(self):
+        if self.dir is None:
+            return self
+        import fcntl
+        import os
+        open(os.path.join(self.dir, "ref_wants_gpu"), "w").close()
+        self.fd = os.open(os.path.join(self.dir, "gpu.lock"), os.O_CREAT | os.O_RDWR)
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        if self.dir is None:
+            return False
+        import fcntl
+        import os
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        os.close(self.fd)
+        self.fd = None
+        try:
+            os.remove(os.path.join(self.dir, "ref_wants_gpu"))
+        except FileNotFoundError:
+            pass
+        return False
+
+
 def dump(what, out=None, out_dir=None):
     """tests/test_reference_gpu.py runs the reference in a SUBPROCESS (`python -m oracle.gpu_reference --dump a,b --out-dir D`, one per
     test session, started by tests/conftest.py while the kernel tests run): the reference's `animatediff` / `diffusers` packages and the
@@ -217,13 +257,14 @@ def dump(what, out=None, out_dir=None):
     golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     whats = what.split(",")
     models = {}
+    turn = GpuTurn(out_dir)
 
     def model(ocfg):
         key = repr(ocfg)
         if key not in models:
             models.clear()                       # one reference model on the device at a time
             torch.cuda.empty_cache()
-            models[key] = build_reference_unet(dev, attention="sdpa", ocfg=ocfg)[1]
+            models[key] = build_reference_unet("cpu", attention="sdpa", ocfg=ocfg)[1]      # on the HOST: this is the part that overlaps the test session
         return models[key]
 
     for w in whats:
@@ -233,16 +274,21 @@ def dump(what, out=None, out_dir=None):
             unet = model(TRAJECTORIES["cfg3"]()[5] if "cfg3" in whats else Fn.UNetConfig())
             inp = W.seeded_inputs(Fn.UNetConfig(), 1, int(g["frames"]), int(g["h"]), int(g["w"]), seed=int(g["input_seed"]))
             x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
-            res = {name: forward(unet, x9, int(g["timestep"]), inp["text"], torch.from_numpy(g["fps"]), torch.from_numpy(g["flow"]), ac).cpu()
-                   for name, ac in (("f32", None), ("bf16", torch.bfloat16), ("f16", torch.float16))}
+            with turn:
+                unet.to(dev)
+                res = {name: forward(unet, x9, int(g["timestep"]), inp["text"], torch.from_numpy(g["fps"]), torch.from_numpy(g["flow"]), ac).cpu()
+                       for name, ac in (("f32", None), ("bf16", torch.bfloat16), ("f16", torch.float16))}
         else:
             frames, lat, num_steps, run_steps, seed, ocfg, mask, use_ip = TRAJECTORIES[w]()
             unet = model(ocfg)
             inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
             # (f32_steps < run_steps: the reference's f32 forward at 32f@768^2 takes ~50 s on the chip - eager kernels - and the f32 mode of the
             # engine is pinned at that shape by the stored golden of tests/test_fullwidth_gpu.py as well: one f32 step, two under autocast)
-            res = {name: reference_trajectory(unet, inp, num_steps, n, ac, mask=mask, ip_tokens=inp["ip_tokens"] if use_ip else None)
-                   for name, ac, n in (("bf16", torch.bfloat16, run_steps), ("f32", None, F32_STEPS.get(w, run_steps)))}
+            with turn:
+                unet.to(dev)
+                res = {name: reference_trajectory(unet, inp, num_steps, n, ac, mask=mask, ip_tokens=inp["ip_tokens"] if use_ip else None)
+                       for name, ac, n in (("bf16", torch.bfloat16, run_steps), ("f32", None, F32_STEPS.get(w, run_steps)))}
+                torch.cuda.synchronize()
         res["seconds"] = time.time() - t0
         path = out if (out and len(whats) == 1) else os.path.join(out_dir, w + ".pt")
         torch.save(res, path + ".tmp")

@@ -29,6 +29,74 @@ def _fresh_library():
     yield
 
 
+class _GpuTurn:
+    """this session's side of oracle/gpu_reference.py::GpuTurn: a GPU test holds flock(<ref dir>/gpu.lock) while it runs and does not start
+    while the reference subprocess has asked for the chip (`ref_wants_gpu`); released around waits for the subprocess's outputs"""
+
+    def __init__(self):
+        self.fd = None
+
+    def acquire(self):
+        d = _REF_PROC.get("dir")
+        if d is None or self.fd is not None:
+            return
+        import fcntl
+        import time
+        flag, proc = os.path.join(d, "ref_wants_gpu"), _REF_PROC.get("proc")
+        while True:
+            while os.path.exists(flag) and proc is not None and proc.poll() is None:
+                time.sleep(0.1)
+            fd = os.open(os.path.join(d, "gpu.lock"), os.O_CREAT | os.O_RDWR)
+            fcntl.flock(fd, fcntl.LOCK_EX)
+            if os.path.exists(flag) and proc is not None and proc.poll() is None:      # asked for between our check and our lock: its turn
+                fcntl.flock(fd, fcntl.LOCK_UN)
+                os.close(fd)
+                continue
+            self.fd = fd
+            return
+
+    def release(self):
+        if self.fd is None:
+            return
+        import fcntl
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        os.close(self.fd)
+        self.fd = None
+
+
+_TURN = _GpuTurn()
+
+
+@pytest.fixture(autouse=True)
+def _library_state_survives_the_test(request):
+    """Around every GPU test: this session's turn on the chip (see _GpuTurn).  After it: the zero page fyc_init() was given (conv padding
+    taps, rows past M, masked attention tiles all read it) still holds zeros - a test that broke it would change the numbers of every later
+    test of the session without failing itself."""
+    is_gpu = request.node.get_closest_marker("gpu") is not None
+    if is_gpu:
+        _TURN.acquire()
+    try:
+        yield
+    finally:
+        if is_gpu:
+            _TURN.release()
+    if not is_gpu:
+        return
+    from followyourclick_amd import ops
+    o = ops.impl
+    if o is None or getattr(o, "_zero", None) is None:
+        return
+    import torch
+    torch.cuda.synchronize()
+    assert not bool(o._zero.any()), f"{request.node.nodeid} left the library's zero page non-zero"
+
+
 # ---- session-wide caches for the full-width GPU tests (round 6: the suite built the same 1.28 B-parameter seeded state dict 8 times
 # - 22 s each - and packed the same engines up to 5 times) -------------------------------------------------------------------------------
 class _FullWidthCache:
@@ -135,11 +203,13 @@ def device_reference():
         proc, path = _REF_PROC["proc"], os.path.join(_REF_PROC["dir"], what + ".pt")
         assert what in _REF_PROC["what"], (what, _REF_PROC["what"])
         t0 = time.time()
+        _TURN.release()                       # the subprocess may need the chip to produce what we wait for
         while not os.path.exists(path):
             if proc.poll() is not None and not os.path.exists(path):
                 _REF_PROC["log"].flush()
                 raise AssertionError("the reference subprocess ended without " + what + ".pt:\n" + open(os.path.join(_REF_PROC["dir"], "log.txt")).read()[-3000:])
             assert time.time() - t0 < timeout, f"no {what}.pt after {timeout} s"
             time.sleep(1.0)
+        _TURN.acquire()
         return torch.load(path)
     return get

@@ -72,6 +72,19 @@ def test_full_width_forward_vs_reference(golden_dir, engines):
         if dtype == torch.float32:
             assert r32 < 1e-3, r32
         else:
+            if not r32 < BF16_FACTOR * drift:
+                # round 6: this bound failed once (2.36e-2, a library built from a half-edited source) inside a full-suite run and could not be
+                # reproduced alone - a failure now says what kind it is: a second forward of the same engine, and a freshly packed engine
+                # from the same weights, on the same inputs
+                out2 = eng.forward(_nhwc(x9, dtype), temb, 2, F, H, Wd).float().cpu().reshape(2, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+                from followyourclick_amd import ops as _ops
+                zero_ok = not bool(_ops.get()._zero.any())
+                fresh = UNet3DEngine(pack_unet(W.make_weights(W.unet_state_shapes(cfg), 0), UNet3DConfig(), dtype, DEV))
+                fresh.prepare_context(inp["text"])
+                _, temb3 = fresh.prepare_time_embeddings([int(g["timestep"])], g["fps"].tolist(), g["flow"].tolist(), 2)
+                out3 = fresh.forward(_nhwc(x9, dtype), temb3, 2, F, H, Wd).float().cpu().reshape(2, F, H, Wd, 4).permute(0, 4, 1, 2, 3)
+                report(f"full-width fwd bf16 FAILED its bound: second forward of the same engine {rel(out2, g['out_f32']):.3e} (identical to the first: "
+                       f"{torch.equal(out, out2)}), freshly packed engine {rel(out3, g['out_f32']):.3e}, zero page intact: {zero_ok}")
             assert r32 < BF16_FACTOR * drift, (r32, drift)
             assert r16 < BF16_VS_BF16 * drift, (r16, drift)
 

@@ -57,3 +57,43 @@ def test_reference_trajectory_reproduces_the_oracle_loop():
     assert r.returncode == 0, r.stderr[-2000:]
     rel = float([l for l in r.stdout.splitlines() if l.startswith("REL")][-1].split()[1])
     assert rel < 2e-5, rel
+
+
+def test_reference_subprocess_and_session_take_turns_on_the_chip(tmp_path):
+    """tests/conftest.py::_GpuTurn vs oracle/gpu_reference.py::GpuTurn (two processes, no GPU needed): the subprocess's turn waits for the
+    test that holds the lock, and the session does not start its next test while the subprocess has asked for the chip"""
+    import subprocess
+    import sys
+    import time
+    import conftest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time, os; sys.path.insert(0, %r)\n"
+            "from oracle.gpu_reference import GpuTurn\n"
+            "d = sys.argv[1]\n"
+            "with GpuTurn(d):\n"
+            "    open(os.path.join(d, 'ref_started'), 'w').close(); time.sleep(1.0)\n"
+            "open(os.path.join(d, 'ref_done'), 'w').close()\n") % root
+    old = dict(conftest._REF_PROC)
+    turn = conftest._GpuTurn()
+    try:
+        conftest._REF_PROC.clear()
+        conftest._REF_PROC.update(dir=str(tmp_path), proc=None)
+        turn.acquire()                                       # "a GPU test is running"
+        proc = subprocess.Popen([sys.executable, "-c", code, str(tmp_path)])
+        conftest._REF_PROC["proc"] = proc
+        t0 = time.time()
+        while not os.path.exists(tmp_path / "ref_wants_gpu"):
+            assert time.time() - t0 < 120 and proc.poll() is None
+            time.sleep(0.05)
+        time.sleep(0.5)
+        assert not os.path.exists(tmp_path / "ref_started")  # it waits for the running test
+        turn.release()
+        turn.acquire()                                       # "the next test": must not start before the subprocess's turn is over
+        assert os.path.exists(tmp_path / "ref_started")
+        assert not os.path.exists(tmp_path / "ref_wants_gpu")
+        turn.release()
+        assert proc.wait(timeout=60) == 0 and os.path.exists(tmp_path / "ref_done")
+    finally:
+        turn.release()
+        conftest._REF_PROC.clear()
+        conftest._REF_PROC.update(old)

@@ -106,6 +106,11 @@ PY
       done
       echo "-- FYC_ABL_EPI=3 (no epilogue)"
       FYC_LIB_PATH=tools/exp/libfyc_abl_epi3.so PROBE_SWEEP=1 PROBE_CFGS=0,5,6 timeout 600 python tools/gemm_probe.py 2>&1 | grep "GEGLU\|heads\|tQKV\|case" | tee $OUT/probe_epi2_abl3.txt | cut -c1-100 ;;
+    mi32)         # 32x32x16 matrix instruction in the K loop (tile configs 12 / 13 / 14 = twins of 5 / 7 / 3): parity, cold-operand probe, whole loop
+      timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_kernels_f16_gpu.py -x -q -k "test_gemm_plain or test_gemm_conv or output_statistics or heads or split_k or geglu" 2>&1 | tail -6 | tee $OUT/mi32_parity.txt
+      PROBE_SWEEP=1 PROBE_CFGS=${MI32_CFGS:-0,5,12,7,13,3,14} timeout 900 python tools/gemm_probe.py > $OUT/probe_mi32.txt 2>&1; grep -v amdgpu.ids $OUT/probe_mi32.txt | cut -c1-130 ;;
+    mi32_probe)   # the probe alone
+      PROBE_SWEEP=1 PROBE_CFGS=${MI32_CFGS:-0,5,12} timeout 900 python tools/gemm_probe.py > $OUT/probe_mi32_v2.txt 2>&1; grep -v amdgpu.ids $OUT/probe_mi32_v2.txt | cut -c1-130 ;;
     keys_ab)      # in-pipeline per-shape times of the in-tree library under tuning keys (KEYS="12=1 13=1 12=1,13=1")
       for k in "" ${KEYS:-12=1 13=1}; do
         tag=$(echo "x$k" | tr '=,' '__')
