@@ -183,7 +183,11 @@ int tile_bm(int cfg) {
   switch (cfg) { case 3: case 4: case 5: case 7: case 12: case 13: case 14: case 21: case 23: return 256; default: return 128; }
 }
 // the 32x32x16-instruction twin of a tile config (same tile, same wave grid, same epilogues): 0 = none built
+#ifdef FYC_GEMM_MI32
 int mi32_twin(int cfg) { return cfg == 5 ? 12 : cfg == 7 ? 13 : cfg == 3 ? 14 : 0; }
+#else
+int mi32_twin(int) { return 0; }
+#endif
 // sample slots a row tile of bm rows can touch when a sample has cs_rows rows
 int stat_slots(int bm, int cs_rows) {
   if (cs_rows % bm == 0) return 1;

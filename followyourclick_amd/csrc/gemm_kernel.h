@@ -61,6 +61,7 @@ struct GemmP {
   int res_acc;   // bf16 LINEAR wide epilogue: the residual tile is loaded INTO the accumulators before the K loop (see epilogue_linear_packed)
   float inv_seg_cols, inv_head_dim;   // HEADS epilogue: reciprocals for fdiv_small (host: fyc_gemm)
   int fast1;   // packed LINEAR epilogue: specialised pass 1 (fyc_set_tuning key 13 = 1: the generic one, A/B)
+  int heads_pk; // head-split epilogue: the pack-first form (epilogue_heads_packed) - M <= 8192 only, see launch()
   int pre;     // round 6: the epilogue's per-row / per-column inputs are already in LDS (issue_consts in fyc_gemm_kernel), see pre_bytes()
   int phase_delay;   // round 6 (A/B, fyc_set_tuning key 11): every other block of an XCD starts this many x 1024 cycles late, see fyc_gemm_kernel
   unsigned long long* trace;   // timing builds (-DFYC_TRACE, tools/gemm_phase_probe.py): per-block s_memtime stamps; nullptr otherwise
@@ -895,7 +896,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[BM / 
   T* O = reinterpret_cast<T*>(p.out) + bz * p.stride_o;
   const T* R = reinterpret_cast<const T*>(p.residual);
   if constexpr (WIDE && EPI == FYC_EPI_HEADS && sizeof(T) == 2) {
-    if (p.fast1) {
+    if (p.fast1 && p.heads_pk) {
 #if defined(FYC_ABL_EPI) && FYC_ABL_EPI == 3      // timing build: no epilogue (the accumulators stay alive)
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
@@ -1706,6 +1707,10 @@ int launch(const GemmP& p, int batch, hipStream_t st) {
              (p.ln_stats == nullptr || (p.M % 2 == 0 && ((uintptr_t)p.ln_stats % 16) == 0))) ? 1 : 0;
   }
   q.fast1 = g_fyc_tuning[13] == 1 ? 0 : 1;
+  // pack-first head-split epilogue: in the pipeline it wins at the 16x16 level only (8192x3840x1280 0.588 -> 0.562 ms per DDIM step, 8192x1280x1280
+  // 0.235 -> 0.212) and LOSES at the 64x64 / 32x32 levels (131072x960x320 0.970 -> 1.051, 32768x1920x640 0.666 -> 0.756: profiles/r06_gemm_epilogue_ab.txt
+  // part 4) - key 15 = 1 forces it on, 2 off
+  q.heads_pk = g_fyc_tuning[15] == 1 ? 1 : g_fyc_tuning[15] == 2 ? 0 : (p.M <= 8192 ? 1 : 0);
   q.stagger = g_fyc_tuning[5] == 1 ? 0 : 1;
   q.phase_delay = g_fyc_tuning[11] > 0 ? g_fyc_tuning[11] : 0;
   q.res_acc = (WIDE && EPI == FYC_EPI_LINEAR && p.residual != nullptr && p.ln_stats == nullptr && !(q.splitk > 1)) ? 1 : 0;
@@ -1761,10 +1766,13 @@ int dispatch_cfg(int cfg, int ns, const GemmP& p, int batch, hipStream_t st) {
       // round 6: 128x160 over 2x2 waves (64x80 per wave, the wave tile of config 6) with 72 KB of ring: TWO independent workgroups per CU,
       // so one's epilogue / first fill runs under the other's K loop - for the short-K problems whose 128x320 tiles spend as long in the
       // epilogue as in the K loop (profiles/r06_gemm_two_workgroups_ab.txt)
-      // round 6: the 32x32x16 matrix instruction in the K loop (same tiles and wave grids as 5 / 7 / 3)
+      // round 6: the 32x32x16 matrix instruction in the K loop (same tiles and wave grids as 5 / 7 / 3).  Parity-green, 8-12 % SLOWER than the
+      // 16x16x32 loop on every shape (profiles/r06_gemm_mi32_ab.txt): only in builds with FYC_BUILD_EXTRA=-DFYC_GEMM_MI32 (tests: FYC_TEST_MI32=1)
+#ifdef FYC_GEMM_MI32
       case 12: return launch<T, 256, 320, 4, 2, MODE, EPI, 2, 128, true, 32>(p, batch, st);
       case 13: return launch<T, 256, 256, 2, 4, MODE, EPI, 2, 128, true, 32>(p, batch, st);
       case 14: return launch<T, 256, 128, 4, 2, MODE, EPI, 2, 128, true, 32>(p, batch, st);
+#endif
       case 11: if constexpr (EPI == FYC_EPI_GEGLU) FYC_FAIL(-2, "fyc_gemm: tile config 11 gives a wave an odd number of column blocks: not built for GEGLU");
                else return launch<T, 128, 160, 2, 2, MODE, EPI, 2, 128, true>(p, batch, st);
     }

@@ -55,7 +55,9 @@ int fyc_device_caps(int64_t* caps);
  * key 11 = v > 0: every other GEMM block of an XCD starts v x 1024 cycles late (phase shift between the CUs' epilogues, A/B);
  * key 12 = 1: the GEMM epilogues load their per-row / per-column inputs themselves instead of finding them pre-staged in LDS (A/B);
  * key 13 = 1: the generic pass 1 of the packed LINEAR epilogue instead of its specialised copies (A/B);
- * keys 14..15 reserved */
+ * key 14 = 1: the 32x32x16 matrix instruction in the K loop of the 256-row tiles (tile configs 12 / 13 / 14 = twins of 5 / 7 / 3) - only in a
+ * library built with -DFYC_GEMM_MI32 (measured 8-12 % slower, not part of the product library); key 15 = 1 / 2: the pack-first head-split
+ * epilogue on / off for every problem (default: M <= 8192 only) */
 int fyc_set_tuning(int key, int value);
 
 /* ---- GEMM / implicit-GEMM convolution --------------------------------------------------
