@@ -1444,6 +1444,17 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   // itself hipcc sinks the A reads between the MFMAs (6 reads - wait - 5 MFMA - [1 read - wait - 5 MFMA] x 3 on the 128x320 tile):
   // three exposed LDS round trips per 20 MFMAs, on both waves of a SIMD at once.
   constexpr bool FRAG_ALL = sizeof(T) == 2 && (WTM * WTN + WTM + WTN) * 4 <= 150;
+  // FRAG_ROW (round 6): the big tiles (256x320: 4 x 10 blocks per wave, 256x256: 8 x 4) have no room for all fragments of a k-step, and hipcc's
+  // own order was: the column fragments + A[0] - wait - one block row of MFMAs - [read A[i] - lgkmcnt(0) - one block row] x (WTM - 1): a FULL LDS round
+  // trip exposed in front of every block row but the first, 8 per K tile and wave on the 256x320 tile (profiles/r06_gemm_row_prefetch_ab.txt).  Now the
+  // row fragments run PF block rows ahead in a small register ring (PF x WTN x 16 matrix cycles >= ~250), pinned by scheduling fences: the wait in
+  // front of block row i is lgkmcnt(PF) and only the first read batch of a k-step is exposed.
+#ifdef FYC_NO_FRAG_ROW
+  constexpr bool FRAG_ROW = false;
+#else
+  constexpr bool FRAG_ROW = sizeof(T) == 2 && !FRAG_ALL && !M32;
+#endif
+  constexpr int PF = (WTN >= 8) ? 2 : (WTN >= 4 ? 4 : 6);      // block rows of read-ahead
   auto compute = [&](int stage, int s0, int s1) {     // MFMA k-steps [s0, s1) of one staged K tile
     const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * RB;
     const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * RB;
@@ -1451,6 +1462,23 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
     for (int s = 0; s < KSTEPS; ++s) {
       if (s < s0 || s >= s1) continue;
       const int coff = ((4 * s + g) ^ sw) * 16;
+      if constexpr (FRAG_ROW) {
+        constexpr int RING = PF + 1;
+        Frag bfr[WTN], ar[RING];
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) bfr[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * RB + coff);
+#pragma unroll
+        for (int i = 0; i < PF && i < WTM; ++i) ar[i % RING] = *reinterpret_cast<const Frag*>(sA + i * 16 * RB + coff);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+          if (i + PF < WTM) ar[(i + PF) % RING] = *reinterpret_cast<const Frag*>(sA + (i + PF) * 16 * RB + coff);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bfr[j], ar[i % RING], acc[i][j]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        continue;
+      }
       Frag af[WTM], bf[WTN];
 #pragma unroll
       for (int i = 0; i < WTM; ++i) af[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * RB + coff);
@@ -1463,6 +1491,42 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
         for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bf[j], af[i], acc[i][j]);
       if (FRAG_ALL) __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  // XSTEP (round 6): the small tiles (FRAG_ALL) have room for the fragments of BOTH k-steps of a K tile: the second step's reads are issued in
+  // front of the first step's matrix instructions, so one LDS round trip per K tile is exposed instead of two.
+  // (A/B, profiles/r06_gemm_row_prefetch_ab.txt: -DFYC_NO_XSTEP / -DFYC_NO_FRAG_ROW rebuild the round-5 orders)
+#ifdef FYC_NO_XSTEP
+  constexpr bool XSTEP = false;
+#else
+  constexpr bool XSTEP = FRAG_ALL && KSTEPS == 2 && !M32 && (WTM * WTN + 2 * (WTM + WTN)) * 4 <= 190;
+#endif
+  auto compute_xstep = [&](int stage, auto&& between) {
+    const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * RB;
+    const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * RB;
+    const int coff0 = (g ^ sw) * 16, coff1 = ((4 + g) ^ sw) * 16;
+    Frag af0[WTM], bf0[WTN], af1[WTM], bf1[WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) af0[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * RB + coff0);
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) bf0[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * RB + coff0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) af1[i] = *reinterpret_cast<const Frag*>(sA + i * 16 * RB + coff1);
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) bf1[j] = *reinterpret_cast<const Frag*>(sB + j * 16 * RB + coff1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bf0[j], af0[i], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    between();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bf1[j], af1[i], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
   };
   // 32x32x16 form: k32-step s = two k16-steps; lane (h = lane / 32, r32 = lane % 32) reads row r32 of a 32-row block, chunk 2 s' + h
   const int r32 = lane & 31, h32 = lane >> 5;
@@ -1623,9 +1687,13 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       // (one copy of the MFMA code, two of the issue block: the accumulators never cross a divergent join)
       const bool late = STAGGER && p.stagger && wave >= (WGM * WGN) / 2;
       if (!late && i_tile < nwork) issue_next();
-      if constexpr (M32) compute32(st_c, 0, 1); else compute(st_c, 0, 1);
-      if (late && i_tile < nwork) issue_next();
-      if constexpr (M32) compute32(st_c, 1, KSTEPS); else compute(st_c, 1, KSTEPS);
+      if constexpr (XSTEP) {
+        compute_xstep(st_c, [&]() { if (late && i_tile < nwork) issue_next(); });
+      } else {
+        if constexpr (M32) compute32(st_c, 0, 1); else compute(st_c, 0, 1);
+        if (late && i_tile < nwork) issue_next();
+        if constexpr (M32) compute32(st_c, 1, KSTEPS); else compute(st_c, 1, KSTEPS);
+      }
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     }
     if constexpr (M32) {      // 32x32 blocks -> the 16x16 layout every epilogue (and the split-K partial store) is written for

@@ -274,26 +274,36 @@ def dump(what, out=None, out_dir=None):
             unet = model(TRAJECTORIES["cfg3"]()[5] if "cfg3" in whats else Fn.UNetConfig())
             inp = W.seeded_inputs(Fn.UNetConfig(), 1, int(g["frames"]), int(g["h"]), int(g["w"]), seed=int(g["input_seed"]))
             x9 = torch.cat([Fn.build_model_input(inp["latents"], inp["first_image_latents"], inp["first_images_mask"])] * 2)
+            t_host = time.time() - t0
             with turn:
+                t1 = time.time()
                 unet.to(dev)
                 res = {name: forward(unet, x9, int(g["timestep"]), inp["text"], torch.from_numpy(g["fps"]), torch.from_numpy(g["flow"]), ac).cpu()
                        for name, ac in (("f32", None), ("bf16", torch.bfloat16), ("f16", torch.float16))}
+                t_dev = time.time() - t1
         else:
             frames, lat, num_steps, run_steps, seed, ocfg, mask, use_ip = TRAJECTORIES[w]()
             unet = model(ocfg)
             inp = W.seeded_inputs(ocfg, 1, frames, lat, lat, seed=seed)
             # (f32_steps < run_steps: the reference's f32 forward at 32f@768^2 takes ~50 s on the chip - eager kernels - and the f32 mode of the
             # engine is pinned at that shape by the stored golden of tests/test_fullwidth_gpu.py as well: one f32 step, two under autocast)
+            t_host = time.time() - t0
             with turn:
+                t1 = time.time()
                 unet.to(dev)
-                res = {name: reference_trajectory(unet, inp, num_steps, n, ac, mask=mask, ip_tokens=inp["ip_tokens"] if use_ip else None)
-                       for name, ac, n in (("bf16", torch.bfloat16, run_steps), ("f32", None, F32_STEPS.get(w, run_steps)))}
-                torch.cuda.synchronize()
+                res = {}
+                for name, ac, n in (("bf16", torch.bfloat16, run_steps), ("f32", None, F32_STEPS.get(w, run_steps))):
+                    t2 = time.time()
+                    res[name] = reference_trajectory(unet, inp, num_steps, n, ac, mask=mask, ip_tokens=inp["ip_tokens"] if use_ip else None)
+                    torch.cuda.synchronize()
+                    print(f"[gpu_reference] {w} {name}: {n} step(s) in {time.time() - t2:.1f} s", flush=True)
+                t_dev = time.time() - t1
         res["seconds"] = time.time() - t0
         path = out if (out and len(whats) == 1) else os.path.join(out_dir, w + ".pt")
         torch.save(res, path + ".tmp")
         os.replace(path + ".tmp", path)
-        print(f"[gpu_reference] {w}: {res['seconds']:.1f} s", flush=True)
+        res["seconds_host"], res["seconds_device"] = t_host, t_dev
+        print(f"[gpu_reference] {w}: {res['seconds']:.1f} s (host side {t_host:.1f} s, its turn on the chip {t_dev:.1f} s, the rest waiting for the turn)", flush=True)
 
 
 def rectangle_mask(lat):

@@ -173,6 +173,11 @@ def pytest_collection_finish(session):
         return
     out_dir = tempfile.mkdtemp(prefix="fyc_ref_")
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    # the host side of the subprocess (seeded weights of 1.28 B parameters, state-dict load) runs beside the tests: a bounded thread pool keeps it
+    # from taking the cores the tests' CPU oracles need (round 6: CPU-side tests ran 3-5x slower beside an unbounded one); MIOpen's fast find mode:
+    # the reference's F.conv2d calls are run once or twice per shape, an exhaustive search per shape is the larger part of their time
+    env.setdefault("OMP_NUM_THREADS", "16")
+    env.setdefault("MIOPEN_FIND_MODE", "FAST")
     log = open(os.path.join(out_dir, "log.txt"), "w")
     proc = subprocess.Popen([sys.executable, "-m", "oracle.gpu_reference", "--dump", ",".join(what), "--out-dir", out_dir], cwd=ROOT, env=env,
                             stdout=log, stderr=subprocess.STDOUT)
@@ -187,6 +192,11 @@ def pytest_sessionfinish(session, exitstatus):
             proc.wait()
         _REF_PROC["log"].close()
         import shutil
+        try:      # (what the reference side spent its time on: kept beside the parity report)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            shutil.copyfile(os.path.join(_REF_PROC["dir"], "log.txt"), os.path.join(ROOT, "gpurun_out", "reference_subprocess_log.txt"))
+        except OSError:
+            pass
         shutil.rmtree(_REF_PROC["dir"], ignore_errors=True)
         _REF_PROC.clear()
 

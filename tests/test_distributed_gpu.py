@@ -18,7 +18,7 @@ def test_bench_under_torch_distributed_run_on_one_gpu():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29781",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--frames", "2", "--size", "64", "--ddim-steps", "2",
-           "--no-cpu-baseline", "--no-roofline", "--no-gpu-reference"]
+           "--no-cpu-baseline", "--no-roofline", "--no-gpu-reference", "--no-parity", "--no-vae"]      # (the legs a default run adds are covered by the driver's own bench run)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -111,6 +111,17 @@ PY
       PROBE_SWEEP=1 PROBE_CFGS=${MI32_CFGS:-0,5,12,7,13,3,14} timeout 900 python tools/gemm_probe.py > $OUT/probe_mi32.txt 2>&1; grep -v amdgpu.ids $OUT/probe_mi32.txt | cut -c1-130 ;;
     mi32_probe)   # the probe alone
       PROBE_SWEEP=1 PROBE_CFGS=${MI32_CFGS:-0,5,12} timeout 900 python tools/gemm_probe.py > $OUT/probe_mi32_v2.txt 2>&1; grep -v amdgpu.ids $OUT/probe_mi32_v2.txt | cut -c1-130 ;;
+    libs_probe)   # cold-operand probe of several libraries: LIBS="a.so b.so" (first = reference), PROBE_CFGS as usual
+      for lib in ${LIBS}; do
+        echo "-- $lib"
+        FYC_LIB_PATH=$lib PROBE_SWEEP=1 PROBE_CFGS=${PROBE_CFGS:-0,5,6,7} timeout 600 python tools/gemm_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/probe_$(basename $lib .so).txt | cut -c1-110
+      done ;;
+    libs_bench)   # whole loop, per-shape, alternating over LIBS (2 passes)
+      for i in 1 2; do for lib in ${LIBS}; do
+        tag=$(basename $lib .so)_$i
+        FYC_LIB_PATH=$lib FYC_BENCH_SHAPES=$OUT/shapes_lib_$tag.txt timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-reference --no-parity --no-vae > $OUT/bench_lib_$tag.json 2> $OUT/bench_lib_$tag.err
+      done; done
+      benchline $OUT/bench_lib_*.json | tee $OUT/bench_libs.txt ;;
     keys_ab)      # in-pipeline per-shape times of the in-tree library under tuning keys (KEYS="12=1 13=1 12=1,13=1")
       for k in "" ${KEYS:-12=1 13=1}; do
         tag=$(echo "x$k" | tr '=,' '__')
