@@ -109,7 +109,7 @@ CASES = [  # (name, config kwargs, B, F, H, W)
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0].replace(" ", "_") for c in CASES])
-def test_forward_does_not_read_unwritten_memory(case, dtype, engines):
+def test_forward_does_not_read_unwritten_memory(case, dtype, engines, fullwidth):
     name, kw, B, F, H, W = case
     if dtype != torch.bfloat16 and not kw:
         pytest.skip("full width runs in the benchmarked precision only (f16 shares the kernels' templates, the f32 parity mode every epilogue / statistics "
@@ -119,7 +119,11 @@ def test_forward_does_not_read_unwritten_memory(case, dtype, engines):
         text_dim = kw["cross_attention_dim"]
     else:
         text_dim = 768
-    eng = engines(kw, dtype)
+    if kw:
+        eng = engines(kw, dtype)
+    else:       # the session's full-width engine (tests/conftest.py::fullwidth: packed once for test_fullwidth_gpu.py / test_reference_gpu.py)
+        from oracle import functional as Fn
+        eng = fullwidth.engine(Fn.UNetConfig(), UNet3DConfig(), dtype, seed=0)
     x, text = _inputs(B, F, H, W, 11)
     text = text[:, :, :text_dim].contiguous()
     a = _forward(eng, x, text, B, F, H, W, 0x00)
