@@ -861,23 +861,52 @@ __device__ __forceinline__ void load_residual_acc(const GemmP& p, f32x4 (&acc)[B
   const int g = lane >> 4, r16 = lane & 15;
   const T* R = reinterpret_cast<const T*>(p.residual);
   const T* zero = reinterpret_cast<const T*>(p.zero);
-  u32x2 raw[WTM][WTN];
+  // Round 6 (profiles/r06_gemm_phase_trace.txt: the gap between an epilogue and the next K loop is 3-4 k ticks without a residual, 17-27 k with one on the
+  // 256x320 tile): the loads above fetch what a lane owns - 8 bytes, and a load instruction 16 rows x 32 contiguous bytes.  Column blocks are now
+  // fetched in PAIRS with 16 bytes per lane (lane g of a row: columns 32 jp + 8 g .. + 7, i.e. 16 rows x 64 contiguous bytes per instruction, half as
+  // many instructions) and re-sorted in registers to the accumulator layout: (lane bit 5, lane bit 4, dword pair) = (block of the pair, half of the
+  // block, quarter of the half) must become (half, quarter, block) - v_permlane16_swap then v_permlane32_swap on the dword pairs (0, 2) and (1, 3).
+  // Same values, same conversion: bitwise the results of the 8-byte form (-DFYC_RES_LOAD8 rebuilds it).
+#ifdef FYC_RES_LOAD8
+  constexpr int NP = 0;
+#else
+  constexpr int NP = WTN / 2;                          // column-block pairs; an odd last block keeps the 8-byte form
+#endif
+  u32x4 raw16[WTM][NP > 0 ? NP : 1];
+  u32x2 raw[WTM][WTN - 2 * NP > 0 ? WTN - 2 * NP : 1];
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
     const int m = tile_m * BM + (wm * WTM + i) * 16 + r16;
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) {
+    for (int jp = 0; jp < NP; ++jp) {
+      const int n = tile_n * BN + (wn * WTN + 2 * jp) * 16 + g * 8;
+      const T* ptr = (m < p.M && n < p.N) ? R + ((long long)m * p.ldr + n) : zero;      // (host: N % 8 == 0, ldr % 8 == 0, 16-byte aligned base)
+      raw16[i][jp] = *reinterpret_cast<const u32x4*>(ptr);
+    }
+#pragma unroll
+    for (int j = 2 * NP; j < WTN; ++j) {
       const int n = tile_n * BN + (wn * WTN + j) * 16 + g * 4;
       const T* ptr = (m < p.M && n < p.N) ? R + ((long long)m * p.ldr + n) : zero;
-      raw[i][j] = *reinterpret_cast<const u32x2*>(ptr);
+      raw[i][j - 2 * NP] = *reinterpret_cast<const u32x2*>(ptr);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < WTM; ++i)
+  for (int i = 0; i < WTM; ++i) {
 #pragma unroll
-    for (int j = 0; j < WTN; ++j)
-      acc[i][j] = (f32x4){Pair16<T>::lo(raw[i][j][0]), Pair16<T>::hi(raw[i][j][0]), Pair16<T>::lo(raw[i][j][1]), Pair16<T>::hi(raw[i][j][1])};
+    for (int jp = 0; jp < NP; ++jp) {
+      unsigned x0 = raw16[i][jp][0], x1 = raw16[i][jp][1], y0 = raw16[i][jp][2], y1 = raw16[i][jp][3];
+      auto a = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+      auto b = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+      auto c = __builtin_amdgcn_permlane32_swap(a[0], a[1], false, false);
+      auto d = __builtin_amdgcn_permlane32_swap(b[0], b[1], false, false);
+      acc[i][2 * jp] = (f32x4){Pair16<T>::lo(c[0]), Pair16<T>::hi(c[0]), Pair16<T>::lo(d[0]), Pair16<T>::hi(d[0])};
+      acc[i][2 * jp + 1] = (f32x4){Pair16<T>::lo(c[1]), Pair16<T>::hi(c[1]), Pair16<T>::lo(d[1]), Pair16<T>::hi(d[1])};
+    }
+#pragma unroll
+    for (int j = 2 * NP; j < WTN; ++j)
+      acc[i][j] = (f32x4){Pair16<T>::lo(raw[i][j - 2 * NP][0]), Pair16<T>::hi(raw[i][j - 2 * NP][0]), Pair16<T>::lo(raw[i][j - 2 * NP][1]), Pair16<T>::hi(raw[i][j - 2 * NP][1])};
+  }
 }
 
 // ---- epilogue: lane holds out[m][n0 .. n0+3] per (i, j).
