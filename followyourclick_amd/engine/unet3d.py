@@ -191,29 +191,7 @@ class UNet3DEngine(EngineBase):
         self.ops.row_stats(x, st, rows=rows, C_=C, eps=eps)
         return st
 
-    # ---- fused statistics ------------------------------------------------------------------------
-    def _cs_plan(self, rows: int, rows_per_sample: int, N: int, K: int, mode: int):
-        """row-tile partial buffer for the producer's epilogue: (parts, tile_rows, slots), or None when the shape cannot be fused
-        (rows per frame not a multiple of 16, or a row tile would touch more than 4 frames)"""
-        if not self.fuse_stats or rows_per_sample % 16 or rows % rows_per_sample:
-            return None
-        # small M, long K - the 8x8 latents - run split-K: since round 6 (ABI 301) its finish kernel writes the same partial sums and
-        # fyc_gemm_stat_layout answers for it; an older A/B library (FYC_LIB_PATH) keeps the separate statistics pass
-        if getattr(self.ops, "abi_version", 301) < 301 and self.ops.gemm_split_bytes(self.dtype, M=rows, N=N, K=K, mode=mode) > 0:
-            return None
-        nt, tile_rows, slots = self.ops.gemm_stat_layout(self.dtype, M=rows, N=N, K=K, cs_rows=rows_per_sample, mode=mode)
-        if not 1 <= slots <= 4:
-            return None
-        return self.new(nt * slots * N * 2, dtype=torch.float32), tile_rows, slots
-
-    def _cs_finish(self, plan, rows: int, rows_per_sample: int, N: int, out_rows: int) -> Tensor:
-        """per-(GroupNorm sample, channel) f64 sums from the epilogue's row-tile partials; out_rows = rows of the consuming
-        norm's sample (a frame, or the F frames of a clip)"""
-        parts, tile_rows, slots = plan
-        cs = self.new(rows // out_rows, N, 2, dtype=torch.float64)
-        self.ops.chan_stats_reduce(parts, cs, rows=rows, N=N, cs_rows=rows_per_sample, tile_rows=tile_rows, slots=slots, out_rows=out_rows)
-        return cs
-
+    # ---- fused statistics: _cs_plan / _cs_finish live in EngineBase (the VAE engines use them too) ----------------------------------------
     def _gn(self, x: Union[Act, Tuple[Act, Act]], gamma: Tensor, beta: Tensor, rows: int, rows_per_sample: int, eps: float,
             silu: bool) -> Tuple[Tensor, Optional[Tensor]]:
         """GroupNorm (+SiLU) of an activation or of the channel concat of two (up blocks: cat([hidden, skip], dim=1),

@@ -8,6 +8,8 @@ decodes one frame per call; here all frames of a chunk go through the same launc
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib as L
@@ -15,6 +17,8 @@ from .. import ops as ops_mod
 from .base import EngineBase
 from .config import VAEDecoderConfig
 from .weights import Packed, pad_channels
+
+FUSE_STATS = os.environ.get("FYC_VAE_FUSE_STATS", "1") != "0"      # GroupNorm statistics from the producing convolution's epilogue (A/B switch)
 
 Tensor = torch.Tensor
 
@@ -29,20 +33,40 @@ class VAEDecoderEngine(EngineBase):
         self.groups = self.cfg.norm_num_groups
         self.ops.ensure_init(self.device)
 
-    def resnet(self, r: Packed, x: Tensor, frames: int, H: int, W: int) -> Tensor:
-        rows, hw = frames * H * W, H * W
-        h = self.group_norm(x, r.n1_g, r.n1_b, rows, r.cin, hw, 1e-6, True)
-        h = self.conv(h, r.c1_w, r.c1_b, frames, H, W)
-        h = self.group_norm(h, r.n2_g, r.n2_b, rows, r.cout, hw, 1e-6, True)
-        sc = self.lin(x, r.sc_w, rows, bias=r.sc_b) if r.sc_w is not None else x
-        return self.conv(h, r.c2_w, r.c2_b, frames, H, W, residual=sc)
+    # ---- GroupNorm statistics from the producing convolution's epilogue (round 6: the decode used to run a statistics pass over every
+    # GroupNorm input - 30 passes, 3.3 of 49 ms per 16-frame chunk at 512^2; the UNet engine has taken them from the epilogues since round 2) ----
+    def conv_cs(self, x: Tensor, w: Tensor, b: Tensor, frames: int, Hin: int, Win: int, **kw):
+        """a 3x3 convolution whose output feeds a per-frame GroupNorm -> (output, per-(frame, channel) sums or None)"""
+        Cout, K = w.shape
+        up2, stride, pad = kw.get("up2", False), kw.get("stride", 1), kw.get("pad", 1)
+        Ho, Wo = (2 * Hin, 2 * Win) if up2 else ((Hin + pad - 2) // stride + 1, (Win + pad - 2) // stride + 1)
+        rows, hw = frames * Ho * Wo, Ho * Wo
+        plan = self._cs_plan(rows, hw, Cout, K, L.GEMM_CONV3X3_UP2 if up2 else L.GEMM_CONV3X3) if FUSE_STATS else None
+        out = self.conv(x, w, b, frames, Hin, Win, chan_parts=None if plan is None else plan[0], cs_rows=hw if plan is not None else 0, **kw)
+        return out, (None if plan is None else self._cs_finish(plan, rows, hw, Cout, hw))
 
-    def attention(self, a: Packed, x: Tensor, frames: int, H: int, W: int) -> Tensor:
+    def gn(self, x: Tensor, cs, g: Tensor, b: Tensor, rows: int, C: int, hw: int, silu: bool) -> Tensor:
+        if cs is None:
+            return self.group_norm(x, g, b, rows, C, hw, 1e-6, silu)
+        y = self.new(rows, C)
+        self.ops.gn_apply_cs(x, cs, g, b, y, rows=rows, C1=C, groups=self.groups, rows_per_sample=hw, eps=1e-6, silu=silu, cs_rows=hw)
+        return y
+
+    def resnet(self, r: Packed, x: Tensor, frames: int, H: int, W: int, cs=None):
+        """-> (output, its per-(frame, channel) sums or None); `cs`: the sums of x when its producer wrote them"""
+        rows, hw = frames * H * W, H * W
+        h = self.gn(x, cs, r.n1_g, r.n1_b, rows, r.cin, hw, True)
+        h, cs1 = self.conv_cs(h, r.c1_w, r.c1_b, frames, H, W)
+        h = self.gn(h, cs1, r.n2_g, r.n2_b, rows, r.cout, hw, True)
+        sc = self.lin(x, r.sc_w, rows, bias=r.sc_b) if r.sc_w is not None else x
+        return self.conv_cs(h, r.c2_w, r.c2_b, frames, H, W, residual=sc)
+
+    def attention(self, a: Packed, x: Tensor, frames: int, H: int, W: int, cs=None) -> Tensor:
         """single head, d = C (512): scores materialised through the batched GEMM, softmax in f32"""
         o = self.ops
         rows, N = frames * H * W, H * W
         C = a.o_w.shape[0]
-        h = self.group_norm(x, a.g, a.b, rows, C, N, 1e-6, False)
+        h = self.gn(x, cs, a.g, a.b, rows, C, N, False)
         ld = ((N + 7) // 8) * 8
         q, k = self.new(frames, 1, N, C), self.new(frames, 1, N, C)
         vt = self.zeros(frames, 1, C, ld) if ld != N else self.new(frames, 1, C, ld)
@@ -68,18 +92,18 @@ class VAEDecoderEngine(EngineBase):
         o.nchw_to_nhwc(z, x, N=N, C_=Cz, HW=H * W, c_pad=cp, scale=1.0 / cfg.scaling_factor)
         y = self.zeros(N * H * W, cp)
         o.gemm(x, P.pq_w, y, M=N * H * W, N=Cz, K=cp, lda=cp, ldw=cp, ldo=cp, bias=P.pq_b)   # post_quant_conv (1x1)
-        x = self.conv(y, P.conv_in_w, P.conv_in_b, N, H, W)
-        x = self.resnet(P.mid_r0, x, N, H, W)
-        x = self.attention(P.attn, x, N, H, W)
-        x = self.resnet(P.mid_r1, x, N, H, W)
+        x, cs = self.conv_cs(y, P.conv_in_w, P.conv_in_b, N, H, W)
+        x, cs = self.resnet(P.mid_r0, x, N, H, W, cs)
+        x = self.attention(P.attn, x, N, H, W, cs)          # (its output projection writes no sums: mid_r1's first norm runs the statistics pass)
+        x, cs = self.resnet(P.mid_r1, x, N, H, W)
         for blk in P.ups:
             for r in blk.resnets:
-                x = self.resnet(r, x, N, H, W)
+                x, cs = self.resnet(r, x, N, H, W, cs)
             if blk.up is not None:
-                x = self.conv(x, blk.up.w, blk.up.b, N, H, W, up2=True)
+                x, cs = self.conv_cs(x, blk.up.w, blk.up.b, N, H, W, up2=True)
                 H, W = 2 * H, 2 * W
         c0 = cfg.block_out_channels[0]
-        h = self.group_norm(x, P.out_g, P.out_b, N * H * W, c0, H * W, 1e-6, True)
+        h = self.gn(x, cs, P.out_g, P.out_b, N * H * W, c0, H * W, True)
         Co = cfg.out_channels
         ldo = ((Co + 3) // 4) * 4
         img = self.new(N * H * W, ldo)
@@ -115,18 +139,18 @@ class VAEEncoderEngine(VAEDecoderEngine):
         cp = pad_channels(Ci)
         h = self.new(N * H * W, cp)
         o.nchw_to_nhwc(x, h, N=N, C_=Ci, HW=H * W, c_pad=cp, scale=1.0)
-        h = self.conv(h, P.conv_in_w, P.conv_in_b, N, H, W)
+        h, cs = self.conv_cs(h, P.conv_in_w, P.conv_in_b, N, H, W)
         for blk in P.downs:
             for r in blk.resnets:
-                h = self.resnet(r, h, N, H, W)
+                h, cs = self.resnet(r, h, N, H, W, cs)
             if blk.down is not None:
-                h = self.conv(h, blk.down.w, blk.down.b, N, H, W, stride=2, pad=0)
+                h, cs = self.conv_cs(h, blk.down.w, blk.down.b, N, H, W, stride=2, pad=0)
                 H, W = H // 2, W // 2
-        h = self.resnet(P.mid_r0, h, N, H, W)
-        h = self.attention(P.attn, h, N, H, W)
-        h = self.resnet(P.mid_r1, h, N, H, W)
+        h, cs = self.resnet(P.mid_r0, h, N, H, W, cs)
+        h = self.attention(P.attn, h, N, H, W, cs)
+        h, cs = self.resnet(P.mid_r1, h, N, H, W)
         c = cfg.block_out_channels[-1]
-        h = self.group_norm(h, P.out_g, P.out_b, N * H * W, c, H * W, 1e-6, True)
+        h = self.gn(h, cs, P.out_g, P.out_b, N * H * W, c, H * W, True)
         C2 = 2 * cfg.latent_channels
         cp2 = pad_channels(C2)
         z = self.zeros(N * H * W, cp2)                      # conv_out into a zero-padded row so quant_conv (1x1) can read 128-B K tiles
