@@ -1484,7 +1484,14 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
   constexpr bool FRAG_ROW = sizeof(T) == 2 && !FRAG_ALL && !M32;
 #endif
   constexpr int PF = (WTN >= 8) ? 2 : (WTN >= 4 ? 4 : 6);      // block rows of read-ahead
-  auto compute = [&](int stage, int s0, int s1) {     // MFMA k-steps [s0, s1) of one staged K tile
+  // FYC_LATE_POS (A/B, round 6): where the late half of the waves issues its DMAs - 0 (default): between the two k-steps; r > 0: inside the
+  // SECOND k-step, behind block row r - 1 (FRAG_ROW tiles only; the callback `mid` of compute())
+#ifndef FYC_LATE_POS
+#define FYC_LATE_POS 0
+#endif
+  constexpr int LATE_ROW = (FRAG_ROW && FYC_LATE_POS > 0 && FYC_LATE_POS < WTM) ? FYC_LATE_POS : 0;
+  auto no_mid = []() {};
+  auto compute = [&](int stage, int s0, int s1, auto&& mid) {     // MFMA k-steps [s0, s1) of one staged K tile
     const char* sA = smem + stage * STAGE + (wm * WTM * 16 + r16) * RB;
     const char* sB = smem + stage * STAGE + A_BYTES + (wn * WTN * 16 + r16) * RB;
 #pragma unroll
@@ -1505,6 +1512,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
 #pragma unroll
           for (int j = 0; j < WTN; ++j) acc[i][j] = Tr::mma(bfr[j], ar[i % RING], acc[i][j]);
           __builtin_amdgcn_sched_barrier(0);
+          if (LATE_ROW > 0 && s == KSTEPS - 1 && i == LATE_ROW - 1) { mid(); __builtin_amdgcn_sched_barrier(0); }
         }
         continue;
       }
@@ -1719,9 +1727,9 @@ __global__ void __launch_bounds__(WGM* WGN * 64) fyc_gemm_kernel(const GemmP p) 
       if constexpr (XSTEP) {
         compute_xstep(st_c, [&]() { if (late && i_tile < nwork) issue_next(); });
       } else {
-        if constexpr (M32) compute32(st_c, 0, 1); else compute(st_c, 0, 1);
-        if (late && i_tile < nwork) issue_next();
-        if constexpr (M32) compute32(st_c, 1, KSTEPS); else compute(st_c, 1, KSTEPS);
+        if constexpr (M32) compute32(st_c, 0, 1); else compute(st_c, 0, 1, no_mid);
+        if (LATE_ROW == 0 && late && i_tile < nwork) issue_next();
+        if constexpr (M32) compute32(st_c, 1, KSTEPS); else compute(st_c, 1, KSTEPS, [&]() { if (late && i_tile < nwork) issue_next(); });
       }
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     }
